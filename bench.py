@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Benchmark of the layout-conditioned denoising hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one pass of the hot path over one batch of synthetic input = a complete 50-step PLMS
+denoise (CFG 7.5, alpha_type [0.3,0,0.7] -> 102 UNet evaluations per image, run as 51 evaluations of
+the 2B [cond;uncond] batch) of B=4 latents of 4x64x64 with 8 grounding boxes per image: BASELINE.json
+configs[1] "1xMI355X, 512x512, 50 PLMS steps, batch=4, 8 grounding boxes per image, fp16".
+Weights are random (recipe scaling; no checkpoint exists offline), inputs synthetic and resident in
+HBM before the timed region.  value = images/s over all ranks (weak scaling: 4 images per GPU per step).
+
+Extra objects in the JSON line:
+  roofline      whole-UNet-forward MFMA roofline: algorithmic FLOPs of the forwards executed in the
+                timed region (F_full = 1.1477 TFLOP / sample-forward with the fuser,
+                F_off = 0.8141 TFLOP when the sampler's scale-0 skips it) / HIP-event time of those
+                forward launches (graph replays) vs the 2.5 PFLOP/s dense fp16 MFMA peak.
+  cpu_baseline  the fp32 oracle (CPU restatement of the reference UNet, oracle/unet_ref.py) timed on
+                this box's host cores on a bounded sample (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+F_FULL = 1.1477e12      # algorithmic FLOPs / sample-forward, 64x64 latent, fuser on   
+F_OFF = 0.8141e12       # ... with the gated-SA fuser exactly skipped (scale == 0)
+MFMA_PEAK_TFLOPS = 2500.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=4, help="images per GPU per step (config 2: 4)")
+    ap.add_argument("--latent", type=int, default=64, help="latent side (64 = 512x512)")
+    ap.add_argument("--plms-steps", type=int, default=50)
+    ap.add_argument("--boxes", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tiny", action="store_true", help="debug: tiny UNet (not a valid benchmark)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from layoutllm_t2i_amd import recipe
+    from layoutllm_t2i_amd.arch import TINY, UNetConfig
+    from layoutllm_t2i_amd.dist import broadcast_packed
+    from layoutllm_t2i_amd.engine import UNetEngine
+    from layoutllm_t2i_amd.interface import denoise
+    from layoutllm_t2i_amd.model import GroundingNetInput, LatentDiffusion, UNetModel
+    from layoutllm_t2i_amd.weights import pack_state_dict, random_state_dict
+
+    cfg = TINY if args.tiny else UNetConfig()
+    B, side = args.batch, args.latent
+
+    # ---- weights: rank 0 builds + packs, one RCCL broadcast to the others (timed separately)
+    t0 = time.time()
+    sd_cpu_sample = None
+    packed = None
+    if rank == 0:
+        sd = random_state_dict(cfg, dev, seed=0)
+        fc = {"weight": torch.randn(cfg.model_channels, cfg.in_channels, 3, 3, device=dev) * 0.16,
+              "bias": torch.zeros(cfg.model_channels, device=dev)}
+        packed = pack_state_dict(sd, cfg, dev, fc)
+        if world == 1 and not args.no_cpu_baseline:
+            sd_cpu_sample = {k: v.cpu() for k, v in sd.items()}
+        del sd
+    bcast_ms = None
+    if world > 1:
+        torch.cuda.synchronize()
+        dist.barrier()
+        tb = time.time()
+        packed = broadcast_packed(packed, cfg, dev, src=0)
+        torch.cuda.synchronize()
+        dist.barrier()
+        bcast_ms = (time.time() - tb) * 1e3
+    model = UNetModel.__new__(UNetModel)
+    # assemble the facade around already-packed weights (UNetModel.__init__ packs from a state_dict)
+    model.cfg, model.device = cfg, dev
+    model.image_size, model.in_channels, model.out_channels, model.model_channels = cfg.image_size, cfg.in_channels, cfg.out_channels, cfg.model_channels
+    model.first_conv_restorable, model.first_conv_type = True, "GLIGEN"
+    model.grounding_tokenizer_input = GroundingNetInput()
+    model.fuser_scale, model.training, model._cond_key = 1.0, False, None
+    model.engine = UNetEngine(packed)
+    diffusion = LatentDiffusion(device=dev)
+    all_models = (model, None, None, diffusion, {})
+    setup_s = time.time() - t0
+
+    # ---- synthetic inputs, resident on the device (seed 1234 + rank)
+    inp = {k: torch.from_numpy(v).to(dev) for k, v in
+           recipe.synth_inputs(cfg, B, side, n_boxes=args.boxes, n_rel=3, seed=1234 + rank).items()}
+    batch = dict(boxes=inp["boxes"], masks=inp["masks"], text_embeddings=inp["positive_embeddings"])
+
+    # ---- HIP-event timing of every UNet forward launch (graph replay) on the launch stream
+    eng = model.engine
+    fwd_events = []
+    orig_forward = eng.forward
+
+    def timed_forward(x_lat, t, fuser_scale=1.0, sd_conv=False, reps=1, eps_out=None):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig_forward(x_lat, t, fuser_scale, sd_conv, reps, eps_out)
+        e1.record()
+        fwd_events.append((e0, e1, fuser_scale != 0, x_lat.shape[0] * reps))
+        return out
+    eng.forward = timed_forward
+
+    def one_step():
+        model.first_conv_type = "GLIGEN"
+        return denoise(all_models, inp["context"], inp["uc"], inp["relations"], batch, inp["x"], [0.3, 0.0, 0.7], 7.5,
+                       steps=args.plms_steps)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = one_step()
+    fwd_events.clear()
+    sync()
+    t1 = time.time()
+    for _ in range(args.steps):
+        out = one_step()
+    sync()
+    elapsed = time.time() - t1
+    assert torch.isfinite(out).all(), "non-finite latents"
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- roofline of the UNet forward (dominant launch)
+    flops = 0.0
+    gpu_ms = 0.0
+    for e0, e1, fuser_on, nsamp in fwd_events:
+        gpu_ms += e0.elapsed_time(e1)
+        flops += nsamp * (F_FULL if fuser_on else F_OFF)
+    n_fwd = len(fwd_events)
+    scale_flops = 1.0 if (side == 64 and not args.tiny) else float("nan")   # F_* are for the 64x64 full model only
+    achieved = flops * scale_flops / (gpu_ms * 1e-3) / 1e12 if gpu_ms > 0 else float("nan")
+    roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "launch": "UNet forward of the 2B=8 [cond;uncond] batch (one hipGraph replay)",
+                "launches": n_fwd, "avg_launch_ms": round(gpu_ms / max(n_fwd, 1), 3),
+                "flops_per_launch": round(flops / max(n_fwd, 1)), "flop_model": "SURVEY 8d minimal (32 F_full + 70 F_off per image)"}
+
+    images = args.steps * B * world
+    value = images / elapsed
+    result = {
+        "metric": "512x512 50-step images/sec (PLMS, CFG 7.5, layout-conditioned GLIGEN UNet)",
+        "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "fp16 (fp32 accumulate)", "data": "synthetic inputs, random-init weights of the reference architecture",
+        "config": {"workload": f"configs[1]: {side * 8}x{side * 8}, {args.plms_steps} PLMS steps, batch={B}/GPU, {args.boxes} grounding boxes/image, fp16",
+                   "images_per_gpu_per_step": B, "unet_forwards_per_image": 2 * (args.plms_steps + 1), "latent": [B, 4, side, side],
+                   "parallelism": f"replicas x{world}, one weight broadcast, no per-step collectives"},
+        "unet_step_ms": round(gpu_ms / max(n_fwd, 1), 3),
+        "images_per_sec_per_gpu": round(value / world, 4),
+        "roofline": roofline,
+        "setup_s": round(setup_s, 1),
+    }
+    if bcast_ms is not None:
+        result["weight_broadcast_ms"] = round(bcast_ms, 1)
+        result["weight_bytes"] = packed.nbytes()
+
+    # ---- CPU baseline: the oracle on the host cores, bounded sample (rank 0, N=1 only)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and sd_cpu_sample is not None:
+        from oracle import unet_ref
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        ci = {k: torch.from_numpy(v) for k, v in recipe.synth_inputs(cfg, 1, side, n_boxes=args.boxes, n_rel=3, seed=1234).items()}
+        with torch.no_grad():
+            tc = time.time()
+            unet_ref.unet_forward(sd_cpu_sample, cfg, ci["x"], torch.tensor([481]), ci["context"], ci["relations"], ci["boxes"],
+                                  ci["masks"], ci["positive_embeddings"])
+            t_fwd = time.time() - tc
+        per_image = t_fwd * 2 * (args.plms_steps + 1)
+        result["cpu_baseline"] = {"value": round(1.0 / per_image, 6), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+                                  "sample": f"1 conditional UNet forward, B=1, {side}x{side} latent, fp32 oracle: {t_fwd:.1f} s; x{2 * (args.plms_steps + 1)} forwards/image extrapolated",
+                                  "seconds_per_forward": round(t_fwd, 2)}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,137 @@
+"""ctypes binding of libgligen_hip.so (the C ABI declared in include/gligen_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or its ABI does not match, importing
+this module's ``lib()`` raises.  Struct layouts mirror include/gligen_hip.h and are size-checked
+against the library at load time.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgligen_hip.so")
+ABI_VERSION = 1
+
+# enum gl_epilogue / gl_out_mode
+EPI_BIAS, EPI_SILU, EPI_GEGLU, EPI_RES, EPI_GATE_RES, EPI_ROWBIAS = range(6)
+OUT_F16_ROWMAJOR, OUT_F32_NCHW = 0, 1
+
+vp = C.c_void_p
+i32 = C.c_int32
+i64 = C.c_int64
+f32 = C.c_float
+fp = C.c_void_p  # float* passed as raw address
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("a", vp), ("lda", i32),
+        ("a2", vp), ("lda2", i32), ("ksplit", i32),
+        ("w", vp),
+        ("bias", vp),
+        ("M", i32), ("N", i32), ("K", i32),
+        ("epi", i32),
+        ("out_mode", i32),
+        ("out", vp), ("ldc", i32),
+        ("res", vp), ("ldres", i32),
+        ("gate", vp),
+        ("rowbias", vp), ("ld_rowbias", i32), ("rows_per_sample", i32),
+        ("hw", i32),
+    ]
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [
+        ("inp", vp),
+        ("B", i32), ("Hin", i32), ("Win", i32), ("Cin", i32),
+        ("Hout", i32), ("Wout", i32),
+        ("stride", i32),
+        ("upsample2x", i32),
+        ("g", GemmArgs),
+    ]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [
+        ("q", vp), ("q_bstride", i64), ("ldq", i32),
+        ("k", vp), ("k_bstride", i64), ("ldk", i32),
+        ("vt", vp), ("ldvt", i32),
+        ("out", vp), ("o_bstride", i64), ("ldo", i32),
+        ("B", i32), ("H", i32), ("d", i32), ("Nq", i32), ("Nk", i32),
+        ("scale", f32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/gligen_hip.h declares
+PROTOTYPES = {
+    "gl_gemm": (i32, [C.POINTER(GemmArgs), vp]),
+    "gl_conv3x3": (i32, [C.POINTER(ConvArgs), vp]),
+    "gl_attention": (i32, [C.POINTER(AttnArgs), vp]),
+    "gl_transpose_v": (i32, [vp, i64, i32, vp, i32, i32, i32, i32, i32, vp]),
+    "gl_groupnorm_stats": (i32, [vp, i32, vp, i32, i32, i32, fp, i32, vp]),
+    "gl_groupnorm_apply": (i32, [vp, i32, vp, i32, i32, i32, fp, i32, fp, fp, f32, i32, vp, vp]),
+    "gl_layernorm": (i32, [vp, i32, vp, i32, fp, fp, i32, i32, i32, i32, i32, f32, vp]),
+    "gl_rela_pool": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp]),
+    "gl_rela_merge": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp]),
+    "gl_posnet_input": (i32, [fp, fp, fp, fp, fp, i32, i32, i32, vp, vp]),
+    "gl_timestep_embedding": (i32, [fp, i32, i32, vp, vp]),
+    "gl_silu_f16": (i32, [vp, vp, i64, vp]),
+    "gl_cfg_combine": (i32, [fp, f32, i64, fp, vp]),
+    "gl_plms_update": (i32, [fp, fp, fp, fp, fp, f32, f32, f32, f32, f32, f32, f32, f32, f32, i64, fp, vp]),
+    "gl_pack_latent": (i32, [fp, i32, i32, i32, i32, i32, vp, vp]),
+    "gl_abi_version": (i32, []),
+    "gl_sizeof_gemm_args": (i32, []),
+    "gl_sizeof_conv_args": (i32, []),
+    "gl_sizeof_attn_args": (i32, []),
+    "gl_init": (i32, []),
+}
+
+_lib = None
+_inited = False
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Loads (once) and returns the HIP library; raises HipLibraryError if it cannot be used."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} not found: build it with `python -m layoutllm_t2i_amd.csrc.build` "
+            "(or __graft_entry__.build()).  There is no CPU fallback for the denoising path.")
+    try:
+        l = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise HipLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(l, name)
+        except AttributeError as e:
+            raise HipLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if l.gl_abi_version() != ABI_VERSION:
+        raise HipLibraryError(f"ABI version mismatch: lib {l.gl_abi_version()} vs host {ABI_VERSION}")
+    for cls, fn in ((GemmArgs, l.gl_sizeof_gemm_args), (ConvArgs, l.gl_sizeof_conv_args), (AttnArgs, l.gl_sizeof_attn_args)):
+        if C.sizeof(cls) != fn():
+            raise HipLibraryError(f"struct size mismatch for {cls.__name__}: host {C.sizeof(cls)} vs lib {fn()}")
+    _lib = l
+    return l
+
+
+def init_device() -> None:
+    """One-time per-process device-side setup (needs a GPU)."""
+    global _inited
+    if not _inited:
+        check(lib().gl_init(), "gl_init")
+        _inited = True
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        raise HipLibraryError(f"{what} failed with code {code}" + (" (bad argument)" if code == -1 else ""))

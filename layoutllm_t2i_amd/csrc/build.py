@@ -1,0 +1,62 @@
+"""Builds libgligen_hip.so (gfx950) from the .hip sources in this directory, in-tree.
+
+    python -m layoutllm_t2i_amd.csrc.build [--force]
+
+hipcc cross-compiles for gfx950 without a GPU.  The resulting .so is git-ignored but travels to the
+GPU box with the repo snapshot.  No torch headers: the library only depends on the HIP runtime.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+REPO = os.path.dirname(PKG)
+SOURCES = ["gemm_conv.hip", "attention.hip", "norms.hip", "rela.hip", "misc.hip"]
+LIB = os.path.join(PKG, "libgligen_hip.so")
+OBJDIR = os.path.join(HERE, "build")
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (need ROCm's hipcc to build the gfx950 kernels)")
+
+
+def _newer(a: str, b: str) -> bool:
+    return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    hipcc = _hipcc()
+    os.makedirs(OBJDIR, exist_ok=True)
+    deps = [os.path.join(HERE, "common.h"), os.path.join(REPO, "include", "gligen_hip.h")]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(REPO, "include"), "-I" + HERE]
+
+    def compile_one(src: str) -> str:
+        s = os.path.join(HERE, src)
+        o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+        if force or _newer(s, o) or any(_newer(d, o) for d in deps):
+            cmd = [hipcc, *flags, "-c", s, "-o", o]
+            if verbose:
+                print("[build]", " ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+        return o
+
+    with ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    if force or any(_newer(o, LIB) for o in objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,46 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) kernels of the GLIGEN denoising path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 half_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 half2_t;
+typedef __attribute__((ext_vector_type(4))) _Float16 half4_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 half8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define GL_WAVE 64
+
+// v_mfma_f32_32x32x16_f16: D[i][j] += sum_k A[i][k] * B[j][k]   (both operands "row x k")
+//   operand fragment: lane l holds row (l & 31), k = 8*(l >> 5) + [0..7]   (8 halfs = 16 B)
+//   accumulator:      lane l, reg r holds D[i = (r&3) + 8*(r>>2) + 4*(l>>5)][j = l & 31]
+__device__ __forceinline__ f32x16 mfma32(half8_t a, half8_t b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// exact-erf GELU (torch F.gelu default; reference attention.py:45)
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ uint4 ld16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ void st16(void* p, uint4 v) { *reinterpret_cast<uint4*>(p) = v; }
+
+static inline int gl_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+#define GL_CHECK_LAUNCH()                                   \
+    do {                                                    \
+        hipError_t e__ = hipGetLastError();                 \
+        if (e__ != hipSuccess) return (int)e__;             \
+    } while (0)

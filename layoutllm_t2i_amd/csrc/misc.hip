@@ -1,0 +1,166 @@
+// Small kernels of the denoising path: grounding-token input (Fourier box embedding + null blend),
+// sinusoidal timestep embedding, SiLU, the PLMS/CFG latent update, latent packing, ABI introspection.
+#include "common.h"
+#include "gligen_hip.h"
+
+namespace {
+
+// text_grounding_net.py:30-41 + util.py:12-26.  One block per (b, i) row; out row = [in_dim | 8*num_freqs].
+// Fourier order: for each frequency f_j = 100^(j/num_freqs): sin(f_j * xyxy) (4) then cos(f_j * xyxy) (4).
+__global__ __launch_bounds__(256) void posnet_input_kernel(const float* __restrict__ boxes, const float* __restrict__ masks,
+                                                           const float* __restrict__ emb, const float* __restrict__ null_pos,
+                                                           const float* __restrict__ null_xyxy, int in_dim, int num_freqs,
+                                                           half_t* __restrict__ out) {
+    const int row = blockIdx.x;
+    const float m = masks[row];
+    const int pos_dim = num_freqs * 8;
+    half_t* o = out + (size_t)row * (in_dim + pos_dim);
+    for (int c = threadIdx.x; c < in_dim; c += 256) {
+        const float v = emb[(size_t)row * in_dim + c] * m + (1.0f - m) * null_pos[c];
+        o[c] = (half_t)v;
+    }
+    for (int c = threadIdx.x; c < pos_dim; c += 256) {
+        const int j = c / 8;
+        const int r = c - j * 8;
+        const int coord = r & 3;
+        const float freq = powf(100.0f, (float)j / (float)num_freqs);
+        const float arg = freq * boxes[(size_t)row * 4 + coord];
+        const float e = (r < 4) ? sinf(arg) : cosf(arg);
+        o[in_dim + c] = (half_t)(e * m + (1.0f - m) * null_xyxy[c]);
+    }
+}
+
+// util.py:161-181: [cos(t*w) | sin(t*w)], w_k = exp(-ln(10000) * k / half)
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, int dim, half_t* __restrict__ out) {
+    const int b = blockIdx.x;
+    const int half_dim = dim / 2;
+    for (int k = threadIdx.x; k < half_dim; k += blockDim.x) {
+        const float w = expf(-9.210340371976184f * (float)k / (float)half_dim);
+        const float a = t[b] * w;
+        out[(size_t)b * dim + k] = (half_t)cosf(a);
+        out[(size_t)b * dim + half_dim + k] = (half_t)sinf(a);
+    }
+    if ((dim & 1) && threadIdx.x == 0) out[(size_t)b * dim + dim - 1] = (half_t)0.0f;
+}
+
+__global__ void silu_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, size_t nvec) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+        uint4 raw = ld16(x + i * 8);
+        const half8_t v = *reinterpret_cast<half8_t*>(&raw);
+        half8_t o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (half_t)silu_f((float)v[j]);
+        st16(y + i * 8, *reinterpret_cast<uint4*>(&o));
+    }
+}
+
+// The sampler arithmetic follows the reference's operation order with contraction disabled so that,
+// given identical eps, x_prev is bit-identical to torch fp32 (plms.py:123,126-161).
+#pragma clang fp contract(off)
+__global__ void cfg_combine_kernel(const float* __restrict__ eps2b, float guidance, size_t n, float* __restrict__ e) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float ec = eps2b[i];
+        const float eu = eps2b[n + i];
+        e[i] = eu + guidance * (ec - eu);
+    }
+}
+
+__global__ void plms_update_kernel(const float* __restrict__ x, const float* __restrict__ e, const float* __restrict__ e1,
+                                   const float* __restrict__ e2, const float* __restrict__ e3, float c0, float c1,
+                                   float c2, float c3, float div, float sqrt_at, float s1m, float sqrt_aprev,
+                                   float dir_coef, size_t n, float* __restrict__ x_prev) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        // e' : (c0*e + c1*e1 + c2*e2 + c3*e3) / div, left to right as plms.py:146-159 writes it
+        float ep = c0 * e[i];
+        if (e1) ep = ep + c1 * e1[i];
+        if (e2) ep = ep + c2 * e2[i];
+        if (e3) ep = ep + c3 * e3[i];
+        ep = ep / div;
+        const float pred_x0 = (x[i] - s1m * ep) / sqrt_at;
+        const float dir_xt = dir_coef * ep;
+        x_prev[i] = sqrt_aprev * pred_x0 + dir_xt;
+    }
+}
+#pragma clang fp contract(fast)
+
+// x fp32 [B, C, hw] -> fp16 [reps*B, hw, Cpad]
+__global__ void pack_latent_kernel(const float* __restrict__ x, int B, int C, int hw, int Cpad, int reps,
+                                   half_t* __restrict__ out) {
+    const size_t total = (size_t)reps * B * hw * Cpad;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cpad);
+        const size_t t = i / Cpad;
+        const int p = (int)(t % hw);
+        const int rb = (int)(t / hw);
+        const int b = rb % B;
+        float v = 0.0f;
+        if (c < C) v = x[((size_t)b * C + c) * hw + p];
+        out[i] = (half_t)v;
+    }
+}
+
+int ew_blocks(size_t n) {
+    size_t b = (n + 255) / 256;
+    return (int)(b > 2048 ? 2048 : (b == 0 ? 1 : b));
+}
+
+}  // namespace
+
+extern "C" int gl_posnet_input(const float* boxes, const float* masks, const float* emb, const float* null_pos,
+                               const float* null_xyxy, int32_t rows, int32_t in_dim, int32_t num_freqs, void* out,
+                               void* stream) {
+    if (!boxes || !masks || !emb || !null_pos || !null_xyxy || !out || rows <= 0) return GL_ERR_BAD_ARG;
+    posnet_input_kernel<<<dim3(rows), dim3(256), 0, (hipStream_t)stream>>>(boxes, masks, emb, null_pos, null_xyxy, in_dim,
+                                                                           num_freqs, reinterpret_cast<half_t*>(out));
+    GL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gl_timestep_embedding(const float* t, int32_t B, int32_t dim, void* out, void* stream) {
+    if (!t || !out || B <= 0 || dim <= 0) return GL_ERR_BAD_ARG;
+    timestep_embedding_kernel<<<dim3(B), dim3(256), 0, (hipStream_t)stream>>>(t, dim, reinterpret_cast<half_t*>(out));
+    GL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gl_silu_f16(const void* x, void* y, int64_t n, void* stream) {
+    if (!x || !y || n <= 0 || (n % 8)) return GL_ERR_BAD_ARG;
+    silu_kernel<<<dim3(ew_blocks((size_t)n / 8)), dim3(256), 0, (hipStream_t)stream>>>(
+        reinterpret_cast<const half_t*>(x), reinterpret_cast<half_t*>(y), (size_t)n / 8);
+    GL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gl_cfg_combine(const float* eps2b, float guidance, int64_t n, float* e_out, void* stream) {
+    if (!eps2b || !e_out || n <= 0) return GL_ERR_BAD_ARG;
+    cfg_combine_kernel<<<dim3(ew_blocks((size_t)n)), dim3(256), 0, (hipStream_t)stream>>>(eps2b, guidance, (size_t)n, e_out);
+    GL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gl_plms_update(const float* x, const float* e, const float* e1, const float* e2, const float* e3, float c0,
+                              float c1, float c2, float c3, float div, float sqrt_at, float s1m, float sqrt_aprev,
+                              float dir_coef, int64_t n, float* x_prev, void* stream) {
+    if (!x || !e || !x_prev || n <= 0) return GL_ERR_BAD_ARG;
+    plms_update_kernel<<<dim3(ew_blocks((size_t)n)), dim3(256), 0, (hipStream_t)stream>>>(
+        x, e, e1, e2, e3, c0, c1, c2, c3, div, sqrt_at, s1m, sqrt_aprev, dir_coef, (size_t)n, x_prev);
+    GL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gl_pack_latent(const float* x, int32_t B, int32_t C, int32_t hw, int32_t Cpad, int32_t reps, void* out,
+                              void* stream) {
+    if (!x || !out || B <= 0 || C <= 0 || hw <= 0 || Cpad < C || reps <= 0) return GL_ERR_BAD_ARG;
+    pack_latent_kernel<<<dim3(ew_blocks((size_t)reps * B * hw * Cpad)), dim3(256), 0, (hipStream_t)stream>>>(
+        x, B, C, hw, Cpad, reps, reinterpret_cast<half_t*>(out));
+    GL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gl_init_gemm(void);
+
+extern "C" int gl_abi_version(void) { return GL_ABI_VERSION; }
+extern "C" int gl_sizeof_gemm_args(void) { return (int)sizeof(gl_gemm_args); }
+extern "C" int gl_sizeof_conv_args(void) { return (int)sizeof(gl_conv_args); }
+extern "C" int gl_sizeof_attn_args(void) { return (int)sizeof(gl_attn_args); }
+extern "C" int gl_init(void) { return gl_init_gemm(); }

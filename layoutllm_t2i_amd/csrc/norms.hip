@@ -1,0 +1,227 @@
+// GroupNorm(32) (+SiLU, + two-source channel concat) and LayerNorm over token-major fp16 activations,
+// fp32 statistics.  Both are HBM-bound: 16-byte coalesced loads, per-thread partial sums, LDS / wave
+// shuffle reductions.
+//
+// GroupNorm32 (util.py:226-228, eps 1e-5) + SiLU feeds every ResBlock conv (openaimodel.py:155-157,
+// 180-181) and the out conv (:385-388); Normalize (attention.py:78-79, eps 1e-6) feeds proj_in.
+// In NHWC a group is C/32 contiguous channels of every pixel, so statistics are gathered in two
+// stages: gn_stats writes per-(sample, pixel-chunk, group) partial (sum, sumsq); gn_apply re-reduces
+// the partials of its sample (<= 64 chunks), then normalises.  The reduction order is fixed
+// (bitwise reproducible, no atomics).
+#include "common.h"
+#include "gligen_hip.h"
+
+namespace {
+
+__device__ __forceinline__ const half_t* src_ptr(const half_t* x1, int C1, const half_t* x2, int C2, size_t pix,
+                                                 int c, int* cl) {
+    // channel c of the virtual concat [x1 | x2] at flat pixel index `pix`
+    if (c < C1) { *cl = c; return x1 + pix * C1; }
+    *cl = c - C1;
+    return x2 + pix * C2;
+}
+
+// grid (nchunk, B); block 256.  thread -> fixed 8-channel vector(s), strided over the chunk's pixels.
+// Per-channel partial sums go to LDS as [pixel-lane][channel]; 32 threads then fold them per group in
+// a fixed order (bitwise reproducible).
+constexpr int GN_MAX_C = 2560;
+__global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict__ x1, int C1,
+                                                       const half_t* __restrict__ x2, int C2, int HW, int nchunk,
+                                                       float* __restrict__ partial) {
+    __shared__ float lsum[GN_MAX_C];
+    __shared__ float lsq[GN_MAX_C];
+    const int C = C1 + C2;
+    const int cpg = C / 32;
+    const int nvec = C / 8;
+    const int b = blockIdx.y;
+    const int chunk = blockIdx.x;
+    const int ppc = (HW + nchunk - 1) / nchunk;
+    const int p0 = chunk * ppc;
+    const int p1 = min(HW, p0 + ppc);
+
+    const int vlanes = min(nvec, 256);       // vectors handled side by side
+    const int nplanes = 256 / vlanes;        // pixel lanes (nplanes * C <= 2048 when nvec <= 256)
+    const int plane = threadIdx.x / vlanes;
+    const int v0 = threadIdx.x - plane * vlanes;
+    if (plane < nplanes) {
+        for (int vec = v0; vec < nvec; vec += vlanes) {
+            float s[8], ss[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s[j] = 0.0f; ss[j] = 0.0f; }
+            const int c = vec * 8;
+            for (int pix = p0 + plane; pix < p1; pix += nplanes) {
+                int cl;
+                const half_t* base = src_ptr(x1, C1, x2, C2, (size_t)b * HW + pix, c, &cl);
+                uint4 raw = ld16(base + cl);
+                const half8_t hv = *reinterpret_cast<half8_t*>(&raw);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float f = (float)hv[j];
+                    s[j] += f;
+                    ss[j] += f * f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                lsum[plane * C + c + j] = s[j];
+                lsq[plane * C + c + j] = ss[j];
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int g = threadIdx.x;
+        float s = 0.0f, ss = 0.0f;
+        for (int pl = 0; pl < nplanes; ++pl)
+            for (int cc = 0; cc < cpg; ++cc) {
+                s += lsum[pl * C + g * cpg + cc];
+                ss += lsq[pl * C + g * cpg + cc];
+            }
+        float* pp = partial + (((size_t)b * nchunk + chunk) * 32 + g) * 2;
+        pp[0] = s;
+        pp[1] = ss;
+    }
+}
+
+// grid (nblk, B); block 256: elementwise normalise (+SiLU) of the virtual concat into out [B, HW, C].
+__global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict__ x1, int C1,
+                                                       const half_t* __restrict__ x2, int C2, int HW, int nchunk,
+                                                       const float* __restrict__ partial,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float eps, int silu, half_t* __restrict__ out) {
+    __shared__ float mean_s[32], rstd_s[32];
+    const int C = C1 + C2;
+    const int cpg = C / 32;
+    const int nvec = C / 8;
+    const int b = blockIdx.y;
+    if (threadIdx.x < 32) {
+        float s = 0.0f, ss = 0.0f;
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const float* pp = partial + (((size_t)b * nchunk + ch) * 32 + threadIdx.x) * 2;
+            s += pp[0];
+            ss += pp[1];
+        }
+        const float n = (float)cpg * (float)HW;
+        const float mean = s / n;
+        float var = ss / n - mean * mean;
+        var = fmaxf(var, 0.0f);
+        mean_s[threadIdx.x] = mean;
+        rstd_s[threadIdx.x] = rsqrtf(var + eps);
+    }
+    __syncthreads();
+    const size_t total = (size_t)HW * nvec;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const size_t pix = idx / nvec;
+        const int vec = (int)(idx - pix * nvec);
+        const int c = vec * 8;
+        int cl;
+        const half_t* base = src_ptr(x1, C1, x2, C2, (size_t)b * HW + pix, c, &cl);
+        uint4 raw = ld16(base + cl);
+        const half8_t hv = *reinterpret_cast<half8_t*>(&raw);
+        half8_t ov;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int g = (c + j) / cpg;
+            float v = ((float)hv[j] - mean_s[g]) * rstd_s[g] * gamma[c + j] + beta[c + j];
+            if (silu) v = silu_f(v);
+            ov[j] = (half_t)v;
+        }
+        st16(out + ((size_t)b * HW + pix) * C + c, *reinterpret_cast<uint4*>(&ov));
+    }
+}
+
+// One wave per row; up to 4 x 8-channel vectors per lane (C <= 2048).
+__global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, int ldx, half_t* __restrict__ y,
+                                                        int ldy, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int nrows, int rows_in,
+                                                        int rows_out, int row_off, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const int nvec = C / 8;
+    const half_t* xr = x + (size_t)row * ldx;
+    half8_t v[4];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int vec = lane + 64 * i;
+        if (vec < nvec) {
+            uint4 raw = ld16(xr + vec * 8);
+            v[i] = *reinterpret_cast<half8_t*>(&raw);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += (float)v[i][j];
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float ss = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int vec = lane + 64 * i;
+        if (vec < nvec) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float dlt = (float)v[i][j] - mean;
+                ss += dlt * dlt;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)C + eps);
+    const int bidx = row / rows_in;
+    const int i_in = row - bidx * rows_in;
+    half_t* yr = y + ((size_t)bidx * rows_out + row_off + i_in) * ldy;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int vec = lane + 64 * i;
+        if (vec < nvec) {
+            half8_t ov;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = vec * 8 + j;
+                ov[j] = (half_t)(((float)v[i][j] - mean) * rstd * gamma[c] + beta[c]);
+            }
+            st16(yr + vec * 8, *reinterpret_cast<uint4*>(&ov));
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int gl_groupnorm_stats(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t B, int32_t HW,
+                                  float* partial, int32_t nchunk, void* stream) {
+    const int C = C1 + (x2 ? C2 : 0);
+    if (!x1 || !partial || C <= 0 || C > GN_MAX_C || (C % 32) || (C1 % 8) || (x2 && (C2 % 8)) || nchunk <= 0 || nchunk > HW)
+        return GL_ERR_BAD_ARG;
+    gn_stats_kernel<<<dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream>>>(
+        reinterpret_cast<const half_t*>(x1), C1, reinterpret_cast<const half_t*>(x2), x2 ? C2 : 0, HW, nchunk, partial);
+    GL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gl_groupnorm_apply(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t B, int32_t HW,
+                                  const float* partial, int32_t nchunk, const float* gamma, const float* beta,
+                                  float eps, int32_t silu, void* out, void* stream) {
+    const int C = C1 + (x2 ? C2 : 0);
+    if (!x1 || !partial || !gamma || !beta || !out || C <= 0 || (C % 32) || (C1 % 8) || (x2 && (C2 % 8)))
+        return GL_ERR_BAD_ARG;
+    const size_t total = (size_t)HW * (C / 8);
+    int nblk = (int)((total + 255) / 256);
+    if (nblk > 1024) nblk = 1024;
+    gn_apply_kernel<<<dim3(nblk, B), dim3(256), 0, (hipStream_t)stream>>>(
+        reinterpret_cast<const half_t*>(x1), C1, reinterpret_cast<const half_t*>(x2), x2 ? C2 : 0, HW, nchunk, partial,
+        gamma, beta, eps, silu, reinterpret_cast<half_t*>(out));
+    GL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gl_layernorm(const void* x, int32_t ldx, void* y, int32_t ldy, const float* gamma, const float* beta,
+                            int32_t B, int32_t rows_in, int32_t rows_out, int32_t row_off, int32_t C, float eps,
+                            void* stream) {
+    if (!x || !y || !gamma || !beta || C <= 0 || (C % 8) || C > 2048 || (ldx % 8) || (ldy % 8)) return GL_ERR_BAD_ARG;
+    const int nrows = B * rows_in;
+    if (nrows <= 0) return GL_ERR_BAD_ARG;
+    layernorm_kernel<<<dim3(gl_cdiv(nrows, 4)), dim3(256), 0, (hipStream_t)stream>>>(
+        reinterpret_cast<const half_t*>(x), ldx, reinterpret_cast<half_t*>(y), ldy, gamma, beta, nrows, rows_in,
+        rows_out, row_off, C, eps);
+    GL_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,276 @@
+"""Drop-in counterpart of ``GLIGEN/interface.py``: same function names, signatures, argument meaning
+and quirks, with the denoiser (UNet + PLMS) running on the MI355X HIP engine.
+
+    load_all_models(ckpt, device)                     interface.py:366-373
+    load_ckpt(ckpt_path, device)                      interface.py:78-101
+    generate_batch_images(all_models, captions, labels, bboxes, clip_model, clip_processor, device)  :551-570
+    generate_one_image(all_models, caption, label, bbox, clip_model, clip_processor, device)          :376-395
+    run_batch_images / run_one_image(all_models, args, meta, starting_noise, clip_model, clip_processor, device)
+    set_alpha_scale, alpha_generator, prepare_batch, prepare_batch_multiple, prepare_relation_phrases,
+    convert_xywh_to_ltrb, convert_xcycwh_to_ltrb
+
+``all_models`` stays the reference's 5-tuple ``(model, autoencoder, text_encoder, diffusion, config)``.
+``model`` is this package's UNetModel; ``autoencoder`` / ``text_encoder`` are whatever the caller
+provides with the reference's ``decode(z)`` / ``encode(list[str], return_pooler_output=...)`` methods
+(the reference's own CPU modules work unchanged -- VAE and CLIP are SURVEY 8f "next" rows, and the
+LLM / policy orchestration stays on the reference path by design).
+
+Preserved behaviour: alpha_type [0.3, 0, 0.7]; 50 PLMS steps; CFG 7.5; noise from the
+global CPU RNG ``torch.randn(bs, 4, 64, 64)``; ``generate_batch_images`` passes boxes through
+UNconverted while ``generate_one_image`` converts xywh -> ltrb; ``config.update(args)`` mutates the
+caller's dict; relation phrases are "PAD" + every relation twice, truncated to max_relations;
+clamp -> *0.5+0.5 -> *255 -> astype(uint8) truncation.
+"""
+from __future__ import annotations
+
+import os
+import warnings
+from functools import partial
+from typing import Union
+
+import numpy as np
+import torch
+
+from . import host
+from .arch import UNetConfig
+from .model import GroundingNetInput, LatentDiffusion, UNetModel, load_sd_first_conv
+from .sampler import PLMSSampler
+
+MAX_OBJS = 30
+PLMS_STEPS = 50
+
+
+def set_alpha_scale(model, alpha_scale):
+    """interface.py:34-38: only the gated self-attention fuser is scaled; rela_fuse.scale stays 1."""
+    model.fuser_scale = alpha_scale
+
+
+alpha_generator = host.alpha_generator
+
+
+class _AttrDict(dict):
+    """Enough of OmegaConf.create(dict) for run_*_images: attribute access on a dict."""
+    __getattr__ = dict.__getitem__
+
+
+def _instantiate_reference(config_node):
+    """instantiate_from_config (ldm/util.py:71-85) for the non-hot-path modules (VAE, CLIP text encoder):
+    resolved from whatever ``ldm`` package is importable (the reference's, on its CPU path)."""
+    import importlib
+    module, cls = config_node["target"].rsplit(".", 1)
+    return getattr(importlib.import_module(module), cls)(**config_node.get("params", dict()))
+
+
+def load_ckpt(ckpt_path, device="cuda"):
+    """interface.py:78-101.  The UNet ('model') is built by this package from saved_ckpt['model'];
+    autoencoder / text_encoder / grounding tokenizer are instantiated from the checkpoint's config."""
+    saved_ckpt = torch.load(ckpt_path, map_location="cpu")
+    config = saved_ckpt["config_dict"]["_content"]
+    cfg = UNetConfig.from_dict(config["model"]["params"])
+    sd_path = os.environ.get("GLIGEN_SD_FIRST_CONV",
+                             os.path.join(os.path.dirname(os.path.abspath(ckpt_path)), "SD_input_conv_weight_bias.pth"))
+    model = UNetModel(cfg, saved_ckpt["model"], device=device, sd_first_conv=load_sd_first_conv(sd_path))
+    dparams = config["diffusion"].get("params", {})
+    diffusion = LatentDiffusion(linear_start=dparams.get("linear_start", 0.00085), linear_end=dparams.get("linear_end", 0.012),
+                                timesteps=dparams.get("timesteps", 1000), device=device)
+    autoencoder = _instantiate_reference(config["autoencoder"]).to(device).eval()
+    text_encoder = _instantiate_reference(config["text_encoder"]).to(device).eval()
+    autoencoder.load_state_dict(saved_ckpt["autoencoder"])
+    text_encoder.load_state_dict(saved_ckpt["text_encoder"])
+    for m in (autoencoder, text_encoder):
+        if "device" in vars(m):
+            m.device = device
+    return model, autoencoder, text_encoder, diffusion, config
+
+
+def load_all_models(ckpt, device):
+    """interface.py:366-373."""
+    model, autoencoder, text_encoder, diffusion, config = load_ckpt(ckpt, device)
+    model.grounding_tokenizer_input = GroundingNetInput()
+    return model, autoencoder, text_encoder, diffusion, config
+
+
+def convert_xcycwh_to_ltrb(bbox):
+    xc, yc, w, h = bbox
+    return [xc - w / 2, yc - h / 2, xc + w / 2, yc + h / 2]
+
+
+def convert_xywh_to_ltrb(bbox):
+    x1, y1, w, h = bbox
+    return [x1, y1, x1 + w, y1 + h]
+
+
+def complete_mask(has_mask, max_objs):
+    mask = torch.ones(1, max_objs)
+    if has_mask is None:
+        return mask
+    if type(has_mask) == int or type(has_mask) == float:
+        return mask * has_mask
+    for idx, value in enumerate(has_mask):
+        mask[0, idx] = value
+    return mask
+
+
+def get_clip_feature(model, processor, input, device, is_image=False):
+    """interface.py:114-141, text branch ('before' projection = pooler_output).  Image grounding is
+    not on the text_layout path."""
+    if input is None:
+        return None
+    if is_image:
+        raise NotImplementedError("image grounding tokens are not on the text_layout path")
+    inputs = processor(text=input, return_tensors="pt", padding=True)
+    inputs["input_ids"] = inputs["input_ids"].to(device)
+    inputs["pixel_values"] = torch.ones(1, 3, 224, 224).to(device)
+    inputs["attention_mask"] = inputs["attention_mask"].to(device)
+    outputs = model(**inputs)
+    return outputs.text_model_output.pooler_output
+
+
+def _one_sample_grounding(phrases, locations, model, processor, max_objs, device):
+    boxes = torch.zeros(max_objs, 4)
+    masks = torch.zeros(max_objs)
+    text_masks = torch.zeros(max_objs)
+    image_masks = torch.zeros(max_objs)
+    text_embeddings = torch.zeros(max_objs, 768)
+    image_embeddings = torch.zeros(max_objs, 768)
+    feats = [get_clip_feature(model, processor, ph, device, is_image=False) for ph in phrases]
+    for idx, (box, feat) in enumerate(zip(locations, feats)):
+        boxes[idx] = torch.tensor(box)
+        masks[idx] = 1
+        if feat is not None:
+            text_embeddings[idx] = feat
+            text_masks[idx] = 1
+    return boxes, masks, text_masks, image_masks, text_embeddings, image_embeddings
+
+
+@torch.no_grad()
+def prepare_batch(meta, model, processor, batch=1, max_objs=MAX_OBJS, device=None):
+    """interface.py:156-193: one layout repeated `batch` times."""
+    boxes, masks, tm, im, te, ie = _one_sample_grounding(meta.get("phrases"), meta["locations"], model, processor, max_objs, device)
+    out = {
+        "boxes": boxes.unsqueeze(0).repeat(batch, 1, 1),
+        "masks": masks.unsqueeze(0).repeat(batch, 1),
+        "text_masks": tm.unsqueeze(0).repeat(batch, 1) * complete_mask(meta.get("text_mask"), max_objs),
+        "image_masks": im.unsqueeze(0).repeat(batch, 1) * complete_mask(meta.get("image_mask"), max_objs),
+        "text_embeddings": te.unsqueeze(0).repeat(batch, 1, 1),
+        "image_embeddings": ie.unsqueeze(0).repeat(batch, 1, 1),
+    }
+    return {k: v.to(device) for k, v in out.items()}
+
+
+@torch.no_grad()
+def prepare_batch_multiple(meta, model, processor, batch=1, max_objs=MAX_OBJS, device=None):
+    """interface.py:424-475: one layout per prompt."""
+    phrases_batch = meta.get("phrases")
+    assert batch == len(phrases_batch)
+    cols = [[] for _ in range(6)]
+    for i, phrases in enumerate(phrases_batch):
+        parts = _one_sample_grounding(phrases, meta["locations"][i], model, processor, max_objs, device)
+        parts = list(parts)
+        parts[2] = parts[2].unsqueeze(0) * complete_mask(meta.get("text_mask"), max_objs)
+        parts[3] = parts[3].unsqueeze(0) * complete_mask(meta.get("image_mask"), max_objs)
+        for j in (0, 1, 4, 5):
+            parts[j] = parts[j].unsqueeze(0)
+        for j in range(6):
+            cols[j].append(parts[j])
+    names = ("boxes", "masks", "text_masks", "image_masks", "text_embeddings", "image_embeddings")
+    return {n: torch.cat(c, dim=0).to(device) for n, c in zip(names, cols)}
+
+
+@torch.no_grad()
+def prepare_relation_phrases(prompt, batch_size=1, max_relas=5, text_encoder=None, device=None):
+    """interface.py:221-252: scene-graph triplets -> CLIP pooled embeddings, 'PAD' first, each relation
+    listed twice, truncated / zero-padded to max_relas."""
+    import sng_parser   # same optional dependency as the reference (interface.py:8)
+    graph = sng_parser.parse(prompt)
+    entities = graph["entities"]
+    triplets = []
+    for r in graph.get("relations", []):
+        triplets.append(" ".join([entities[r["subject"]]["lemma_head"], r["relation"], entities[r["object"]]["lemma_head"]]))
+    if not triplets:
+        emb = torch.zeros(max_relas, 768)
+    else:
+        relations = (["PAD"] + triplets + triplets)[:max_relas]
+        _, pooled = text_encoder.encode(relations, return_pooler_output=True)
+        emb = torch.zeros(max_relas, 768)
+        emb[:len(relations), :] = pooled
+    return emb.unsqueeze(0).repeat(batch_size, 1, 1).to(device)
+
+
+def _postprocess(samples):
+    """interface.py:543-547: clamp -> [0,1] -> *255 -> uint8 truncation -> PIL."""
+    from PIL import Image
+    out = []
+    for sample in samples:
+        sample = torch.clamp(sample, min=-1, max=1) * 0.5 + 0.5
+        sample = sample.cpu().numpy().transpose(1, 2, 0) * 255
+        out.append(Image.fromarray(sample.astype(np.uint8)))
+    return out
+
+
+@torch.no_grad()
+def denoise(all_models, context, uc, relations, grounding_batch, starting_noise, alpha_type=None, guidance_scale=7.5,
+            steps=PLMS_STEPS):
+    """The denoising hot path proper, from conditioning tensors to the final latent
+    (run_batch_images lines interface.py:505-539 without text/VAE stages)."""
+    model, autoencoder, text_encoder, diffusion, config = all_models
+    sampler = PLMSSampler(diffusion, model, alpha_generator_func=partial(alpha_generator, type=alpha_type),
+                          set_alpha_scale=set_alpha_scale)
+    grounding_input = model.grounding_tokenizer_input.prepare(grounding_batch, text_encoder)
+    input = dict(x=starting_noise, timesteps=None, context=context, relations=relations, grounding_input=grounding_input,
+                 inpainting_extra_input=None, grounding_extra_input=None)
+    shape = tuple(starting_noise.shape)
+    return sampler.sample(S=steps, shape=shape, input=input, uc=uc, guidance_scale=guidance_scale, mask=None, x0=None)
+
+
+def _run(all_models, args, meta, starting_noise, clip_model, clip_processor, device, multiple):
+    model, autoencoder, text_encoder, diffusion, config = all_models
+    config.update(args)                      # mutates the caller's dict, like interface.py:297/484
+    cfg = _AttrDict(config)
+    if cfg.get("no_plms", False):
+        raise NotImplementedError("the DDIM path is broken in the reference with this UNet (SURVEY App-B#8); PLMS only")
+    bs = cfg.batch_size
+    max_rel = cfg.get("max_relations", 10)
+    if multiple:
+        batch = prepare_batch_multiple(meta, clip_model, clip_processor, bs, device=device)
+        context = text_encoder.encode(meta["prompts"])
+        relations = torch.cat([prepare_relation_phrases(p, 1, max_rel, text_encoder, device=device) for p in meta["prompts"]], dim=0)
+    else:
+        batch = prepare_batch(meta, clip_model, clip_processor, bs, device=device)
+        context = text_encoder.encode([meta["prompt"]] * bs)
+        relations = prepare_relation_phrases(meta["prompt"], bs, max_rel, text_encoder, device=device)
+    uc = text_encoder.encode(bs * [""])
+    samples = denoise(all_models, context, uc, relations, batch, starting_noise, meta.get("alpha_type"), cfg.guidance_scale)
+    return _postprocess(autoencoder.decode(samples))
+
+
+@torch.no_grad()
+def run_one_image(all_models, args, meta, starting_noise=None, clip_model=None, clip_processor=None, device=None):
+    """interface.py:292-357."""
+    return _run(all_models, args, meta, starting_noise, clip_model, clip_processor, device, multiple=False)
+
+
+@torch.no_grad()
+def run_batch_images(all_models, args, meta, starting_noise=None, clip_model=None, clip_processor=None, device=None):
+    """interface.py:478-549."""
+    return _run(all_models, args, meta, starting_noise, clip_model, clip_processor, device, multiple=True)
+
+
+def generate_one_image(all_models, caption, label, bbox, clip_model=None, clip_processor=None, device=None):
+    """interface.py:376-395 (converts xywh -> ltrb, :383)."""
+    args = dict(batch_size=1, no_plms=False, guidance_scale=7.5)
+    bbox = [convert_xywh_to_ltrb(b) for b in bbox]
+    meta = dict(prompt=caption, phrases=label, locations=bbox, alpha_type=[0.3, 0.0, 0.7])
+    starting_noise = torch.randn(args["batch_size"], 4, 64, 64).to(device)
+    warnings.filterwarnings("ignore", category=DeprecationWarning)
+    return run_one_image(all_models, args, meta, starting_noise, clip_model, clip_processor, device=device)
+
+
+def generate_batch_images(all_models, captions, labels, bboxes, clip_model=None, clip_processor=None, device=None):
+    """interface.py:551-570 (boxes are NOT converted here, App-B#10)."""
+    bs = len(captions)
+    args = dict(batch_size=bs, no_plms=False, guidance_scale=7.5)
+    meta = dict(prompts=captions, phrases=labels, locations=bboxes, alpha_type=[0.3, 0.0, 0.7])
+    starting_noise = torch.randn(bs, 4, 64, 64).to(device)
+    warnings.filterwarnings("ignore", category=DeprecationWarning)
+    return run_batch_images(all_models, args, meta, starting_noise, clip_model, clip_processor, device=device)

@@ -1,0 +1,275 @@
+"""Host-side wrappers: torch tensors (device memory + streams only) -> raw pointers -> C ABI.
+
+Each function launches exactly one HIP kernel from libgligen_hip.so on torch's current stream.
+There is no eager/PyTorch fallback: a missing library or a non-GPU tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import (EPI_BIAS, EPI_GATE_RES, EPI_GEGLU, EPI_RES, EPI_ROWBIAS, EPI_SILU, OUT_F16_ROWMAJOR, OUT_F32_NCHW,
+                   AttnArgs, ConvArgs, GemmArgs, check)
+
+F16 = torch.float16
+F32 = torch.float32
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _req(t: torch.Tensor, dtype, name: str, align: int = 16) -> None:
+    if not t.is_cuda:
+        raise _lib.HipLibraryError(f"{name}: tensor is not on the GPU (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if t.data_ptr() % align:
+        raise ValueError(f"{name}: pointer not {align}-byte aligned")
+
+
+def _rows(t: torch.Tensor, name: str):
+    """2-D row view: returns (rows, cols, row_stride) requiring unit column stride."""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"{name}: need a 2-D tensor with contiguous columns, got shape {tuple(t.shape)} stride {t.stride()}")
+    return t.shape[0], t.shape[1], t.stride(0)
+
+
+def _fill_epilogue(g: GemmArgs, epi, out, N_out, bias, res, gate, rowbias, rows_per_sample, nchw_hw):
+    g.bias = _ptr(bias)
+    if bias is not None:
+        _req(bias, F32, "bias")
+    g.epi = epi
+    if nchw_hw:
+        _req(out, F32, "out")
+        g.out_mode, g.hw = OUT_F32_NCHW, nchw_hw
+        g.out, g.ldc = out.data_ptr(), 0
+    else:
+        _req(out, F16, "out", 8)
+        r, c, ld = _rows(out, "out")
+        if c != N_out:
+            raise ValueError(f"out has {c} columns, expected {N_out}")
+        g.out_mode, g.hw = OUT_F16_ROWMAJOR, 0
+        g.out, g.ldc = out.data_ptr(), ld
+    if res is not None:
+        _req(res, F16, "res", 8)
+        g.res, g.ldres = res.data_ptr(), _rows(res, "res")[2]
+    if gate is not None:
+        _req(gate, F32, "gate", 4)
+        g.gate = gate.data_ptr()
+    if rowbias is not None:
+        _req(rowbias, F16, "rowbias", 8)
+        g.rowbias, g.ld_rowbias, g.rows_per_sample = rowbias.data_ptr(), _rows(rowbias, "rowbias")[2], rows_per_sample
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias=None, epi: int = EPI_BIAS, res=None, gate=None,
+         rowbias=None, rows_per_sample: int = 0, a2: Optional[torch.Tensor] = None, nchw_hw: int = 0) -> torch.Tensor:
+    """out = [a | a2] @ w.T (+ epilogue).  a [M, K1], a2 [M, K2] (optional), w [N, K1+K2] fp16."""
+    _req(a, F16, "a")
+    _req(w, F16, "w")
+    M, K1, lda = _rows(a, "a")
+    N, K, ldw = _rows(w, "w")
+    if ldw != K:
+        raise ValueError("w must be contiguous")
+    g = GemmArgs()
+    g.a, g.lda = a.data_ptr(), lda
+    if a2 is not None:
+        _req(a2, F16, "a2")
+        M2, K2, lda2 = _rows(a2, "a2")
+        if M2 != M or K1 + K2 != K:
+            raise ValueError("a2 shape mismatch")
+        g.a2, g.lda2, g.ksplit = a2.data_ptr(), lda2, K1
+    elif K1 != K:
+        raise ValueError(f"a has K={K1}, w has K={K}")
+    g.w = w.data_ptr()
+    g.M, g.N, g.K = M, N, K
+    _fill_epilogue(g, epi, out, N // 2 if epi == EPI_GEGLU else N, bias, res, gate, rowbias, rows_per_sample, nchw_hw)
+    check(_lib.lib().gl_gemm(C.byref(g), _stream()), "gl_gemm")
+    return out
+
+
+def conv3x3(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, B: int, Hin: int, Win: int, bias=None,
+            stride: int = 1, upsample2x: bool = False, epi: int = EPI_BIAS, res=None, rowbias=None,
+            rows_per_sample: int = 0, nchw_hw: int = 0, n_valid: Optional[int] = None) -> torch.Tensor:
+    """x [B*Hin*Win, Cin] fp16 NHWC; w [Cout, 9*Cin] fp16 (tap-major, channel-minor)."""
+    _req(x, F16, "x")
+    _req(w, F16, "w")
+    rows, Cin, ldx = _rows(x, "x")
+    if ldx != Cin or rows != B * Hin * Win:
+        raise ValueError("x must be a contiguous [B*Hin*Win, Cin] matrix")
+    N, K, _ = _rows(w, "w")
+    if K != 9 * Cin:
+        raise ValueError("w must be [Cout, 9*Cin]")
+    if upsample2x:
+        Hout, Wout = 2 * Hin, 2 * Win
+    else:
+        Hout, Wout = (Hin + 2 - 3) // stride + 1, (Win + 2 - 3) // stride + 1
+    a = ConvArgs()
+    a.inp = x.data_ptr()
+    a.B, a.Hin, a.Win, a.Cin, a.Hout, a.Wout = B, Hin, Win, Cin, Hout, Wout
+    a.stride, a.upsample2x = stride, int(upsample2x)
+    a.g.w = w.data_ptr()
+    a.g.N = N if n_valid is None else n_valid
+    _fill_epilogue(a.g, epi, out, a.g.N, bias, res, None, rowbias, rows_per_sample, nchw_hw)
+    check(_lib.lib().gl_conv3x3(C.byref(a), _stream()), "gl_conv3x3")
+    return out
+
+
+def transpose_v(v: torch.Tensor, v_bstride: int, ldv: int, vt: torch.Tensor, B: int, H: int, d: int, Nk: int):
+    """v: fp16 view whose element (b, key, h*d + c) sits at v.data_ptr + b*v_bstride + key*ldv + h*d + c.
+    vt: [B, H, d, ldvt] fp16 contiguous, ldvt >= roundup(Nk, 64)."""
+    _req(v, F16, "v", 2)
+    _req(vt, F16, "vt")
+    ldvt = vt.shape[-1]
+    check(_lib.lib().gl_transpose_v(v.data_ptr(), v_bstride, ldv, vt.data_ptr(), ldvt, B, H, d, Nk, _stream()),
+          "gl_transpose_v")
+    return vt
+
+
+def attention(q: torch.Tensor, q_bstride: int, ldq: int, k: torch.Tensor, k_bstride: int, ldk: int, vt: torch.Tensor,
+              out: torch.Tensor, o_bstride: int, ldo: int, B: int, H: int, d: int, Nq: int, Nk: int, scale: float):
+    _req(q, F16, "q")
+    _req(k, F16, "k")
+    _req(vt, F16, "vt")
+    _req(out, F16, "out", 8)
+    a = AttnArgs()
+    a.q, a.q_bstride, a.ldq = q.data_ptr(), q_bstride, ldq
+    a.k, a.k_bstride, a.ldk = k.data_ptr(), k_bstride, ldk
+    a.vt, a.ldvt = vt.data_ptr(), vt.shape[-1]
+    a.out, a.o_bstride, a.ldo = out.data_ptr(), o_bstride, ldo
+    a.B, a.H, a.d, a.Nq, a.Nk = B, H, d, Nq, Nk
+    a.scale = scale
+    check(_lib.lib().gl_attention(C.byref(a), _stream()), "gl_attention")
+    return out
+
+
+def gn_nchunk(HW: int) -> int:
+    return max(1, min(64, HW // 4))
+
+
+def groupnorm(x1: torch.Tensor, x2: Optional[torch.Tensor], B: int, HW: int, gamma: torch.Tensor, beta: torch.Tensor,
+              eps: float, silu: bool, out: torch.Tensor, partial: torch.Tensor) -> torch.Tensor:
+    """GroupNorm(32) of the channel concat [x1 | x2] (x2 may be None); x* are [B*HW, C*] fp16."""
+    _req(x1, F16, "x1")
+    C1 = x1.shape[-1]
+    C2 = 0
+    if x2 is not None:
+        _req(x2, F16, "x2")
+        C2 = x2.shape[-1]
+    _req(gamma, F32, "gamma")
+    _req(beta, F32, "beta")
+    _req(out, F16, "out")
+    _req(partial, F32, "partial")
+    nchunk = gn_nchunk(HW)
+    if partial.numel() < B * nchunk * 64:
+        raise ValueError("partial buffer too small")
+    l = _lib.lib()
+    check(l.gl_groupnorm_stats(x1.data_ptr(), C1, _ptr(x2), C2, B, HW, partial.data_ptr(), nchunk, _stream()),
+          "gl_groupnorm_stats")
+    check(l.gl_groupnorm_apply(x1.data_ptr(), C1, _ptr(x2), C2, B, HW, partial.data_ptr(), nchunk, gamma.data_ptr(),
+                               beta.data_ptr(), eps, int(silu), out.data_ptr(), _stream()), "gl_groupnorm_apply")
+    return out
+
+
+def layernorm(x: torch.Tensor, y: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, B: int, rows_in: int,
+              rows_out: Optional[int] = None, row_off: int = 0, eps: float = 1e-5) -> torch.Tensor:
+    """x [B*rows_in, C] -> y rows b*rows_out + row_off + i (y is [B*rows_out, C])."""
+    _req(x, F16, "x")
+    _req(y, F16, "y")
+    _req(gamma, F32, "gamma")
+    _req(beta, F32, "beta")
+    _, Cc, ldx = _rows(x, "x")
+    _, _, ldy = _rows(y, "y")
+    rows_out = rows_in if rows_out is None else rows_out
+    check(_lib.lib().gl_layernorm(x.data_ptr(), ldx, y.data_ptr(), ldy, gamma.data_ptr(), beta.data_ptr(), B, rows_in,
+                                  rows_out, row_off, Cc, eps, _stream()), "gl_layernorm")
+    return y
+
+
+def rela_pool(hid, B, H, W, Cc, rects, nvalid, poison, max_objs, feat):
+    _req(hid, F16, "hid")
+    _req(feat, F16, "feat")
+    for t, n in ((rects, "rects"), (nvalid, "nvalid"), (poison, "poison")):
+        _req(t, torch.int32, n, 4)
+    check(_lib.lib().gl_rela_pool(hid.data_ptr(), B, H, W, Cc, rects.data_ptr(), nvalid.data_ptr(), poison.data_ptr(),
+                                  max_objs, feat.data_ptr(), _stream()), "gl_rela_pool")
+    return feat
+
+
+def rela_merge(x, hid, f, B, H, W, Cc, rects, nvalid, poison, max_objs, y):
+    for t, n in ((x, "x"), (hid, "hid"), (f, "f"), (y, "y")):
+        _req(t, F16, n)
+    check(_lib.lib().gl_rela_merge(x.data_ptr(), hid.data_ptr(), f.data_ptr(), B, H, W, Cc, rects.data_ptr(),
+                                   nvalid.data_ptr(), poison.data_ptr(), max_objs, y.data_ptr(), _stream()),
+          "gl_rela_merge")
+    return y
+
+
+def posnet_input(boxes, masks, emb, null_pos, null_xyxy, num_freqs, out):
+    for t, n in ((boxes, "boxes"), (masks, "masks"), (emb, "emb"), (null_pos, "null_pos"), (null_xyxy, "null_xyxy")):
+        _req(t, F32, n, 4)
+        if not t.is_contiguous():
+            raise ValueError(f"{n} must be contiguous")
+    _req(out, F16, "out")
+    rows = boxes.shape[0] * boxes.shape[1]
+    in_dim = emb.shape[-1]
+    check(_lib.lib().gl_posnet_input(boxes.data_ptr(), masks.data_ptr(), emb.data_ptr(), null_pos.data_ptr(),
+                                     null_xyxy.data_ptr(), rows, in_dim, num_freqs, out.data_ptr(), _stream()),
+          "gl_posnet_input")
+    return out
+
+
+def timestep_embedding(t: torch.Tensor, dim: int, out: torch.Tensor):
+    _req(t, F32, "t", 4)
+    _req(out, F16, "out")
+    check(_lib.lib().gl_timestep_embedding(t.data_ptr(), t.shape[0], dim, out.data_ptr(), _stream()),
+          "gl_timestep_embedding")
+    return out
+
+
+def silu(x: torch.Tensor, y: torch.Tensor):
+    _req(x, F16, "x")
+    _req(y, F16, "y")
+    check(_lib.lib().gl_silu_f16(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "gl_silu_f16")
+    return y
+
+
+def cfg_combine(eps2b: torch.Tensor, guidance: float, e_out: torch.Tensor):
+    _req(eps2b, F32, "eps2b")
+    _req(e_out, F32, "e_out")
+    check(_lib.lib().gl_cfg_combine(eps2b.data_ptr(), guidance, e_out.numel(), e_out.data_ptr(), _stream()),
+          "gl_cfg_combine")
+    return e_out
+
+
+def plms_update(x, e, olds, coefs, div, sqrt_at, s1m, sqrt_aprev, dir_coef, x_prev):
+    """x_prev from e' = (coefs[0]*e + sum coefs[1+j]*olds[j]) / div (plms.py:144-161)."""
+    _req(x, F32, "x")
+    _req(e, F32, "e")
+    _req(x_prev, F32, "x_prev")
+    ps = [None, None, None]
+    cs = [0.0, 0.0, 0.0]
+    for j, o in enumerate(olds):
+        _req(o, F32, "old_eps")
+        ps[j] = o.data_ptr()
+        cs[j] = float(coefs[1 + j])
+    check(_lib.lib().gl_plms_update(x.data_ptr(), e.data_ptr(), ps[0], ps[1], ps[2], float(coefs[0]), cs[0], cs[1],
+                                    cs[2], float(div), float(sqrt_at), float(s1m), float(sqrt_aprev), float(dir_coef),
+                                    x.numel(), x_prev.data_ptr(), _stream()), "gl_plms_update")
+    return x_prev
+
+
+def pack_latent(x: torch.Tensor, Cpad: int, reps: int, out: torch.Tensor):
+    """x fp32 [B, C, h, w] -> out fp16 [reps*B, h*w, Cpad]."""
+    _req(x, F32, "x")
+    _req(out, F16, "out")
+    B, Cc, h, w = x.shape
+    check(_lib.lib().gl_pack_latent(x.data_ptr(), B, Cc, h * w, Cpad, reps, out.data_ptr(), _stream()), "gl_pack_latent")
+    return out

@@ -1,0 +1,203 @@
+"""Checkpoint ingestion: reference-named fp32 state_dict -> packed fp16/fp32 device tensors.
+
+The engine never sees torch modules; it consumes the flat dict this module produces.  Packing is
+layout work only (no arithmetic beyond dtype casts and tanh of the scalar gates):
+
+  * Linear / 1x1-conv weights  [N, K]            -> fp16 [N, K]
+  * 3x3 conv weights [Cout, Cin, 3, 3]          -> fp16 [Cout, 9*Cin] tap-major/channel-minor (NHWC implicit GEMM);
+                                                   the 4-channel first conv is zero-padded to Cin = 64
+  * GEGLU proj [8C, C] (x rows | gate rows)      -> rows interleaved in blocks of 32 (x32 | gate32 | x32 | ...)
+                                                   so x_j and gate_j land in adjacent MFMA tiles (bias likewise)
+  * self-attention to_q/to_k/to_v                -> one [3C, C] matrix (single QKV GEMM)
+  * cross-attention to_k/to_v (context/relations)-> one [2C, 768] matrix (hoisted K/V GEMM)
+  * the 22 ResBlock emb_layers                   -> one [sum Cout, 4*mc] matrix (one GEMM per step)
+  * biases, norm affine params                   -> fp32
+  * alpha_attn / alpha_dense                     -> tanh() as python floats (fuser: multiplied by the
+                                                   sampler's scale per step; rela_fuse: constant)
+State-dict names follow SURVEY.md App-C, so a real GLIGEN checkpoint's ``saved_ckpt['model']`` loads
+(strict=False semantics, interface.py:91: missing keys raise here, unexpected keys are ignored).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Mapping
+
+import numpy as np
+import torch
+
+from .arch import Plan, UNetConfig, build_plan, param_shapes
+
+CIN_PAD = 64
+
+
+def _t(v, device) -> torch.Tensor:
+    if not torch.is_tensor(v):
+        v = torch.from_numpy(np.ascontiguousarray(np.asarray(v, dtype=np.float32)))
+    return v.to(device=device, dtype=torch.float32)
+
+
+def _h(x: torch.Tensor) -> torch.Tensor:
+    return x.to(torch.float16).contiguous()
+
+
+def pack_conv3x3(w: torch.Tensor, cin_pad: int | None = None) -> torch.Tensor:
+    cout, cin = w.shape[0], w.shape[1]
+    wp = w.permute(0, 2, 3, 1)                       # [Cout, 3, 3, Cin]
+    if cin_pad is not None and cin_pad > cin:
+        z = torch.zeros(cout, 3, 3, cin_pad - cin, dtype=w.dtype, device=w.device)
+        wp = torch.cat([wp, z], dim=-1)
+    return _h(wp.reshape(cout, -1))
+
+
+def geglu_interleave(t: torch.Tensor) -> torch.Tensor:
+    """rows [x (4C) | gate (4C)] -> blocks of 32: x[0:32], gate[0:32], x[32:64], gate[32:64], ..."""
+    half = t.shape[0] // 2
+    assert half % 32 == 0, "GEGLU inner dim must be a multiple of 32"
+    x = t[:half].reshape(half // 32, 1, 32, *t.shape[1:])
+    g = t[half:].reshape(half // 32, 1, 32, *t.shape[1:])
+    return torch.cat([x, g], dim=1).reshape(t.shape)
+
+
+class PackedWeights:
+    """Flat container: ``w[name]`` tensors on device + python scalars in ``s[name]``."""
+
+    def __init__(self, cfg: UNetConfig, plan: Plan, device):
+        self.cfg, self.plan, self.device = cfg, plan, device
+        self.w: Dict[str, torch.Tensor] = {}
+        self.s: Dict[str, float] = {}
+        self.emb_offsets: Dict[str, int] = {}
+        self.emb_total = 0
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.w.values())
+
+
+def pack_state_dict(sd: Mapping[str, object], cfg: UNetConfig, device, sd_first_conv: Mapping[str, object] | None = None
+                    ) -> PackedWeights:
+    plan = build_plan(cfg)
+    need = param_shapes(cfg)
+    missing = [k for k in need if k not in sd]
+    if missing:
+        raise KeyError(f"state_dict is missing {len(missing)} tensors, e.g. {missing[:3]}")
+    for k, shp in need.items():
+        if tuple(sd[k].shape) != tuple(shp):
+            raise ValueError(f"{k}: shape {tuple(sd[k].shape)} != expected {shp}")
+    P = PackedWeights(cfg, plan, device)
+    W, S = P.w, P.s
+    g = lambda k: _t(sd[k], device)
+
+    def lin(p, dst=None, bias=True):
+        dst = dst or p
+        W[dst + ".w"] = _h(g(p + ".weight").reshape(g(p + ".weight").shape[0], -1))
+        if bias:
+            W[dst + ".b"] = g(p + ".bias").contiguous()
+
+    def norm(p):
+        W[p + ".g"] = g(p + ".weight").contiguous()
+        W[p + ".b"] = g(p + ".bias").contiguous()
+
+    def conv3(p, cin_pad=None):
+        W[p + ".w"] = pack_conv3x3(g(p + ".weight"), cin_pad)
+        W[p + ".b"] = g(p + ".bias").contiguous()
+
+    def ff(p):
+        W[p + ".ff1.w"] = _h(geglu_interleave(g(p + ".net.0.proj.weight")))
+        W[p + ".ff1.b"] = geglu_interleave(g(p + ".net.0.proj.bias")).contiguous()
+        lin(p + ".net.2", p + ".ff2")
+
+    def self_attn(p):
+        W[p + ".qkv.w"] = _h(torch.cat([g(p + ".to_q.weight"), g(p + ".to_k.weight"), g(p + ".to_v.weight")], 0))
+        lin(p + ".to_out.0", p + ".o")
+
+    def cross_attn(p):
+        W[p + ".q.w"] = _h(g(p + ".to_q.weight"))
+        W[p + ".kv.w"] = _h(torch.cat([g(p + ".to_k.weight"), g(p + ".to_v.weight")], 0))
+        lin(p + ".to_out.0", p + ".o")
+
+    lin("time_embed.0")
+    lin("time_embed.2")
+    # first conv: GLIGEN's own and the "SD" replacement (openaimodel.py:393-405)
+    conv3("input_blocks.0.0", CIN_PAD)
+    if sd_first_conv is not None:
+        W["sd_first_conv.w"] = pack_conv3x3(_t(sd_first_conv["weight"], device), CIN_PAD)
+        W["sd_first_conv.b"] = _t(sd_first_conv["bias"], device).contiguous()
+
+    emb_w, emb_b, off = [], [], 0
+    for l in plan.all_layers():
+        p = l.prefix
+        if l.kind in ("down", "up"):
+            conv3(p)
+        elif l.kind == "res":
+            norm(p + ".in_layers.0")
+            conv3(p + ".in_layers.2")
+            norm(p + ".out_layers.0")
+            conv3(p + ".out_layers.3")
+            if l.cin != l.cout:
+                lin(p + ".skip_connection")
+            emb_w.append(g(p + ".emb_layers.1.weight"))
+            emb_b.append(g(p + ".emb_layers.1.bias"))
+            P.emb_offsets[p] = off
+            off += l.cout
+        elif l.kind == "st":
+            norm(p + ".norm")
+            lin(p + ".proj_in")
+            lin(p + ".proj_out")
+            t = p + ".transformer_blocks.0"
+            self_attn(t + ".attn1")
+            cross_attn(t + ".attn2")
+            ff(t + ".ff")
+            for n in ("norm1", "norm2", "norm3"):
+                norm(f"{t}.{n}")
+            f = t + ".fuser"
+            lin(f + ".linear")
+            self_attn(f + ".attn")
+            ff(f + ".ff")
+            norm(f + ".norm1")
+            norm(f + ".norm2")
+            S[f + ".tanh_attn"] = math.tanh(float(g(f + ".alpha_attn")))
+            S[f + ".tanh_dense"] = math.tanh(float(g(f + ".alpha_dense")))
+            r = t + ".rela_fuse"
+            cross_attn(r + ".attn")
+            ff(r + ".ff")
+            for n in ("norm1", "norm2", "norm3"):
+                norm(f"{r}.{n}")
+            S[r + ".tanh_attn"] = math.tanh(float(g(r + ".alpha_attn")))
+            S[r + ".tanh_dense"] = math.tanh(float(g(r + ".alpha_dense")))
+    W["emb_all.w"] = _h(torch.cat(emb_w, 0))
+    W["emb_all.b"] = torch.cat(emb_b, 0).contiguous()
+    P.emb_total = off
+    norm("out.0")
+    conv3("out.2")
+    W["position_net.null_pos"] = g("position_net.null_positive_feature").contiguous()
+    W["position_net.null_xyxy"] = g("position_net.null_position_feature").contiguous()
+    for i in (0, 2, 4):
+        lin(f"position_net.linears.{i}")
+    return P
+
+
+@torch.no_grad()
+def random_state_dict(cfg: UNetConfig, device, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Fast on-device random weights with the recipe's *scaling rules* (not its values): used by the
+    benchmark, where only shapes and magnitudes matter (no checkpoint is obtainable offline)."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    out: Dict[str, torch.Tensor] = {}
+    for name, shape in param_shapes(cfg).items():
+        leaf = name.rsplit(".", 1)[-1]
+        u = lambda: torch.rand(shape if len(shape) else (1,), generator=gen, device=device, dtype=torch.float32) * 2 - 1
+        if leaf in ("alpha_attn", "alpha_dense"):
+            v = u().reshape(())
+            t = torch.sign(v) * (0.3 + 0.35 * v.abs())
+        elif leaf.startswith("null_"):
+            t = u() * 0.5
+        elif (".norm" in name or "in_layers.0" in name or "out_layers.0" in name or name.startswith("out.0")) and len(shape) == 1:
+            t = 1.0 + 0.1 * u() if leaf == "weight" else 0.05 * u()
+        elif leaf == "bias":
+            t = 0.02 * u()
+        else:
+            fan_in = 1
+            for s in shape[1:]:
+                fan_in *= s
+            t = u() * math.sqrt(3.0 / max(fan_in, 1))
+        out[name] = t
+    return out

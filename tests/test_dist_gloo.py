@@ -1,0 +1,70 @@
+"""world_size-2 gloo tests (CPU) of the N>1 path: one flat weight broadcast + round-robin prompt sharding.
+No data-path collective exists besides that broadcast."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from layoutllm_t2i_amd import recipe
+from layoutllm_t2i_amd.arch import TINY
+from layoutllm_t2i_amd.dist import broadcast_packed, checksum, flatten_packed, shard_indices, unflatten_packed
+from layoutllm_t2i_amd.weights import pack_state_dict
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_broadcast_and_shard_world2():
+    import json
+    import subprocess
+    world = 2
+    port = _free_port()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_worker.py")
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, worker], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    res = []
+    try:
+        for p in procs:
+            out, err = p.communicate(timeout=240)
+            assert p.returncode == 0, err[-2000:]
+            line = next(l for l in out.splitlines() if l.startswith("RESULT "))
+            res.append(json.loads(line[7:]))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    res.sort(key=lambda d: d["rank"])
+    a, b = res
+    assert a["checksum"] == b["checksum"] == a["local_checksum"], "ranks disagree after the weight broadcast"
+    assert a["n"] == b["n"] and a["emb_total"] == b["emb_total"] and a["scalars"] == b["scalars"]
+    assert sorted(a["shard"] + b["shard"]) == list(range(7)) and not set(a["shard"]) & set(b["shard"])
+    assert a["d16"] == b["d16"] == "torch.float16" and a["d32"] == b["d32"] == "torch.float32"
+
+
+def test_flatten_roundtrip_single_process():
+    P = pack_state_dict(recipe.state_dict(TINY, 0), TINY, "cpu", recipe.sd_first_conv(TINY, 0))
+    flat, man = flatten_packed(P)
+    assert flat.dtype == torch.uint8 and flat.numel() % 256 == 0
+    Q = unflatten_packed(flat.clone(), man, TINY, "cpu")
+    assert set(Q.w) == set(P.w)
+    for k in P.w:
+        assert torch.equal(Q.w[k], P.w[k]) and Q.w[k].dtype == P.w[k].dtype, k
+        assert Q.w[k].data_ptr() % 16 == 0
+    assert Q.s == P.s and Q.emb_offsets == P.emb_offsets and checksum(P) == checksum(Q)
+
+
+def test_shard_indices_ragged():
+    assert shard_indices(64, 3, 8) == [3, 11, 19, 27, 35, 43, 51, 59]
+    assert shard_indices(5, 7, 8) == []
+    assert sum(len(shard_indices(13, r, 4)) for r in range(4)) == 13

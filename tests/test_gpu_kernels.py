@@ -1,0 +1,401 @@
+"""Per-kernel parity on a real MI355X, through the C ABI (layoutllm_t2i_amd.ops -> libgligen_hip.so).
+
+Reference = the same op in torch fp32 on the CPU, evaluated on the SAME fp16-rounded inputs/weights
+(isolates kernel error from quantisation of the inputs).  Tolerance is north_star's
+rtol=1e-3 / atol=1e-4 scaled by the output magnitude (fp16 output rounding is 4.9e-4 relative),
+except where a comment says otherwise.  Sampler arithmetic is checked bit-exactly.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from layoutllm_t2i_amd import host, ops, recipe
+from layoutllm_t2i_amd._lib import (EPI_BIAS, EPI_GATE_RES, EPI_GEGLU, EPI_RES, EPI_ROWBIAS, EPI_SILU, init_device)
+from layoutllm_t2i_amd.weights import geglu_interleave, pack_conv3x3
+
+DEV = "cuda:0"
+RTOL, ATOL = 1e-3, 1e-4
+
+
+def rnd(tag, shape, scale=1.0):
+    return torch.from_numpy(recipe.normal(f"gpu.{tag}", tuple(shape), 11)) * scale
+
+
+def h16(x):
+    """fp16-rounded fp32 copy (CPU) and the fp16 device tensor."""
+    xh = x.to(torch.float16)
+    return xh.float(), xh.to(DEV)
+
+
+def check(out, ref, name, rtol=RTOL, atol=ATOL, frac_ok=0.0):
+    out = out.float().cpu()
+    ref = ref.float()
+    assert out.shape == ref.shape, (name, out.shape, ref.shape)
+    assert torch.isfinite(out).all(), f"{name}: non-finite output"
+    scale = max(1.0, float(ref.abs().max()))
+    err = (out - ref).abs()
+    tol = atol * scale + rtol * ref.abs()
+    bad = (err > tol).float().mean().item()
+    rel_l2 = float((out - ref).norm() / (ref.norm() + 1e-30))
+    print(f"[{name}] max|err|={err.max().item():.3e} rel_l2={rel_l2:.3e} |ref|max={float(ref.abs().max()):.3f} viol={bad:.2e}")
+    assert bad <= frac_ok, f"{name}: {bad:.3e} of elements outside rtol={rtol} atol={atol}*{scale:.2f}; max err {err.max().item():.3e}, rel_l2 {rel_l2:.3e}"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _init():
+    init_device()
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(300, 320, 320), (512, 1280, 640), (240, 512, 832), (8, 1280, 320), (1024, 960, 320)])
+def test_gemm_bias(M, N, K):
+    a, ad = h16(rnd(f"a{M}", (M, K)))
+    w, wd = h16(rnd(f"w{N}", (N, K), 1 / math.sqrt(K)))
+    b = rnd(f"b{N}", (N,), 0.1)
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    ops.gemm(ad, wd, out, b.to(DEV))
+    check(out, F.linear(a, w, b), f"gemm_bias_{M}x{N}x{K}")
+
+
+def test_gemm_epilogues():
+    M, N, K = 384, 640, 320
+    a, ad = h16(rnd("ea", (M, K)))
+    w, wd = h16(rnd("ew", (N, K), 1 / math.sqrt(K)))
+    b = rnd("eb", (N,), 0.1)
+    r, rd = h16(rnd("er", (M, N)))
+    base = F.linear(a, w, b)
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    ops.gemm(ad, wd, out, b.to(DEV), EPI_SILU)
+    check(out, F.silu(base), "gemm_silu")
+    ops.gemm(ad, wd, out, b.to(DEV), EPI_RES, res=rd)
+    check(out, base + r, "gemm_res")
+    gate = torch.tensor([-0.37], dtype=torch.float32, device=DEV)
+    ops.gemm(ad, wd, out, b.to(DEV), EPI_GATE_RES, res=rd, gate=gate)
+    check(out, r + (-0.37) * base, "gemm_gate_res")
+    rb, rbd = h16(rnd("erb", (3, N)))
+    ops.gemm(ad, wd, out, b.to(DEV), EPI_ROWBIAS, rowbias=rbd, rows_per_sample=128)
+    check(out, base + rb.repeat_interleave(128, 0), "gemm_rowbias")
+    # no bias, strided output view
+    big = torch.zeros(M, 2 * N, dtype=torch.float16, device=DEV)
+    ops.gemm(ad, wd, big[:, N:], None)
+    check(big[:, N:], F.linear(a, w), "gemm_strided_out")
+    assert float(big[:, :N].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("C", [64, 320])
+def test_gemm_geglu(C):
+    M = 200
+    a, ad = h16(rnd("ga", (M, C)))
+    w, _ = h16(rnd("gw", (8 * C, C), 1 / math.sqrt(C)))
+    b = rnd("gb", (8 * C,), 0.1)
+    wd = geglu_interleave(w).to(torch.float16).to(DEV)
+    bd = geglu_interleave(b).contiguous().to(DEV)
+    out = torch.empty(M, 4 * C, dtype=torch.float16, device=DEV)
+    ops.gemm(ad, wd, out, bd, EPI_GEGLU)
+    x, g = F.linear(a, w, b).chunk(2, dim=-1)
+    check(out, x * F.gelu(g), f"gemm_geglu_{C}")
+
+
+def test_gemm_two_source():
+    M, K1, K2, N = 260, 128, 192, 256
+    a1, a1d = h16(rnd("ta1", (M, K1)))
+    a2, a2d = h16(rnd("ta2", (M, K2)))
+    w, wd = h16(rnd("tw", (N, K1 + K2), 1 / math.sqrt(K1 + K2)))
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    ops.gemm(a1d, wd, out, None, a2=a2d)
+    check(out, F.linear(torch.cat([a1, a2], 1), w), "gemm_two_source")
+
+
+def test_gemm_full_size_l0_ff():
+    """config-2 level-0 GEGLU projection: M = 4096 tokens (B=1), N = 2560, K = 320."""
+    M, C = 4096, 320
+    a, ad = h16(rnd("fa", (M, C)))
+    w, wd = h16(rnd("fw", (4 * C, C), 1 / math.sqrt(C)))
+    out = torch.empty(M, 4 * C, dtype=torch.float16, device=DEV)
+    ops.gemm(ad, wd, out, None)
+    check(out, F.linear(a, w), "gemm_l0")
+
+
+# ------------------------------------------------------------------------------------------- conv
+def _nhwc(x):  # [B,C,H,W] -> [B*H*W, C]
+    B, C, H, W = x.shape
+    return x.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous()
+
+
+@pytest.mark.parametrize("mode", ["s1", "s2", "up"])
+@pytest.mark.parametrize("Cin,Cout,hw", [(64, 128, 8), (320, 320, 16)])
+def test_conv3x3(mode, Cin, Cout, hw):
+    B = 2
+    x, _ = h16(rnd(f"cx{Cin}{mode}", (B, Cin, hw, hw)))
+    w, _ = h16(rnd(f"cw{Cin}{Cout}", (Cout, Cin, 3, 3), 1 / math.sqrt(9 * Cin)))
+    b = rnd(f"cb{Cout}", (Cout,), 0.1)
+    xd = _nhwc(x).to(torch.float16).to(DEV)
+    wd = pack_conv3x3(w).to(DEV)
+    if mode == "s1":
+        ref = F.conv2d(x, w, b, padding=1)
+        ho = hw
+    elif mode == "s2":
+        ref = F.conv2d(x, w, b, stride=2, padding=1)
+        ho = hw // 2
+    else:
+        ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, b, padding=1)
+        ho = hw * 2
+    out = torch.empty(B * ho * ho, Cout, dtype=torch.float16, device=DEV)
+    ops.conv3x3(xd, wd, out, B, hw, hw, b.to(DEV), stride=2 if mode == "s2" else 1, upsample2x=(mode == "up"))
+    check(out, _nhwc(ref), f"conv_{mode}_{Cin}_{Cout}_{hw}")
+
+
+def test_conv3x3_first_and_last():
+    """first conv (4 channels zero-padded to 64) and the out conv (Cout = 4, fp32 NCHW store)."""
+    B, hw, mc = 2, 16, 64
+    x = rnd("lat", (B, 4, hw, hw))
+    w, _ = h16(rnd("fcw", (mc, 4, 3, 3), 1 / 6))
+    b = rnd("fcb", (mc,), 0.1)
+    xin = torch.empty(2 * B * hw * hw, 64, dtype=torch.float16, device=DEV)
+    ops.pack_latent(x.to(DEV), 64, 2, xin)
+    xr = x.to(torch.float16).float()
+    ref_pack = torch.cat([_nhwc(xr)] * 2, 0)
+    assert torch.equal(xin[:, :4].float().cpu(), ref_pack) and float(xin[:, 4:].abs().max()) == 0.0
+    out = torch.empty(2 * B * hw * hw, mc, dtype=torch.float16, device=DEV)
+    ops.conv3x3(xin, pack_conv3x3(w, 64).to(DEV), out, 2 * B, hw, hw, b.to(DEV))
+    check(out, torch.cat([_nhwc(F.conv2d(xr, w, b, padding=1))] * 2, 0), "conv_first")
+    h, _ = h16(rnd("lh", (B, mc, hw, hw)))
+    w2, _ = h16(rnd("lw", (4, mc, 3, 3), 1 / math.sqrt(9 * mc)))
+    b2 = rnd("lb", (4,), 0.1)
+    eps = torch.empty(B, 4, hw, hw, dtype=torch.float32, device=DEV)
+    ops.conv3x3(_nhwc(h).to(torch.float16).to(DEV), pack_conv3x3(w2).to(DEV), eps, B, hw, hw, b2.to(DEV), nchw_hw=hw * hw)
+    check(eps, F.conv2d(h, w2, b2, padding=1), "conv_last_nchw_f32", rtol=1e-4, atol=1e-5)
+
+
+def test_conv3x3_epilogues():
+    B, C, hw = 2, 128, 8
+    x, _ = h16(rnd("cex", (B, C, hw, hw)))
+    w, _ = h16(rnd("cew", (C, C, 3, 3), 1 / math.sqrt(9 * C)))
+    b = rnd("ceb", (C,), 0.1)
+    emb, embd = h16(rnd("cee", (B, 3 * C)))
+    res, _ = h16(rnd("cer", (B, C, hw, hw)))
+    xd = _nhwc(x).to(torch.float16).to(DEV)
+    wd = pack_conv3x3(w).to(DEV)
+    out = torch.empty(B * hw * hw, C, dtype=torch.float16, device=DEV)
+    base = F.conv2d(x, w, b, padding=1)
+    ops.conv3x3(xd, wd, out, B, hw, hw, b.to(DEV), epi=EPI_ROWBIAS, rowbias=embd[:, C:2 * C], rows_per_sample=hw * hw)
+    check(out, _nhwc(base + emb[:, C:2 * C, None, None]), "conv_rowbias")
+    ops.conv3x3(xd, wd, out, B, hw, hw, b.to(DEV), epi=EPI_RES, res=_nhwc(res).to(torch.float16).to(DEV))
+    check(out, _nhwc(base + res), "conv_res")
+
+
+# ------------------------------------------------------------------------------------------- attention
+def _attn_ref(q, k, v, H):
+    B, Nq, C = q.shape
+    d = C // H
+    qh = q.view(B, Nq, H, d).transpose(1, 2)
+    kh = k.view(B, -1, H, d).transpose(1, 2)
+    vh = v.view(B, -1, H, d).transpose(1, 2)
+    s = torch.matmul(qh, kh.transpose(-1, -2)) * d ** -0.5
+    return torch.matmul(s.softmax(-1), vh).transpose(1, 2).reshape(B, Nq, C)
+
+
+@pytest.mark.parametrize("d,H,Nq,Nk,B", [
+    (16, 4, 64, 64, 2), (32, 4, 200, 230, 2), (40, 8, 256, 286, 1), (64, 2, 130, 77, 2),
+    (80, 8, 1024, 1054, 1), (160, 8, 256, 286, 1), (160, 8, 64, 64, 2), (40, 8, 30, 10, 2), (40, 8, 4096, 4126, 1)])
+def test_attention(d, H, Nq, Nk, B):
+    C = H * d
+    q, qd = h16(rnd(f"aq{d}{Nq}", (B, Nq, C)))
+    k, kd = h16(rnd(f"ak{d}{Nk}", (B, Nk, C)))
+    v, vd = h16(rnd(f"av{d}{Nk}", (B, Nk, C)))
+    ldvt = (Nk + 63) // 64 * 64
+    vt = torch.full((B, H, d, ldvt), float("nan"), dtype=torch.float16, device=DEV)
+    ops.transpose_v(vd, Nk * C, C, vt, B, H, d, Nk)
+    vt_ref = torch.zeros(B, H, d, ldvt)
+    vt_ref[..., :Nk] = v.view(B, Nk, H, d).permute(0, 2, 3, 1)
+    assert torch.equal(vt.float().cpu(), vt_ref), "transpose_v"
+    out = torch.empty(B, Nq, C, dtype=torch.float16, device=DEV)
+    ops.attention(qd, Nq * C, C, kd, Nk * C, C, vt, out, Nq * C, C, B, H, d, Nq, Nk, d ** -0.5)
+    # P is rounded to fp16 before P.V (4.9e-4 relative per weight): allow 2x the base tolerance
+    check(out, _attn_ref(q, k, v, H), f"attn_d{d}_q{Nq}_k{Nk}", rtol=2e-3, atol=2e-4)
+
+
+def test_attention_strided_qkv_and_spike():
+    """fused-QKV addressing (row stride 3C, batch stride (N+30)*3C, Nq < rows) and an outlier key that
+    forces a late running-max jump in the online softmax."""
+    B, H, d, N, mo = 2, 8, 40, 192, 30
+    C = H * d
+    rows = N + mo
+    qkv, qkvd = h16(rnd("sqkv", (B, rows, 3 * C)))
+    qkv[0, 150, C:2 * C] *= 6.0      # spike one key (tile 2)
+    qkv = qkv.to(torch.float16).float()
+    qkvd = qkv.to(torch.float16).to(DEV)
+    flat = qkvd.view(B * rows, 3 * C)
+    vt = torch.empty(B, H, d, 256, dtype=torch.float16, device=DEV)
+    ops.transpose_v(flat[:, 2 * C:], rows * 3 * C, 3 * C, vt, B, H, d, rows)
+    out = torch.empty(B * N, C, dtype=torch.float16, device=DEV)
+    ops.attention(flat, rows * 3 * C, 3 * C, flat[:, C:], rows * 3 * C, 3 * C, vt, out, N * C, C, B, H, d, N, rows, d ** -0.5)
+    ref = _attn_ref(qkv[:, :N, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], H)
+    check(out.view(B, N, C), ref, "attn_strided_spike", rtol=2e-3, atol=2e-4)
+
+
+# ------------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("C1,C2,HW,silu,eps", [(320, 0, 4096, True, 1e-5), (640, 320, 256, True, 1e-5), (1280, 1280, 64, True, 1e-5),
+                                               (64, 0, 64, False, 1e-6), (1280, 0, 256, False, 1e-6), (960, 0, 1024, True, 1e-5)])
+def test_groupnorm(C1, C2, HW, silu, eps):
+    B = 2
+    C = C1 + C2
+    x1, x1d = h16(rnd(f"g1{C1}{HW}", (B * HW, C1)) * 1.5 + 0.3)
+    x2 = x2d = None
+    if C2:
+        x2, x2d = h16(rnd(f"g2{C2}{HW}", (B * HW, C2)) * 0.7 - 0.2)
+    gam = 1 + 0.1 * rnd(f"gg{C}", (C,))
+    bet = 0.1 * rnd(f"gb{C}", (C,))
+    out = torch.empty(B * HW, C, dtype=torch.float16, device=DEV)
+    partial = torch.empty(B * 64 * 64, dtype=torch.float32, device=DEV)
+    ops.groupnorm(x1d, x2d, B, HW, gam.to(DEV), bet.to(DEV), eps, silu, out, partial)
+    x = x1 if x2 is None else torch.cat([x1, x2], 1)
+    xn = x.view(B, HW, C).permute(0, 2, 1)
+    ref = F.group_norm(xn, 32, gam, bet, eps)
+    if silu:
+        ref = F.silu(ref)
+    check(out, ref.permute(0, 2, 1).reshape(B * HW, C), f"groupnorm_{C1}+{C2}_{HW}")
+
+
+@pytest.mark.parametrize("C", [64, 320, 640, 1280])
+def test_layernorm(C):
+    B, rows = 2, 100
+    x, xd = h16(rnd(f"l{C}", (B * rows, C)) * 2 + 0.5)
+    gam = 1 + 0.1 * rnd(f"lg{C}", (C,))
+    bet = 0.1 * rnd(f"lb{C}", (C,))
+    y = torch.empty(B * rows, C, dtype=torch.float16, device=DEV)
+    ops.layernorm(xd, y, gam.to(DEV), bet.to(DEV), B, rows)
+    ref = F.layer_norm(x, (C,), gam, bet, 1e-5)
+    check(y, ref, f"layernorm_{C}")
+    # remapped rows: write into the tail of a [B, rows+30, C] concat buffer
+    cat = torch.zeros(B * (rows + 30), C, dtype=torch.float16, device=DEV)
+    ops.layernorm(xd[:B * 30], cat, gam.to(DEV), bet.to(DEV), B, 30, rows + 30, rows)
+    cref = torch.zeros(B, rows + 30, C)
+    cref[:, rows:] = F.layer_norm(x[:B * 30], (C,), gam, bet, 1e-5).view(B, 30, C)
+    check(cat, cref.view(-1, C), f"layernorm_remap_{C}")
+
+
+# ------------------------------------------------------------------------------------------- rela
+def _rela_closed_form(x, hid, f, rects, nvalid, poison, B, H, W, C, mo):
+    acc = torch.zeros(B, H, W, C)
+    for b in range(B):
+        for i in range(int(nvalid[b])):
+            t, bo, l, r = [int(v) for v in rects[b, i]]
+            acc[b, t:bo, l:r] += f[b, i]
+    y = 0.5 * ((hid.view(B, H, W, C) + acc / mo) + x.view(B, H, W, C))
+    for b in range(B):
+        if poison[b]:
+            y[b] = float("nan")
+    return y.view(B * H * W, C)
+
+
+@pytest.mark.parametrize("C,hw", [(64, 8), (320, 32)])
+def test_rela_pool_merge(C, hw):
+    B, mo = 2, 30
+    boxes = np.zeros((B, mo, 4), np.float32)
+    masks = np.zeros((B, mo), np.float32)
+    boxes[0, :4] = [(0.0, 0.0, 0.5, 0.5), (0.25, 0.25, 1.0, 1.0), (0.6, 0.1, 0.9, 0.45), (0.13, 0.55, 0.41, 0.99)]
+    masks[0, :4] = 1
+    boxes[1, :2] = [(0.1, 0.2, 0.8, 0.9), (0.5, 0.5, 1.2, 1.3)]
+    masks[1, :2] = 1
+    rects, nvalid, poison = host.box_rects(boxes, masks, hw, hw)
+    hid, hidd = h16(rnd(f"rh{C}", (B * hw * hw, C)))
+    x, xd = h16(rnd(f"rx{C}", (B * hw * hw, C)))
+    dr, dn, dp = (torch.from_numpy(a).to(DEV) for a in (rects, nvalid, poison))
+    feat = torch.empty(B * mo, C, dtype=torch.float16, device=DEV)
+    ops.rela_pool(hidd, B, hw, hw, C, dr, dn, dp, mo, feat)
+    ref = torch.zeros(B, mo, C)
+    hv = hid.view(B, hw, hw, C)
+    for b in range(B):
+        for i in range(int(nvalid[b])):
+            t, bo, l, r = [int(v) for v in rects[b, i]]
+            ref[b, i] = hv[b, t:bo, l:r].reshape(-1, C).mean(0)
+    check(feat, ref.view(B * mo, C), f"rela_pool_{C}_{hw}")
+    f, fd = h16(rnd(f"rf{C}", (B * mo, C)))
+    y = torch.empty(B * hw * hw, C, dtype=torch.float16, device=DEV)
+    ops.rela_merge(xd, hidd, fd, B, hw, hw, C, dr, dn, dp, mo, y)
+    check(y, _rela_closed_form(x, hid, f.view(B, mo, C), rects, nvalid, poison, B, hw, hw, C, mo), f"rela_merge_{C}_{hw}")
+
+
+def test_rela_poison_and_null():
+    B, mo, C, hw = 2, 30, 64, 8
+    boxes = np.zeros((B, mo, 4), np.float32)
+    masks = np.zeros((B, mo), np.float32)
+    boxes[0, :2] = [(0.1, 0.1, 0.6, 0.6), (0.7, 0.2, 0.2, 0.5)]   # second: right < left -> NaN sample
+    masks[0, :2] = 1
+    rects, nvalid, poison = host.box_rects(boxes, masks, hw, hw)
+    assert list(nvalid) == [2, 0] and list(poison) == [1, 0]
+    hid, hidd = h16(rnd("ph", (B * hw * hw, C)))
+    x, xd = h16(rnd("px", (B * hw * hw, C)))
+    f, fd = h16(rnd("pf", (B * mo, C)))
+    dr, dn, dp = (torch.from_numpy(a).to(DEV) for a in (rects, nvalid, poison))
+    y = torch.empty(B * hw * hw, C, dtype=torch.float16, device=DEV)
+    ops.rela_merge(xd, hidd, fd, B, hw, hw, C, dr, dn, dp, mo, y)
+    y = y.float().cpu().view(B, -1)
+    assert torch.isnan(y[0]).all(), "poisoned sample must be NaN everywhere (reference: 0 * NaN)"
+    ref1 = 0.5 * (hid.view(B, -1)[1] + x.view(B, -1)[1])      # null grounding: (LN3(x) + x) / 2
+    assert torch.allclose(y[1], ref1, rtol=1e-3, atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------- small kernels
+def test_posnet_input_and_timestep_embedding():
+    from oracle import unet_ref
+    B, mo, dim = 2, 30, 768
+    boxes = torch.from_numpy(np.abs(recipe.uniform("gpu.pb", (B, mo, 4), 3)))
+    masks = torch.zeros(B, mo)
+    masks[0, :5] = 1
+    masks[1, :1] = 1
+    emb = rnd("pe", (B, mo, dim))
+    npos, nxy = rnd("pnp", (dim,), 0.5), rnd("pnx", (64,), 0.5)
+    out = torch.empty(B * mo, dim + 64, dtype=torch.float16, device=DEV)
+    ops.posnet_input(boxes.to(DEV), masks.to(DEV), emb.to(DEV), npos.to(DEV), nxy.to(DEV), 8, out)
+    m = masks.unsqueeze(-1)
+    ref = torch.cat([emb * m + (1 - m) * npos, unet_ref.fourier_embed(boxes, 8) * m + (1 - m) * nxy], -1)
+    check(out, ref.view(B * mo, -1), "posnet_input")
+    t = torch.tensor([1.0, 21.0, 500.0, 981.0])
+    te = torch.empty(4, 320, dtype=torch.float16, device=DEV)
+    ops.timestep_embedding(t.to(DEV), 320, te)
+    check(te, unet_ref.timestep_embedding(t, 320), "timestep_embedding")
+    x, xd = h16(rnd("sx", (16, 1280)) * 3)
+    y = torch.empty_like(xd)
+    ops.silu(xd, y)
+    check(y, F.silu(x), "silu")
+
+
+def test_sampler_arithmetic_bit_exact():
+    """cfg_combine + plms_update reproduce plms.py:123,126-161 bit-for-bit in fp32."""
+    from oracle import plms_ref
+    B, hw = 2, 16
+    n = B * 4 * hw * hw
+    sched = host.make_schedule(50, host.alphas_cumprod())
+    ref_s = plms_ref.make_schedule(50)
+    for k in ("ddim_alphas", "ddim_alphas_prev", "ddim_sqrt_one_minus_alphas"):
+        assert np.array_equal(np.asarray(sched[k], np.float64), np.asarray(ref_s[k], np.float64)), k
+    x = rnd("bx", (B, 4, hw, hw))
+    es = [rnd(f"be{j}", (B, 4, hw, hw)) for j in range(4)]
+    e2b = torch.cat([es[0], es[1]], 0).to(DEV)
+    e = torch.empty(B, 4, hw, hw, dtype=torch.float32, device=DEV)
+    ops.cfg_combine(e2b, 7.5, e)
+    assert torch.equal(e.cpu(), es[1] + 7.5 * (es[0] - es[1]))
+    e0, e1, e2, e3 = es
+    cases = [((1.0,), 1.0, e0), (host.PLMS_COEFS[0][0], host.PLMS_COEFS[0][1], (e0 + e1) / 2),
+             (host.PLMS_COEFS[1][0], host.PLMS_COEFS[1][1], (3 * e0 - e1) / 2),
+             (host.PLMS_COEFS[2][0], host.PLMS_COEFS[2][1], (23 * e0 - 16 * e1 + 5 * e2) / 12),
+             (host.PLMS_COEFS[3][0], host.PLMS_COEFS[3][1], (55 * e0 - 59 * e1 + 37 * e2 - 9 * e3) / 24)]
+    for index in (49, 10, 0):
+        for coefs, div, ep in cases:
+            olds = es[1:len(coefs)]
+            xp = torch.empty_like(e)
+            sq_at, s1m, sq_ap, dirc = host.step_coefs(sched, index)
+            ops.plms_update(x.to(DEV), e0.to(DEV), [o.to(DEV) for o in olds], coefs, div, sq_at, s1m, sq_ap, dirc, xp)
+            a_t = torch.full((B, 1, 1, 1), float(sched["ddim_alphas"][index]))
+            a_prev = torch.full((B, 1, 1, 1), float(sched["ddim_alphas_prev"][index]))
+            s1 = torch.full((B, 1, 1, 1), float(sched["ddim_sqrt_one_minus_alphas"][index]))
+            pred_x0 = (x - s1 * ep) / a_t.sqrt()
+            ref = a_prev.sqrt() * pred_x0 + (1.0 - a_prev).sqrt() * ep
+            assert torch.equal(xp.cpu(), ref), (index, coefs, float((xp.cpu() - ref).abs().max()))

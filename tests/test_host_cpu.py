@@ -1,0 +1,208 @@
+"""CPU tests (no GPU): C-ABI library loads and exports what include/gligen_hip.h declares, host logic
+(box rectangles, schedules, packing layouts, sampler tables), and loud failure without a GPU."""
+import ctypes
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(__file__))
+import golden_cases as gc
+from layoutllm_t2i_amd import _lib, arch, host, recipe
+from layoutllm_t2i_amd.arch import TINY, UNetConfig
+from layoutllm_t2i_amd.weights import geglu_interleave, pack_conv3x3, pack_state_dict
+from oracle import plms_ref, unet_ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+# ------------------------------------------------------------------------------------------- C ABI
+def _ensure_built():
+    if not os.path.exists(_lib.LIB_PATH):
+        from layoutllm_t2i_amd.csrc.build import build
+        build(verbose=False)
+
+
+def test_library_exports_every_declared_symbol():
+    _ensure_built()
+    hdr = open(os.path.join(ROOT, "include", "gligen_hip.h")).read()
+    declared = set(re.findall(r"\bint\s+(gl_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 19, declared
+    l = _lib.lib()                      # also checks ABI version + struct sizes
+    for name in declared:
+        assert hasattr(l, name), f"{name} declared in gligen_hip.h but not exported"
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    assert l.gl_abi_version() == 1
+    assert l.gl_sizeof_gemm_args() == ctypes.sizeof(_lib.GemmArgs)
+    assert l.gl_sizeof_conv_args() == ctypes.sizeof(_lib.ConvArgs)
+    assert l.gl_sizeof_attn_args() == ctypes.sizeof(_lib.AttnArgs)
+
+
+def test_bad_arguments_are_rejected_without_a_gpu():
+    _ensure_built()
+    l = _lib.lib()
+    g = _lib.GemmArgs()
+    assert l.gl_gemm(ctypes.byref(g), None) == -1          # null pointers -> GL_ERR_BAD_ARG, no launch
+    a = _lib.AttnArgs()
+    assert l.gl_attention(ctypes.byref(a), None) == -1
+    assert l.gl_layernorm(None, 0, None, 0, None, None, 1, 1, 1, 0, 64, 1e-5, None) == -1
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_product_path_fails_loudly_without_gpu():
+    from layoutllm_t2i_amd import ops
+    from layoutllm_t2i_amd.model import UNetModel
+    with pytest.raises((_lib.HipLibraryError, RuntimeError, AssertionError)):
+        UNetModel(TINY, recipe.state_dict(TINY, 0), device="cuda:0")
+    with pytest.raises(_lib.HipLibraryError):
+        ops.gemm(torch.zeros(64, 64, dtype=torch.float16), torch.zeros(64, 64, dtype=torch.float16),
+                 torch.zeros(64, 64, dtype=torch.float16))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "layoutllm_t2i_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), fn
+
+
+# ------------------------------------------------------------------------------------------- arch / packing
+def test_param_table_full_model():
+    shapes = arch.param_shapes(UNetConfig())
+    assert len(shapes) == 1238
+    assert arch.count_params(UNetConfig()) == 1_261_457_796
+    assert shapes["input_blocks.0.0.weight"] == (320, 4, 3, 3)
+    assert shapes["output_blocks.11.1.transformer_blocks.0.rela_fuse.attn.to_k.weight"] == (320, 768)
+    plan = arch.build_plan(UNetConfig())
+    assert len(plan.res_layers()) == 22 and len(plan.st_layers()) == 16
+
+
+def test_geglu_interleave_layout():
+    t = torch.arange(2 * 64).float()
+    p = geglu_interleave(t)
+    assert p[:32].tolist() == list(range(0, 32)) and p[32:64].tolist() == list(range(64, 96))
+    assert p[64:96].tolist() == list(range(32, 64)) and p[96:].tolist() == list(range(96, 128))
+
+
+def test_conv_pack_layout():
+    w = torch.arange(2 * 3 * 9).float().reshape(2, 3, 3, 3)
+    p = pack_conv3x3(w, cin_pad=8).float().reshape(2, 3, 3, 8)
+    for ky in range(3):
+        for kx in range(3):
+            assert torch.equal(p[:, ky, kx, :3], w[:, :, ky, kx])
+            assert float(p[:, ky, kx, 3:].abs().max()) == 0
+
+
+def test_pack_state_dict_cpu_tiny():
+    P = pack_state_dict(recipe.state_dict(TINY, 0), TINY, "cpu", recipe.sd_first_conv(TINY, 0))
+    assert P.w["emb_all.w"].shape == (P.emb_total, TINY.time_embed_dim)
+    assert P.emb_total == sum(l.cout for l in P.plan.res_layers())
+    assert P.w["input_blocks.0.0.w"].shape == (64, 9 * 64)
+    t = "input_blocks.1.1.transformer_blocks.0"
+    assert P.w[t + ".attn1.qkv.w"].shape == (192, 64) and P.w[t + ".attn2.kv.w"].shape == (128, 768)
+    assert abs(P.s[t + ".fuser.tanh_attn"]) > 0.25
+    with pytest.raises(KeyError):
+        pack_state_dict({}, TINY, "cpu")
+
+
+# ------------------------------------------------------------------------------------------- host logic
+def _closed_form(hid, f, rects, nvalid, poison, mo):
+    B, H, W, C = hid.shape
+    acc = torch.zeros_like(hid)
+    for b in range(B):
+        for i in range(int(nvalid[b])):
+            t, bo, l, r = [int(v) for v in rects[b, i]]
+            acc[b, t:bo, l:r] += f[b, i]
+    out = hid + acc / mo
+    for b in range(B):
+        if poison[b]:
+            out[b] = float("nan")
+    return out
+
+
+@pytest.mark.parametrize("variant,hw", [("normal", 8), ("degenerate", 8), ("null", 8), ("clamp", 8), ("maskgap", 16), ("empty_slice", 8)])
+def test_box_rects_closed_form_equals_reference(variant, hw):
+    """host.box_rects + the closed form used by the HIP kernels reproduce the reference's
+    RelationCrossAttention goldens (break rule, clamping, python slices, NaN poison)."""
+    name = {"normal": "rela_normal", "degenerate": "rela_degenerate", "null": "rela_null", "clamp": "rela_clamp",
+            "maskgap": "rela_maskgap", "empty_slice": "rela_empty_slice"}[variant]
+    case = next(c for c in gc.CASES if c["name"] == name)
+    inp = {a: torch.from_numpy(v) for a, v in gc.case_inputs(case).items()}
+    C, heads, mo = case["C"], case["heads"], 30
+    sd = {"r." + n: torch.from_numpy(np.asarray(recipe.tensor(f"golden.{name}.{n}", s, 0)))
+          for n, s in arch.rela_params("", C, gc.CTX).items()}
+    rects, nvalid, poison = host.box_rects(inp["boxes"].numpy(), inp["masks"].numpy(), hw, hw)
+    B = inp["x"].shape[0]
+    hid = torch.nn.functional.layer_norm(inp["x"], (C,), sd["r.norm3.weight"], sd["r.norm3.bias"]).view(B, hw, hw, C)
+    feat = torch.zeros(B, mo, C)
+    for b in range(B):
+        for i in range(int(nvalid[b])):
+            t, bo, l, r = [int(v) for v in rects[b, i]]
+            feat[b, i] = hid[b, t:bo, l:r].reshape(-1, C).mean(0)
+    with torch.no_grad():
+        f = feat + torch.tanh(sd["r.alpha_attn"]) * unet_ref.attention(
+            sd, "r.attn", torch.nn.functional.layer_norm(feat, (C,), sd["r.norm1.weight"], sd["r.norm1.bias"]),
+            inp["relations"], inp["relations"], heads)
+        f = f + torch.tanh(sd["r.alpha_dense"]) * unet_ref.feed_forward(
+            sd, "r.ff", torch.nn.functional.layer_norm(f, (C,), sd["r.norm2.weight"], sd["r.norm2.bias"]))
+    out = _closed_form(hid, f, rects, nvalid, poison, mo).view(B, hw * hw, C).numpy()
+    ref = np.load(os.path.join(GOLD, name + ".npz"))["out"]
+    np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-4, equal_nan=True)
+
+
+def test_box_rects_edge_semantics():
+    b = np.zeros((1, 30, 4), np.float32)
+    m = np.zeros((1, 30), np.float32)
+    b[0, 0] = (0.999, 0.0, 1.0, 1.0)      # x0 = int(63.936) = 63, x1 = 64 -> 1 px wide at w = 64
+    b[0, 1] = (0.5, 0.5, 0.5, 0.9)        # zero width -> break
+    b[0, 2] = (0.1, 0.1, 0.9, 0.9)
+    m[0, :3] = 1
+    rects, nvalid, poison = host.box_rects(b, m, 64, 64)
+    assert nvalid[0] == 1 and poison[0] == 0 and tuple(rects[0, 0]) == (0, 64, 63, 64)
+    b[0, 0] = (-0.5, 0.0, 0.5, 0.5)       # negative x0: int(-32.0) = -32 -> python slice(-32, 32) on w = 64 == [32, 32) -> empty
+    rects, nvalid, poison = host.box_rects(b, m, 64, 64)
+    assert nvalid[0] == 1 and poison[0] == 1
+
+
+def test_schedule_and_alpha_match_reference_goldens():
+    for S in (10, 50):
+        g = np.load(os.path.join(GOLD, f"schedule_s{S}.npz"))
+        acp = host.alphas_cumprod()
+        np.testing.assert_array_equal(acp, g["alphas_cumprod"])
+        s = host.make_schedule(S, acp)
+        np.testing.assert_array_equal(s["ddim_timesteps"], g["ddim_timesteps"])
+        np.testing.assert_array_equal(s["ddim_alphas"], g["ddim_alphas"])
+        np.testing.assert_array_equal(s["ddim_alphas_prev"], g["ddim_alphas_prev"])
+        np.testing.assert_array_equal(s["ddim_sqrt_one_minus_alphas"], g["ddim_sqrt_one_minus_alphas"])
+    g = np.load(os.path.join(GOLD, "alpha_gen.npz"))
+    assert host.alpha_generator(50, [0.3, 0.0, 0.7]) == list(g["a50"])
+    assert host.alpha_generator(20, [0.5, 0.25, 0.25]) == pytest.approx(list(g["a20"]))
+    assert host.alpha_generator(7, None) == list(g["a7"])
+    # 102 UNet evaluations per image at S = 50 (step 0 twice, cond + uncond)
+    assert 2 * (50 + 1) == 102
+
+
+def test_interface_surface_matches_reference_names():
+    import inspect
+    from layoutllm_t2i_amd import interface as I
+    from layoutllm_t2i_amd.sampler import PLMSSampler
+    sig = lambda f: list(inspect.signature(f).parameters)
+    assert sig(I.generate_batch_images) == ["all_models", "captions", "labels", "bboxes", "clip_model", "clip_processor", "device"]
+    assert sig(I.generate_one_image) == ["all_models", "caption", "label", "bbox", "clip_model", "clip_processor", "device"]
+    assert sig(I.run_batch_images) == ["all_models", "args", "meta", "starting_noise", "clip_model", "clip_processor", "device"]
+    assert sig(I.run_one_image) == sig(I.run_batch_images)
+    assert sig(I.load_all_models) == ["ckpt", "device"] and sig(I.load_ckpt) == ["ckpt_path", "device"]
+    assert sig(PLMSSampler.sample) == ["self", "S", "shape", "input", "uc", "guidance_scale", "mask", "x0"]
+    assert sig(PLMSSampler.__init__) == ["self", "diffusion", "model", "schedule", "alpha_generator_func", "set_alpha_scale"]
+    assert I.convert_xywh_to_ltrb([0.1, 0.2, 0.3, 0.4]) == pytest.approx([0.1, 0.2, 0.4, 0.6])
+
+    class M:
+        fuser_scale = 1
+    m = M()
+    I.set_alpha_scale(m, 0)
+    assert m.fuser_scale == 0
