@@ -192,7 +192,7 @@ def main():
     # ---- CPU baseline: the oracle on the host cores, bounded sample (rank 0, N=1 only)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and sd_cpu_sample is not None:
         from oracle import unet_ref
-        cores = os.cpu_count() or 1
+        cores = min(os.cpu_count() or 1, 32)   # eager torch scales poorly past ~32 threads on this op mix
         torch.set_num_threads(cores)
         ci = {k: torch.from_numpy(v) for k, v in recipe.synth_inputs(cfg, 1, side, n_boxes=args.boxes, n_rel=3, seed=1234).items()}
         with torch.no_grad():

@@ -66,12 +66,18 @@ def plms_sample(eps_fn: Callable[[torch.Tensor, torch.Tensor, int, float], torch
     old_eps: List[torch.Tensor] = []
 
     def x_prev_of(xc, e, index):
-        a_t = torch.full((b, 1, 1, 1), float(sched["ddim_alphas"][index]))
-        a_prev = torch.full((b, 1, 1, 1), float(sched["ddim_alphas_prev"][index]))
-        s1m = torch.full((b, 1, 1, 1), float(sched["ddim_sqrt_one_minus_alphas"][index]))
-        pred_x0 = (xc - s1m * e) / a_t.sqrt()
-        dir_xt = (1.0 - a_prev).sqrt() * e
-        return a_prev.sqrt() * pred_x0 + dir_xt
+        # get_x_prev_and_pred_x0 (plms.py:126-140) with sigma = 0.  The three scalar square roots are taken
+        # with numpy float32 (IEEE correctly rounded, = what the reference gets on its GPU): torch's
+        # vectorised CPU sqrt is 1 ulp off on some hosts, which would make this checker platform-dependent.
+        a_t = np.float32(sched["ddim_alphas"][index])
+        a_prev = np.float32(sched["ddim_alphas_prev"][index])
+        s1m = torch.full((b, 1, 1, 1), float(np.float32(sched["ddim_sqrt_one_minus_alphas"][index])))
+        sqrt_at = torch.full((b, 1, 1, 1), float(np.sqrt(a_t)))
+        sqrt_aprev = torch.full((b, 1, 1, 1), float(np.sqrt(a_prev)))
+        dir_coef = torch.full((b, 1, 1, 1), float(np.sqrt(np.float32(1.0) - a_prev)))
+        pred_x0 = (xc - s1m * e) / sqrt_at
+        dir_xt = dir_coef * e
+        return sqrt_aprev * pred_x0 + dir_xt
 
     for i, step in enumerate(time_range):
         index = total - i - 1

@@ -387,15 +387,16 @@ def test_sampler_arithmetic_bit_exact():
              (host.PLMS_COEFS[1][0], host.PLMS_COEFS[1][1], (3 * e0 - e1) / 2),
              (host.PLMS_COEFS[2][0], host.PLMS_COEFS[2][1], (23 * e0 - 16 * e1 + 5 * e2) / 12),
              (host.PLMS_COEFS[3][0], host.PLMS_COEFS[3][1], (55 * e0 - 59 * e1 + 37 * e2 - 9 * e3) / 24)]
-    for index in (49, 10, 0):
+    for index in (49, 33, 10, 0):
         for coefs, div, ep in cases:
             olds = es[1:len(coefs)]
             xp = torch.empty_like(e)
             sq_at, s1m, sq_ap, dirc = host.step_coefs(sched, index)
             ops.plms_update(x.to(DEV), e0.to(DEV), [o.to(DEV) for o in olds], coefs, div, sq_at, s1m, sq_ap, dirc, xp)
-            a_t = torch.full((B, 1, 1, 1), float(sched["ddim_alphas"][index]))
-            a_prev = torch.full((B, 1, 1, 1), float(sched["ddim_alphas_prev"][index]))
-            s1 = torch.full((B, 1, 1, 1), float(sched["ddim_sqrt_one_minus_alphas"][index]))
-            pred_x0 = (x - s1 * ep) / a_t.sqrt()
-            ref = a_prev.sqrt() * pred_x0 + (1.0 - a_prev).sqrt() * ep
+            # scalar sqrt with numpy float32 (IEEE correctly rounded; torch's CPU sqrt is 1 ulp off on some hosts)
+            full = lambda v: torch.full((B, 1, 1, 1), float(v))
+            a_t, a_prev = np.float32(sched["ddim_alphas"][index]), np.float32(sched["ddim_alphas_prev"][index])
+            s1 = full(np.float32(sched["ddim_sqrt_one_minus_alphas"][index]))
+            pred_x0 = (x - s1 * ep) / full(np.sqrt(a_t))
+            ref = full(np.sqrt(a_prev)) * pred_x0 + full(np.sqrt(np.float32(1.0) - a_prev)) * ep
             assert torch.equal(xp.cpu(), ref), (index, coefs, float((xp.cpu() - ref).abs().max()))
