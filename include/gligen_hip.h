@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GL_ABI_VERSION 1
+#define GL_ABI_VERSION 2
 
 /* error codes (negative; positive values are hipError_t) */
 #define GL_ERR_BAD_ARG (-1)
@@ -66,6 +66,10 @@ typedef struct gl_gemm_args {
     const float* gate;                  /* device scalar for GL_EPI_GATE_RES */
     const void* rowbias; int32_t ld_rowbias; int32_t rows_per_sample;  /* fp16 [B, N] */
     int32_t hw;                         /* GL_OUT_F32_NCHW: pixels per sample */
+    /* optional split-K scratch: when the (M, N) grid would leave most of the 256 CUs idle (8x8 / 16x16
+     * levels: 40-160 tiles) and K is long, K is cut into slices that write fp32 partial tiles here and a
+     * second kernel reduces them and applies the epilogue.  NULL disables splitting. */
+    void* workspace;    int64_t workspace_bytes;
 } gl_gemm_args;
 
 /*
@@ -185,6 +189,10 @@ int gl_abi_version(void);
 int gl_sizeof_gemm_args(void);
 int gl_sizeof_conv_args(void);
 int gl_sizeof_attn_args(void);
+/* tuning knobs for A/B measurements: key 1 = GEMM/conv operand staging (1 = global_load_lds direct to LDS,
+ * default; 0 = through registers); key 2 = tile shape policy (0 auto, 1 force 128x128, 2 prefer 128x160).
+ * Results do not depend on these knobs beyond fp32 summation order in split-K. */
+int gl_set_option(int key, int value);
 /* one-time per-process setup (raises dynamic-LDS limits of the tiled kernels); idempotent */
 int gl_init(void);
 

@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgligen_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # enum gl_epilogue / gl_out_mode
 EPI_BIAS, EPI_SILU, EPI_GEGLU, EPI_RES, EPI_GATE_RES, EPI_ROWBIAS = range(6)
@@ -38,6 +38,7 @@ class GemmArgs(C.Structure):
         ("gate", vp),
         ("rowbias", vp), ("ld_rowbias", i32), ("rows_per_sample", i32),
         ("hw", i32),
+        ("workspace", vp), ("workspace_bytes", i64),
     ]
 
 
@@ -85,6 +86,7 @@ PROTOTYPES = {
     "gl_sizeof_conv_args": (i32, []),
     "gl_sizeof_attn_args": (i32, []),
     "gl_init": (i32, []),
+    "gl_set_option": (i32, [i32, i32]),
 }
 
 _lib = None

@@ -18,17 +18,23 @@
 #include "common.h"
 #include "gligen_hip.h"
 
+// 16 zero bytes in global memory: the source of masked lanes (rows past M/N, conv halo) of the
+// direct-to-LDS loads, which cannot be predicated per lane.
+__device__ uint4 g_zero16[4];
+
 namespace {
 
 constexpr int BK = 64;
+int g_opt_glds = 1;          // staging variant: 1 = global_load_lds (direct to LDS), 0 = via registers
+int g_opt_tile = 0;          // 0 = auto; 1 = force 128x128 (N >= 256); 2 = prefer 128x160 whenever N % 160 == 0
 
 struct ConvGeom {
     const half_t* in;
     int B, Hin, Win, Cin, Hout, Wout, stride, ups;
 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool CONV>
-__global__ __launch_bounds__(256) void gemm_kernel(gl_gemm_args p, ConvGeom cg) {
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, bool GLDS>
+__global__ __launch_bounds__(256) void gemm_kernel(gl_gemm_args p, ConvGeom cg, int splitk, int kt_per_split) {
     constexpr int TM = BM / WAVES_M / 32;
     constexpr int TN = BN / WAVES_N / 32;
     constexpr int ACH = BM * (BK / 8) / 256;   // 16-byte chunks of the A tile per thread
@@ -48,7 +54,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(gl_gemm_args p, ConvGeom cg) 
     const int m0 = blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
     const int M = p.M, N = p.N, K = p.K;
-    const int nk = K / BK;
+    const int kt_begin = blockIdx.z * kt_per_split;
+    const int kt_end = min(K / BK, kt_begin + kt_per_split);
 
     const int srow = tid >> 3;   // staging row 0..31 (+32 i)
     const int skc = tid & 7;     // 16-byte chunk within the 128-byte tile row
@@ -143,6 +150,63 @@ __global__ __launch_bounds__(256) void gemm_kernel(gl_gemm_args p, ConvGeom cg) 
         }
     };
 
+    // Direct-to-LDS staging (global_load_lds_dwordx4): a wave's 64 lanes fill 8 consecutive 128-byte
+    // tile rows (LDS destination = wave-uniform base + lane*16, i.e. linear), so the XOR swizzle is applied
+    // to the per-lane GLOBAL source chunk instead: LDS slot (row r, chunk c') receives global chunk
+    // c' ^ ((r >> 1) & 7) and the fragment reads below use the same involution.
+    auto issue_tile = [&](int kt, int buf) {
+        const int k0 = kt * BK;
+        const half_t* zsrc = reinterpret_cast<const half_t*>(g_zero16);
+        int ky = 0, kx = 0, ci0 = 0;
+        if constexpr (CONV) {
+            const int tap = k0 / cg.Cin;
+            ci0 = k0 - tap * cg.Cin;
+            ky = tap / 3;
+            kx = tap - ky * 3;
+        }
+        const bool second = (!CONV) && (A2g != nullptr) && (k0 >= p.ksplit);
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) {
+            const int r = srow + 32 * i;
+            const int gc = (skc ^ ((r >> 1) & 7)) << 3;
+            const half_t* src = zsrc;
+            if constexpr (CONV) {
+                if (cb[i] >= 0) {
+                    int iy, ix;
+                    bool ok;
+                    if (cg.ups) {
+                        const int uy = coy[i] + ky - 1, ux = cox[i] + kx - 1;
+                        ok = (uy >= 0) && (uy < cg.Hout) && (ux >= 0) && (ux < cg.Wout);
+                        iy = uy >> 1; ix = ux >> 1;
+                    } else {
+                        iy = coy[i] * cg.stride + ky - 1;
+                        ix = cox[i] * cg.stride + kx - 1;
+                        ok = (iy >= 0) && (iy < cg.Hin) && (ix >= 0) && (ix < cg.Win);
+                    }
+                    if (ok) src = cg.in + ((size_t)(cb[i] * cg.Hin + iy) * cg.Win + ix) * cg.Cin + ci0 + gc;
+                }
+            } else {
+                const int m = m0 + r;
+                if (m < M) src = second ? (A2g + (size_t)m * p.lda2 + (k0 - p.ksplit) + gc) : (Ag + (size_t)m * p.lda + k0 + gc);
+            }
+            half_t* dst = As + (size_t)(buf * BM + 32 * i + wave * 8) * BK;
+            __builtin_amdgcn_global_load_lds(
+                reinterpret_cast<const __attribute__((address_space(1))) void*>(reinterpret_cast<uintptr_t>(src)),
+                reinterpret_cast<__attribute__((address_space(3))) void*>(reinterpret_cast<uintptr_t>(dst)), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < BCH; ++i) {
+            const int r = srow + 32 * i;
+            const int gc = (skc ^ ((r >> 1) & 7)) << 3;
+            const int n = n0 + r;
+            const half_t* src = (n < N) ? (Wg + (size_t)n * K + k0 + gc) : zsrc;
+            half_t* dst = Bs + (size_t)(buf * BN + 32 * i + wave * 8) * BK;
+            __builtin_amdgcn_global_load_lds(
+                reinterpret_cast<const __attribute__((address_space(1))) void*>(reinterpret_cast<uintptr_t>(src)),
+                reinterpret_cast<__attribute__((address_space(3))) void*>(reinterpret_cast<uintptr_t>(dst)), 16, 0, 0);
+        }
+    };
+
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi)
@@ -154,13 +218,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(gl_gemm_args p, ConvGeom cg) 
     const int frow = lane & 31;
     const int fhi = lane >> 5;
 
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
+    if constexpr (GLDS) {
+        issue_tile(kt_begin, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    } else {
+        load_tile(kt_begin);
+        store_tile(0);
+        __syncthreads();
+    }
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int buf = (kt - kt_begin) & 1;
+        if (kt + 1 < kt_end) {
+            if constexpr (GLDS) issue_tile(kt + 1, buf ^ 1); else load_tile(kt + 1);
+        }
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             half8_t xf[TM], wf[TN];
@@ -180,13 +252,35 @@ __global__ __launch_bounds__(256) void gemm_kernel(gl_gemm_args p, ConvGeom cg) 
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = mfma32(wf[ni], xf[mi], acc[mi][ni]);
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
+        if constexpr (GLDS) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (kt + 1 < kt_end) store_tile(buf ^ 1);
+        }
         __syncthreads();
     }
 
+    if (splitk > 1) {
+        // split-K slice: raw fp32 partial tile -> workspace[z][m][n]; epilogue happens in splitk_reduce_kernel
+        float* ws = reinterpret_cast<float*>(p.workspace) + (size_t)blockIdx.z * M * N;
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            const int m = m0 + wm * (TM * 32) + mi * 32 + frow;
+            if (m >= M) continue;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int n = n0 + wn * (TN * 32) + ni * 32 + 8 * rg + 4 * fhi;
+                    if (n >= N) continue;
+                    *reinterpret_cast<float4*>(ws + (size_t)m * N + n) =
+                        make_float4(acc[mi][ni][rg * 4], acc[mi][ni][rg * 4 + 1], acc[mi][ni][rg * 4 + 2], acc[mi][ni][rg * 4 + 3]);
+                }
+        }
+        return;
+    }
+
     // ------------------------------------------------------------------ epilogue
-    // lane holds output row m = ... + (lane & 31) and, per 4-register group rg, the 4 consecutive
-    // channels n = ... + 8*rg + 4*(lane >> 5) + {0,1,2,3}.
     const float* __restrict__ bias = p.bias;
     const half_t* __restrict__ res = reinterpret_cast<const half_t*>(p.res);
     const half_t* __restrict__ rowbias = reinterpret_cast<const half_t*>(p.rowbias);
@@ -194,107 +288,243 @@ __global__ __launch_bounds__(256) void gemm_kernel(gl_gemm_args p, ConvGeom cg) 
     float gate = 1.0f;
     if (epi == GL_EPI_GATE_RES) gate = p.gate[0];
 
+    if (p.out_mode == GL_OUT_F32_NCHW) {
+        // out conv only (N = 4): lane holds row m = ..+(lane&31) and channels 8*rg + 4*(lane>>5) + {0..3}
 #pragma unroll
-    for (int mi = 0; mi < TM; ++mi) {
-        const int m = m0 + wm * (TM * 32) + mi * 32 + frow;
-        if (m >= M) continue;
-        if (epi == GL_EPI_GEGLU) {
-            if constexpr (TN % 2 == 0) {
-                half_t* out = reinterpret_cast<half_t*>(p.out);
+        for (int mi = 0; mi < TM; ++mi) {
+            const int m = m0 + wm * (TM * 32) + mi * 32 + frow;
+            if (m >= M) continue;
+            float* out = reinterpret_cast<float*>(p.out);
+            const int b = m / p.hw;
+            const int pix = m - b * p.hw;
 #pragma unroll
-                for (int ni = 0; ni < TN; ni += 2) {
+            for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) {
-                        const int nl = 8 * rg + 4 * fhi;
-                        const int nx = n0 + wn * (TN * 32) + ni * 32 + nl;   // packed row of x
-                        if (nx >= N) continue;
-                        const int ng = nx + 32;                               // packed row of gate
-                        const int oc = ((n0 + wn * (TN * 32)) >> 1) + (ni >> 1) * 32 + nl;
-                        half4_t o;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            float xv = acc[mi][ni][rg * 4 + j];
-                            float gv = acc[mi][ni + 1][rg * 4 + j];
-                            if (bias) { xv += bias[nx + j]; gv += bias[ng + j]; }
-                            o[j] = (half_t)(xv * gelu_erf_f(gv));
-                        }
-                        *reinterpret_cast<half4_t*>(out + (size_t)m * p.ldc + oc) = o;
-                    }
-                }
-            }
-            continue;
-        }
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni) {
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int n = n0 + wn * (TN * 32) + ni * 32 + 8 * rg + 4 * fhi;
-                if (n >= N) continue;
-                float v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = acc[mi][ni][rg * 4 + j];
-                if (bias) {
-                    const float4 bv = *reinterpret_cast<const float4*>(bias + n);
-                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-                }
-                if (epi == GL_EPI_SILU) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
-                } else if (epi == GL_EPI_RES) {
-                    const half4_t rv = *reinterpret_cast<const half4_t*>(res + (size_t)m * p.ldres + n);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] += (float)rv[j];
-                } else if (epi == GL_EPI_GATE_RES) {
-                    const half4_t rv = *reinterpret_cast<const half4_t*>(res + (size_t)m * p.ldres + n);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = (float)rv[j] + gate * v[j];
-                } else if (epi == GL_EPI_ROWBIAS) {
-                    const int s = m / p.rows_per_sample;
-                    const half4_t rv = *reinterpret_cast<const half4_t*>(rowbias + (size_t)s * p.ld_rowbias + n);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] += (float)rv[j];
-                }
-                if (p.out_mode == GL_OUT_F32_NCHW) {
-                    float* out = reinterpret_cast<float*>(p.out);
-                    const int b = m / p.hw;
-                    const int pix = m - b * p.hw;
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int n = n0 + wn * (TN * 32) + ni * 32 + 8 * rg + 4 * fhi;
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (n + j < N) out[((size_t)b * N + n + j) * p.hw + pix] = v[j];
-                } else {
-                    half_t* out = reinterpret_cast<half_t*>(p.out);
-                    half4_t o;
+                        if (n + j < N) out[((size_t)b * N + n + j) * p.hw + pix] = acc[mi][ni][rg * 4 + j] + (bias ? bias[n + j] : 0.0f);
+                }
+        }
+        return;
+    }
+
+    // Row-major fp16 output: the fp32 accumulator tile of each wave is staged through LDS (the operand
+    // buffers are dead by now), 32 rows x 64 columns (two MFMA tiles) at a time, so that every lane then
+    // owns 8 CONSECUTIVE channels of one row: residual / row-bias reads and the output stores are 16-byte
+    // accesses, 128 contiguous bytes per row per 8 lanes, instead of 8-byte pieces scattered over 32 rows
+    // straight from the MFMA register layout.  For GEGLU a pass is exactly one [x(32) | gate(32)] pair.
+    constexpr int EPS = 64 + 4;                            // padded fp32 row stride (conflict-free float4 writes)
+    constexpr int NPASS = (TN + 1) / 2;
+    float* stage = reinterpret_cast<float*>(smem) + wave * (32 * EPS);
+    half_t* outp = reinterpret_cast<half_t*>(p.out);
+    const bool geglu = (epi == GL_EPI_GEGLU);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (half_t)v[j];
-                    *reinterpret_cast<half4_t*>(out + (size_t)m * p.ldc + n) = o;
+    for (int mi = 0; mi < TM; ++mi) {
+        const int mbase = m0 + wm * (TM * 32) + mi * 32;
+#pragma unroll
+        for (int np = 0; np < NPASS; ++np) {
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int ni = np * 2 + t;
+                if (ni < TN) {
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg)
+                        *reinterpret_cast<float4*>(stage + frow * EPS + t * 32 + 8 * rg + 4 * fhi) =
+                            make_float4(acc[mi][ni][rg * 4], acc[mi][ni][rg * 4 + 1], acc[mi][ni][rg * 4 + 2], acc[mi][ni][rg * 4 + 3]);
+                }
+            }
+            __syncthreads();
+            const int nbase = n0 + wn * (TN * 32) + np * 64;   // first (packed) column of this pass
+            if (geglu) {
+                // 32 output columns per pass, 8 per lane: 4 lanes per row, 16 rows per sweep
+#pragma unroll
+                for (int ps = 0; ps < 2; ++ps) {
+                    const int r = ps * 16 + (lane >> 2);
+                    const int pc = (lane & 3) * 8;
+                    const int m = mbase + r;
+                    const int nx = nbase + pc;
+                    if (m < M && nx < N) {
+                        const float4 x0 = *reinterpret_cast<const float4*>(stage + r * EPS + pc);
+                        const float4 x1 = *reinterpret_cast<const float4*>(stage + r * EPS + pc + 4);
+                        const float4 g0 = *reinterpret_cast<const float4*>(stage + r * EPS + pc + 32);
+                        const float4 g1 = *reinterpret_cast<const float4*>(stage + r * EPS + pc + 36);
+                        float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                        float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                        half8_t o;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            float a = xv[j], b = gv[j];
+                            if (bias) { a += bias[nx + j]; b += bias[nx + 32 + j]; }
+                            o[j] = (half_t)(a * gelu_erf_f(b));
+                        }
+                        st16(outp + (size_t)m * p.ldc + (nbase >> 1) + pc, *reinterpret_cast<uint4*>(&o));
+                    }
+                }
+            } else {
+                const int ncols = (np * 2 + 1 < TN) ? 64 : 32;  // a trailing odd tile fills only half the pass
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps) {
+                    const int r = ps * 8 + (lane >> 3);
+                    const int c = (lane & 7) * 8;
+                    const int m = mbase + r;
+                    const int n = nbase + c;
+                    if (c < ncols && m < M && n < N) {
+                        const float4 a0 = *reinterpret_cast<const float4*>(stage + r * EPS + c);
+                        const float4 a1 = *reinterpret_cast<const float4*>(stage + r * EPS + c + 4);
+                        float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                        if (bias) {
+                            const float4 b0 = *reinterpret_cast<const float4*>(bias + n);
+                            const float4 b1 = *reinterpret_cast<const float4*>(bias + n + 4);
+                            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+                            v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                        }
+                        if (epi == GL_EPI_SILU) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] = silu_f(v[j]);
+                        } else if (epi == GL_EPI_RES || epi == GL_EPI_GATE_RES) {
+                            uint4 raw = ld16(res + (size_t)m * p.ldres + n);
+                            const half8_t rv = *reinterpret_cast<half8_t*>(&raw);
+                            if (epi == GL_EPI_RES) {
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) v[j] += (float)rv[j];
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) v[j] = (float)rv[j] + gate * v[j];
+                            }
+                        } else if (epi == GL_EPI_ROWBIAS) {
+                            const int sidx = m / p.rows_per_sample;
+                            uint4 raw = ld16(rowbias + (size_t)sidx * p.ld_rowbias + n);
+                            const half8_t rv = *reinterpret_cast<half8_t*>(&raw);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] += (float)rv[j];
+                        }
+                        half8_t o;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) o[j] = (half_t)v[j];
+                        st16(outp + (size_t)m * p.ldc + n, *reinterpret_cast<uint4*>(&o));
+                    }
                 }
             }
         }
     }
 }
 
+// Sums the split-K partial tiles and applies the epilogue (fp16 row-major outputs only).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(gl_gemm_args p, int splitk) {
+    const int M = p.M, N = p.N;
+    const int nq = N / 4;
+    const size_t total = (size_t)M * nq;
+    const float* ws = reinterpret_cast<const float*>(p.workspace);
+    const half_t* res = reinterpret_cast<const half_t*>(p.res);
+    const half_t* rowbias = reinterpret_cast<const half_t*>(p.rowbias);
+    half_t* out = reinterpret_cast<half_t*>(p.out);
+    float gate = 1.0f;
+    if (p.epi == GL_EPI_GATE_RES) gate = p.gate[0];
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int m = (int)(idx / nq);
+        const int n = (int)(idx - (size_t)m * nq) * 4;
+        float4 a = *reinterpret_cast<const float4*>(ws + (size_t)m * N + n);
+        for (int z = 1; z < splitk; ++z) {
+            const float4 b = *reinterpret_cast<const float4*>(ws + ((size_t)z * M + m) * N + n);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        float v[4] = {a.x, a.y, a.z, a.w};
+        if (p.bias) {
+            const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+            v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+        }
+        if (p.epi == GL_EPI_SILU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
+        } else if (p.epi == GL_EPI_RES) {
+            const half4_t rv = *reinterpret_cast<const half4_t*>(res + (size_t)m * p.ldres + n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += (float)rv[j];
+        } else if (p.epi == GL_EPI_GATE_RES) {
+            const half4_t rv = *reinterpret_cast<const half4_t*>(res + (size_t)m * p.ldres + n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (float)rv[j] + gate * v[j];
+        } else if (p.epi == GL_EPI_ROWBIAS) {
+            const int sidx = m / p.rows_per_sample;
+            const half4_t rv = *reinterpret_cast<const half4_t*>(rowbias + (size_t)sidx * p.ld_rowbias + n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += (float)rv[j];
+        }
+        half4_t o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (half_t)v[j];
+        *reinterpret_cast<half4_t*>(out + (size_t)m * p.ldc + n) = o;
+    }
+}
+
+// How many K slices: only when the tile grid underfills the chip and K is long enough to amortise
+// the fp32 partial round trip.
+inline int choose_splitk(const gl_gemm_args& g, int tiles) {
+    const int nk = g.K / BK;
+    if (!g.workspace || g.epi == GL_EPI_GEGLU || g.out_mode != GL_OUT_F16_ROWMAJOR) return 1;
+    if (tiles >= 200 || nk < 16) return 1;
+    int s = (480 + tiles - 1) / tiles;
+    if (s > nk / 8) s = nk / 8;
+    if (s > 16) s = 16;
+    while (s > 1 && (int64_t)s * g.M * g.N * 4 > g.workspace_bytes) --s;
+    return s < 2 ? 1 : s;
+}
+
 template <int BM, int BN>
 constexpr int lds_bytes() { return 2 * (BM + BN) * BK * (int)sizeof(half_t); }
 
-template <int BM, int BN, int WM, int WN, bool CONV>
+template <int BM, int BN, int WM, int WN, bool CONV, bool GLDS>
 int launch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
-    dim3 grid(gl_cdiv(g.M, BM), gl_cdiv(g.N, BN));
+    const int mt = gl_cdiv(g.M, BM), nt = gl_cdiv(g.N, BN);
+    const int nk = g.K / BK;
+    const int splitk = choose_splitk(g, mt * nt);
+    const int kper = gl_cdiv(nk, splitk);
+    const int zs = gl_cdiv(nk, kper);          // slices that actually have work
+    dim3 grid(mt, nt, zs);
     constexpr int lds = lds_bytes<BM, BN>();
-    gemm_kernel<BM, BN, WM, WN, CONV><<<grid, dim3(256), lds, st>>>(g, cg);
+    gemm_kernel<BM, BN, WM, WN, CONV, GLDS><<<grid, dim3(256), lds, st>>>(g, cg, zs, kper);
     GL_CHECK_LAUNCH();
+    if (zs > 1) {
+        const size_t total = (size_t)g.M * (g.N / 4);
+        int nblk = (int)((total + 255) / 256);
+        if (nblk > 2048) nblk = 2048;
+        splitk_reduce_kernel<<<dim3(nblk), dim3(256), 0, st>>>(g, zs);
+        GL_CHECK_LAUNCH();
+    }
     return 0;
 }
 
 template <bool CONV>
 int dispatch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K % BK) != 0 || (g.N % 4) != 0) return GL_ERR_BAD_ARG;
+    if (g.out_mode == GL_OUT_F16_ROWMAJOR && ((g.N % 8) != 0 || (g.ldc % 8) != 0)) return GL_ERR_BAD_ARG;
+    if (g.res != nullptr && (g.ldres % 8) != 0) return GL_ERR_BAD_ARG;
+    if (g.rowbias != nullptr && (g.ld_rowbias % 8) != 0) return GL_ERR_BAD_ARG;
     if (g.epi == GL_EPI_GEGLU && (g.N % 64) != 0) return GL_ERR_BAD_ARG;
     if (g.a2 != nullptr && (g.ksplit % BK) != 0) return GL_ERR_BAD_ARG;
     if ((g.epi == GL_EPI_RES || g.epi == GL_EPI_GATE_RES) && g.res == nullptr) return GL_ERR_BAD_ARG;
     if (g.epi == GL_EPI_GATE_RES && g.gate == nullptr) return GL_ERR_BAD_ARG;
     if (g.epi == GL_EPI_ROWBIAS && (g.rowbias == nullptr || g.rows_per_sample <= 0)) return GL_ERR_BAD_ARG;
-    if ((g.N % 128) == 0) return launch<128, 128, 2, 2, CONV>(g, cg, st);
-    return launch<256, 64, 4, 1, CONV>(g, cg, st);
+    // tile shape: 128x160 (4 waves x 32x160) when it divides N exactly -- N = 320/640/960/... are the
+    // channel widths of this UNet and 128-wide tiles would waste up to 17 % of the MFMA work there;
+    // (convs, whose K is long, prefer it even when 128 also divides N: measured 442 vs 408 and 607 vs 536 TF/s
+    // at the 32x32 and 16x16 levels); otherwise 128x128; 256x64 only for narrow outputs.
+    const bool geglu = (g.epi == GL_EPI_GEGLU);
+    int shape = 0;                                   // 0: 128x128, 1: 128x160, 2: 256x64
+    if (g.N < 256 && (g.N % 128) != 0) shape = 2;
+    else if (!geglu && (g.N % 160) == 0 && ((g.N % 128) != 0 || CONV || g_opt_tile == 2)) shape = 1;
+    if (g_opt_tile == 1 && g.N >= 256) shape = 0;
+    if (g_opt_glds) {
+        if (shape == 1) return launch<128, 160, 4, 1, CONV, true>(g, cg, st);
+        if (shape == 0) return launch<128, 128, 2, 2, CONV, true>(g, cg, st);
+        return launch<256, 64, 4, 1, CONV, true>(g, cg, st);
+    }
+    if (shape == 1) return launch<128, 160, 4, 1, CONV, false>(g, cg, st);
+    if (shape == 0) return launch<128, 128, 2, 2, CONV, false>(g, cg, st);
+    return launch<256, 64, 4, 1, CONV, false>(g, cg, st);
 }
 
 }  // namespace
@@ -320,15 +550,31 @@ extern "C" int gl_conv3x3(const gl_conv_args* a, void* stream) {
     return dispatch<true>(g, cg, (hipStream_t)stream);
 }
 
-extern "C" int gl_init_gemm(void) {
+template <int BM, int BN, int WM, int WN>
+int set_lds_attr() {
     hipError_t e;
-    e = hipFuncSetAttribute((const void*)gemm_kernel<128, 128, 2, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<128, 128>());
+    const int lds = lds_bytes<BM, BN>();
+    e = hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WM, WN, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)gemm_kernel<128, 128, 2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<128, 128>());
+    e = hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WM, WN, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)gemm_kernel<256, 64, 4, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<256, 64>());
+    e = hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WM, WN, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)gemm_kernel<256, 64, 4, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<256, 64>());
+    e = hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WM, WN, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
     return 0;
+}
+
+extern "C" int gl_init_gemm(void) {
+    int e = set_lds_attr<128, 128, 2, 2>();
+    if (e) return e;
+    e = set_lds_attr<128, 160, 4, 1>();
+    if (e) return e;
+    return set_lds_attr<256, 64, 4, 1>();
+}
+
+extern "C" int gl_set_option_gemm(int key, int value) {
+    if (key == 1) { g_opt_glds = value ? 1 : 0; return 0; }
+    if (key == 2) { g_opt_tile = value; return 0; }
+    return GL_ERR_BAD_ARG;
 }

@@ -42,7 +42,23 @@ def _rows(t: torch.Tensor, name: str):
     return t.shape[0], t.shape[1], t.stride(0)
 
 
+_WS = {}
+WORKSPACE_BYTES = 96 << 20
+
+
+def _workspace(device) -> torch.Tensor:
+    """Per-device split-K scratch (fp32 partial tiles); allocated once so captured graphs stay valid."""
+    key = (device.type, device.index)
+    t = _WS.get(key)
+    if t is None:
+        t = torch.empty(WORKSPACE_BYTES // 4, dtype=F32, device=device)
+        _WS[key] = t
+    return t
+
+
 def _fill_epilogue(g: GemmArgs, epi, out, N_out, bias, res, gate, rowbias, rows_per_sample, nchw_hw):
+    ws = _workspace(out.device)
+    g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     g.bias = _ptr(bias)
     if bias is not None:
         _req(bias, F32, "bias")
@@ -273,3 +289,8 @@ def pack_latent(x: torch.Tensor, Cpad: int, reps: int, out: torch.Tensor):
     B, Cc, h, w = x.shape
     check(_lib.lib().gl_pack_latent(x.data_ptr(), B, Cc, h * w, Cpad, reps, out.data_ptr(), _stream()), "gl_pack_latent")
     return out
+
+
+def set_option(key: int, value: int) -> None:
+    """Tuning knob for A/B measurements (see gl_set_option in include/gligen_hip.h)."""
+    check(_lib.lib().gl_set_option(key, value), "gl_set_option")

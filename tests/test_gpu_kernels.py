@@ -101,6 +101,32 @@ def test_gemm_geglu(C):
     check(out, x * F.gelu(g), f"gemm_geglu_{C}")
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(512, 1280, 5120, "res"), (512, 1280, 2560, "bias"), (2048, 1280, 5120, "gate"), (100, 640, 2048, "rowbias")])
+def test_gemm_split_k(M, N, K, epi):
+    """few output tiles + long K -> the launcher cuts K into slices (fp32 partials + reduce/epilogue kernel)."""
+    a, ad = h16(rnd(f"ska{M}{K}", (M, K)))
+    w, wd = h16(rnd(f"skw{N}{K}", (N, K), 1 / math.sqrt(K)))
+    b = rnd(f"skb{N}", (N,), 0.1)
+    r, rd = h16(rnd(f"skr{M}{N}", (M, N)))
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    base = F.linear(a, w, b)
+    if epi == "res":
+        ops.gemm(ad, wd, out, b.to(DEV), EPI_RES, res=rd)
+        ref = base + r
+    elif epi == "gate":
+        gate = torch.tensor([0.61], dtype=torch.float32, device=DEV)
+        ops.gemm(ad, wd, out, b.to(DEV), EPI_GATE_RES, res=rd, gate=gate)
+        ref = r + 0.61 * base
+    elif epi == "rowbias":
+        rb, rbd = h16(rnd("skrb", (4, N)))
+        ops.gemm(ad, wd, out, b.to(DEV), EPI_ROWBIAS, rowbias=rbd, rows_per_sample=25)
+        ref = base + rb.repeat_interleave(25, 0)
+    else:
+        ops.gemm(ad, wd, out, b.to(DEV))
+        ref = base
+    check(out, ref, f"gemm_splitk_{M}x{N}x{K}_{epi}")
+
+
 def test_gemm_two_source():
     M, K1, K2, N = 260, 128, 192, 256
     a1, a1d = h16(rnd("ta1", (M, K1)))
@@ -128,7 +154,7 @@ def _nhwc(x):  # [B,C,H,W] -> [B*H*W, C]
 
 
 @pytest.mark.parametrize("mode", ["s1", "s2", "up"])
-@pytest.mark.parametrize("Cin,Cout,hw", [(64, 128, 8), (320, 320, 16)])
+@pytest.mark.parametrize("Cin,Cout,hw", [(64, 128, 8), (320, 320, 16), (1280, 1280, 8)])
 def test_conv3x3(mode, Cin, Cout, hw):
     B = 2
     x, _ = h16(rnd(f"cx{Cin}{mode}", (B, Cin, hw, hw)))

@@ -102,6 +102,10 @@ def collect():
 def main():
     which = set(sys.argv[1:]) or {"gemm", "conv", "attn", "norm"}
     init_device()
+    if "KB_GLDS" in os.environ:
+        ops.set_option(1, int(os.environ["KB_GLDS"]))
+    if "KB_TILE" in os.environ:
+        ops.set_option(2, int(os.environ["KB_TILE"]))
     gemms, convs, attns, gns, lns = collect()
     h = lambda *s: torch.randn(*s, device=DEV).to(torch.float16)
     tot_on = tot_off = 0.0
