@@ -22,11 +22,15 @@
 
 namespace {
 
+int g_attn_qt2 = 0;
 constexpr int KT = 64;          // keys per tile
 constexpr int VSTR = KT + 4;    // V^T LDS row stride in halfs (136 B: odd number of 8-byte slots)
 
-template <int DQK>
+template <int DQK, int QT>
 __global__ __launch_bounds__(256) void attn_kernel(gl_attn_args p) {
+    // QT = 32-query sub-tiles per wave: 2 for small head dims (256 queries per block: every K/V tile
+    // staged in LDS and every K/V fragment read from LDS is reused twice), 1 where the O accumulator
+    // (NDT x 16 registers per sub-tile) is too large.
     constexpr int NKS = DQK / 16;            // MFMA k-steps over the head dim
     constexpr int NDT = (DQK + 31) / 32;     // 32-wide head-dim tiles of O
     constexpr int KSTR = DQK + 8;            // K LDS row stride in halfs (odd number of 16-byte slots)
@@ -35,9 +39,17 @@ __global__ __launch_bounds__(256) void attn_kernel(gl_attn_args p) {
     constexpr int K_PER_T = (K_ITEMS + 255) / 256;
     constexpr int V_ITEMS = NDT * 32 * (KT / 8);
     constexpr int V_PER_T = (V_ITEMS + 255) / 256;
+    constexpr int QBLK = 4 * 32 * QT;        // queries per block
+    // If the padded head-dim tile has a spare row, V^T row OC is kept at 1.0 so that the P.V MFMA also
+    // produces the softmax denominator (sum_k P) in O column OC: saves 32 VALU adds per tile.
+    constexpr bool ONES = (NDT * 32 > DQK);
+    constexpr int OC = NDT * 32 - 1;
 
-    __shared__ __attribute__((aligned(16))) half_t Ks[KT * KSTR];
-    __shared__ __attribute__((aligned(16))) half_t Vs[NDT * 32 * VSTR];
+    // double-buffered K / V^T tiles: one barrier per 64-key tile
+    constexpr int KBUF = KT * KSTR;
+    constexpr int VBUF = NDT * 32 * VSTR;
+    __shared__ __attribute__((aligned(16))) half_t Ksm[2 * KBUF];
+    __shared__ __attribute__((aligned(16))) half_t Vsm[2 * VBUF];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -46,7 +58,7 @@ __global__ __launch_bounds__(256) void attn_kernel(gl_attn_args p) {
     const int hi = lane >> 5;
     const int b = blockIdx.z;
     const int h = blockIdx.y;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = blockIdx.x * QBLK + wave * (32 * QT);
     const int d = p.d, Nq = p.Nq, Nk = p.Nk;
 
     const half_t* __restrict__ Qg = reinterpret_cast<const half_t*>(p.q) + (size_t)b * p.q_bstride + (size_t)h * d;
@@ -54,9 +66,10 @@ __global__ __launch_bounds__(256) void attn_kernel(gl_attn_args p) {
     const half_t* __restrict__ Vg = reinterpret_cast<const half_t*>(p.vt) + (size_t)(b * p.H + h) * d * p.ldvt;
 
     // Q fragments (B operand: row = query, k = head-dim chunk 2*ks + hi)
-    half8_t qf[NKS];
-    {
-        int q = q0 + ql;
+    half8_t qf[QT][NKS];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        int q = q0 + qt * 32 + ql;
         if (q >= Nq) q = Nq - 1;
         const half_t* qrow = Qg + (size_t)q * p.ldq;
 #pragma unroll
@@ -64,125 +77,159 @@ __global__ __launch_bounds__(256) void attn_kernel(gl_attn_args p) {
             const int c0 = (2 * ks + hi) * 8;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
             if (c0 < d) v = ld16(qrow + c0);
-            qf[ks] = *reinterpret_cast<half8_t*>(&v);
+            qf[qt][ks] = *reinterpret_cast<half8_t*>(&v);
         }
     }
 
-    f32x16 o[NDT];
+    f32x16 o[QT][NDT];
+    float m_run[QT], l_run[QT];
 #pragma unroll
-    for (int dt = 0; dt < NDT; ++dt)
+    for (int qt = 0; qt < QT; ++qt) {
+        m_run[qt] = -INFINITY;
+        l_run[qt] = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[dt][r] = 0.0f;
-    float m_run = -INFINITY;
-    float l_run = 0.0f;
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[qt][dt][r] = 0.0f;
+    }
     const float c_scale = p.scale * 1.4426950408889634f;
 
     uint4 rk[K_PER_T], rv[V_PER_T];
+    // tile-invariant staging coordinates (no per-tile divisions / 64-bit address rebuilds)
+    const half_t* kptr[K_PER_T];
+    const half_t* vptr[V_PER_T];
+    int krow[K_PER_T], klds[K_PER_T], vlds[V_PER_T];
+    bool kok[K_PER_T], vok[V_PER_T], vone[V_PER_T];
+#pragma unroll
+    for (int i = 0; i < K_PER_T; ++i) {
+        const int idx = tid + 256 * i;
+        const int row = idx / KCH;
+        const int c = idx - row * KCH;
+        krow[i] = row;
+        kok[i] = (idx < K_ITEMS) && (c * 8 < d);
+        klds[i] = row * KSTR + c * 8;
+        kptr[i] = Kg + (size_t)row * p.ldk + c * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < V_PER_T; ++i) {
+        const int idx = tid + 256 * i;
+        const int row = idx >> 3;      // head-dim column
+        const int c = idx & 7;         // 8-key chunk
+        vok[i] = (idx < V_ITEMS) && (row < d);
+        vone[i] = ONES && (idx < V_ITEMS) && (row == OC);
+        vlds[i] = row * VSTR + c * 8;
+        vptr[i] = Vg + (size_t)row * p.ldvt + c * 8;
+    }
+    const size_t kstep = (size_t)KT * p.ldk;
 
     auto load_tile = [&](int key0) {
 #pragma unroll
         for (int i = 0; i < K_PER_T; ++i) {
-            const int idx = tid + 256 * i;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (idx < K_ITEMS) {
-                const int row = idx / KCH;
-                const int c = idx - row * KCH;
-                const int key = key0 + row;
-                if (key < Nk && c * 8 < d) v = ld16(Kg + (size_t)key * p.ldk + c * 8);
-            }
+            if (kok[i] && key0 + krow[i] < Nk) v = ld16(kptr[i]);
+            kptr[i] += kstep;
             rk[i] = v;
         }
 #pragma unroll
         for (int i = 0; i < V_PER_T; ++i) {
-            const int idx = tid + 256 * i;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (idx < V_ITEMS) {
-                const int row = idx >> 3;      // head-dim column
-                const int c = idx & 7;         // 8-key chunk
-                if (row < d) v = ld16(Vg + (size_t)row * p.ldvt + key0 + c * 8);
-            }
+            if (vone[i]) v = make_uint4(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u);   // fp16 1.0 x 8
+            if (vok[i]) v = ld16(vptr[i]);
+            vptr[i] += KT;
             rv[i] = v;
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](int buf) {
+        half_t* Ksw = Ksm + buf * KBUF;
+        half_t* Vsw = Vsm + buf * VBUF;
 #pragma unroll
-        for (int i = 0; i < K_PER_T; ++i) {
-            const int idx = tid + 256 * i;
-            if (idx < K_ITEMS) {
-                const int row = idx / KCH;
-                const int c = idx - row * KCH;
-                st16(Ks + row * KSTR + c * 8, rk[i]);
-            }
-        }
+        for (int i = 0; i < K_PER_T; ++i)
+            if (tid + 256 * i < K_ITEMS) st16(Ksw + klds[i], rk[i]);
 #pragma unroll
-        for (int i = 0; i < V_PER_T; ++i) {
-            const int idx = tid + 256 * i;
-            if (idx < V_ITEMS) {
-                const int row = idx >> 3;
-                const int c = idx & 7;
-                uint2* dst = reinterpret_cast<uint2*>(Vs + row * VSTR + c * 8);   // 8-byte aligned only
+        for (int i = 0; i < V_PER_T; ++i)
+            if (tid + 256 * i < V_ITEMS) {
+                uint2* dst = reinterpret_cast<uint2*>(Vsw + vlds[i]);   // 8-byte aligned only
                 dst[0] = make_uint2(rv[i].x, rv[i].y);
                 dst[1] = make_uint2(rv[i].z, rv[i].w);
             }
-        }
     };
 
     const int ntiles = (Nk + KT - 1) / KT;
     load_tile(0);
+    store_tile(0);
+    __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
         const int key0 = t * KT;
-        __syncthreads();            // all waves finished reading the previous tile
-        store_tile();
-        __syncthreads();
-        if (t + 1 < ntiles) load_tile(key0 + KT);
+        const half_t* Ks = Ksm + (t & 1) * KBUF;
+        const half_t* Vs = Vsm + (t & 1) * VBUF;
+        if (t + 1 < ntiles) load_tile(key0 + KT);      // global -> registers, in flight during the MFMAs below
+        const bool tail = (key0 + KT > Nk);
 
-        // ---- S^T = K . Q^T : two 32-key halves
-        f32x16 s[2];
+        // ---- S^T = K . Q^T : two 32-key halves, K fragments shared by the QT query sub-tiles
+        f32x16 s[QT][2];
+        const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int kh = 0; kh < 2; ++kh) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[kh][r] = 0.0f;
+        for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
                 const half8_t kf = *reinterpret_cast<const half8_t*>(Ks + (kh * 32 + ql) * KSTR + (2 * ks + hi) * 8);
-                s[kh] = mfma32(kf, qf[ks], s[kh]);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) s[qt][kh] = mfma32(kf, qf[qt][ks], ks == 0 ? zero16 : s[qt][kh]);
             }
-        }
-        // ---- online softmax (this lane: query ql, keys kh*32 + (r&3) + 8*(r>>2) + 4*hi)
-        float tmax = -INFINITY;
-        const bool tail = (key0 + KT > Nk);
+        // ---- online softmax (this lane: query ql of each sub-tile, keys kh*32 + (r&3) + 8*(r>>2) + 4*hi).
+        // VALU-lean form (the first version spent 32 VALU instructions per MFMA): the row max is taken on the
+        // raw scores, the softmax scale rides in one FMA with the exp2 argument, pairs are converted with
+        // v_cvt_pk_f16_f32, and the O / l rescale is DEFERRED: the running max is only raised (and the 16*NDT
+        // accumulator registers rescaled through AGPR read/mul/write) when some row's tile max exceeds it by
+        // more than 2^DEFER.  Until then P <= 2^DEFER, exactly representable-range for fp16 with the same
+        // relative precision, and l / O accumulate in fp32, so results are unchanged to rounding.
+        constexpr float DEFER = 8.0f;
+        uint4 pf[QT][4];
 #pragma unroll
-        for (int kh = 0; kh < 2; ++kh)
+        for (int qt = 0; qt < QT; ++qt) {
+            if (tail) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = s[kh][r] * c_scale;
-                if (tail) {
-                    const int key = key0 + kh * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (key >= Nk) v = -INFINITY;
+                for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = key0 + kh * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        if (key >= Nk) s[qt][kh][r] = -INFINITY;
+                    }
+            }
+            auto sv = [&](int i) -> float { return s[qt][i >> 4][i & 15]; };
+            float tmax = max3f(sv(0), sv(1), sv(2));
+#pragma unroll
+            for (int i = 3; i < 31; i += 2) tmax = max3f(tmax, sv(i), sv(i + 1));
+            tmax = fmaxf(tmax, sv(31));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * c_scale;
+            if (__any(tmax > m_run[qt] + DEFER)) {
+                const float m_new = fmaxf(m_run[qt], tmax);
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
+                m_run[qt] = m_new;
+                if constexpr (!ONES) l_run[qt] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[qt][dt][r] *= alpha;
+            }
+            const float nm = -m_run[qt];
+            float psum = 0.0f;
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const float p0 = __builtin_amdgcn_exp2f(fmaf(s[qt][kh][r], c_scale, nm));
+                    const float p1 = __builtin_amdgcn_exp2f(fmaf(s[qt][kh][r + 1], c_scale, nm));
+                    if constexpr (!ONES) psum += p0 + p1;
+                    f32x2 pv = {p0, p1};
+                    const half2_t ph = __builtin_convertvector(pv, half2_t);
+                    const unsigned pw = *reinterpret_cast<const unsigned*>(&ph);
+                    const int j = kh * 2 + (r >> 3);
+                    const int e = (r & 7) >> 1;
+                    if (e == 0) pf[qt][j].x = pw; else if (e == 1) pf[qt][j].y = pw; else if (e == 2) pf[qt][j].z = pw; else pf[qt][j].w = pw;
                 }
-                s[kh][r] = v;
-                tmax = fmaxf(tmax, v);
-            }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m_run, tmax);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
-        float psum = 0.0f;
-        half8_t pf[4];
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(s[kh][r] - m_new);
-                psum += pv;
-                pf[kh * 2 + (r >> 3)][r & 7] = (half_t)pv;
-            }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-
+            if constexpr (!ONES) l_run[qt] += psum;
+        }
         // ---- O^T += V^T . P^T : k-step j covers keys 16j..16j+15 in the order (e&3) + 8*(e>>2) + 4*hi
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -193,29 +240,37 @@ __global__ __launch_bounds__(256) void attn_kernel(gl_attn_args p) {
                 const uint2 hi8 = *reinterpret_cast<const uint2*>(vrow + 8);
                 uint4 v4 = make_uint4(lo.x, lo.y, hi8.x, hi8.y);
                 const half8_t vf = *reinterpret_cast<half8_t*>(&v4);
-                o[dt] = mfma32(vf, pf[j], o[dt]);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) o[qt][dt] = mfma32(vf, *reinterpret_cast<const half8_t*>(&pf[qt][j]), o[qt][dt]);
             }
         }
+        if (t + 1 < ntiles) store_tile((t + 1) & 1);   // other buffer: last read one iteration ago, before the barrier
+        __syncthreads();
     }
 
     // ---- finalize: O /= l, write fp16.  lane holds head-dim columns dt*32 + 8*rg + 4*hi + {0..3}
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
-    const int q = q0 + ql;
-    if (q < Nq) {
-        half_t* orow = reinterpret_cast<half_t*>(p.out) + (size_t)b * p.o_bstride + (size_t)q * p.ldo + (size_t)h * d;
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt)
+    for (int qt = 0; qt < QT; ++qt) {
+        float lpart = l_run[qt];
+        if constexpr (ONES) lpart = (hi == 1) ? o[qt][NDT - 1][15] : 0.0f;   // column OC = 31 of the last tile lives in (r = 15, hi = 1)
+        const float l_tot = lpart + __shfl_xor(lpart, 32, 64);
+        const float inv = 1.0f / l_tot;
+        const int q = q0 + qt * 32 + ql;
+        if (q < Nq) {
+            half_t* orow = reinterpret_cast<half_t*>(p.out) + (size_t)b * p.o_bstride + (size_t)q * p.ldo + (size_t)h * d;
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int c = dt * 32 + 8 * rg + 4 * hi;
-                if (c < d) {
-                    half4_t ov;
+            for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) ov[jj] = (half_t)(o[dt][rg * 4 + jj] * inv);
-                    *reinterpret_cast<half4_t*>(orow + c) = ov;
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int c = dt * 32 + 8 * rg + 4 * hi;
+                    if (c < d) {
+                        half4_t ov;
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) ov[jj] = (half_t)(o[qt][dt][rg * 4 + jj] * inv);
+                        *reinterpret_cast<half4_t*>(orow + c) = ov;
+                    }
                 }
-            }
+        }
     }
 }
 
@@ -244,12 +299,23 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const half_t* __restri
     }
 }
 
-template <int DQK>
+template <int DQK, int QT>
 int launch_attn(const gl_attn_args& a, hipStream_t st) {
-    dim3 grid(gl_cdiv(a.Nq, 128), a.H, a.B);
-    attn_kernel<DQK><<<grid, dim3(256), 0, st>>>(a);
+    dim3 grid(gl_cdiv(a.Nq, 128 * QT), a.H, a.B);
+    attn_kernel<DQK, QT><<<grid, dim3(256), 0, st>>>(a);
     GL_CHECK_LAUNCH();
     return 0;
+}
+
+// 64 queries per wave once there are enough query blocks to fill the chip with 256-query tiles
+template <int DQK>
+int launch_attn_auto(const gl_attn_args& a, hipStream_t st) {
+    // measured on MI355X (d = 40, N = 4096): QT = 2 needs 280 registers -> 1 wave/SIMD and runs 651 us vs
+    // 479 us for QT = 1 at 3 waves/SIMD; occupancy beats staging reuse here, so QT = 2 stays opt-in.
+    if constexpr (DQK <= 80) {
+        if (g_attn_qt2 && a.Nq >= 256) return launch_attn<DQK, 2>(a, st);
+    }
+    return launch_attn<DQK, 1>(a, st);
 }
 
 }  // namespace
@@ -261,13 +327,18 @@ extern "C" int gl_attention(const gl_attn_args* a, void* stream) {
     if (a->ldvt < ((a->Nk + 63) / 64) * 64) return GL_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int d = a->d;
-    if (d <= 16) return launch_attn<16>(*a, st);
-    if (d <= 32) return launch_attn<32>(*a, st);
-    if (d <= 48) return launch_attn<48>(*a, st);
-    if (d <= 64) return launch_attn<64>(*a, st);
-    if (d <= 80) return launch_attn<80>(*a, st);
-    if (d <= 128) return launch_attn<128>(*a, st);
-    return launch_attn<160>(*a, st);
+    if (d <= 16) return launch_attn_auto<16>(*a, st);
+    if (d <= 32) return launch_attn_auto<32>(*a, st);
+    if (d <= 48) return launch_attn_auto<48>(*a, st);
+    if (d <= 64) return launch_attn_auto<64>(*a, st);
+    if (d <= 80) return launch_attn_auto<80>(*a, st);
+    if (d <= 128) return launch_attn_auto<128>(*a, st);
+    return launch_attn_auto<160>(*a, st);
+}
+
+extern "C" int gl_set_option_attn(int key, int value) {
+    if (key == 3) { g_attn_qt2 = value ? 1 : 0; return 0; }
+    return GL_ERR_BAD_ARG;
 }
 
 extern "C" int gl_transpose_v(const void* v, int64_t v_bstride, int32_t ldv, void* vt, int32_t ldvt, int32_t B,

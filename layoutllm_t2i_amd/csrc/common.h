@@ -7,6 +7,7 @@ typedef _Float16 half_t;
 typedef __attribute__((ext_vector_type(2))) _Float16 half2_t;
 typedef __attribute__((ext_vector_type(4))) _Float16 half4_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 half8_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
@@ -45,6 +46,13 @@ __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
+}
+
+// single v_max3_f32 (plain fmaxf chains get a canonicalising v_max per MFMA-produced operand)
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
 }
 
 __device__ __forceinline__ uint4 ld16(const void* p) { return *reinterpret_cast<const uint4*>(p); }

@@ -159,7 +159,10 @@ extern "C" int gl_pack_latent(const float* x, int32_t B, int32_t C, int32_t hw, 
 
 extern "C" int gl_init_gemm(void);
 extern "C" int gl_set_option_gemm(int key, int value);
-extern "C" int gl_set_option(int key, int value) { return gl_set_option_gemm(key, value); }
+extern "C" int gl_set_option_attn(int key, int value);
+extern "C" int gl_set_option(int key, int value) {
+    return key == 3 ? gl_set_option_attn(key, value) : gl_set_option_gemm(key, value);
+}
 
 extern "C" int gl_abi_version(void) { return GL_ABI_VERSION; }
 extern "C" int gl_sizeof_gemm_args(void) { return (int)sizeof(gl_gemm_args); }

@@ -104,6 +104,8 @@ def main():
     init_device()
     if "KB_GLDS" in os.environ:
         ops.set_option(1, int(os.environ["KB_GLDS"]))
+    if "KB_QT2" in os.environ:
+        ops.set_option(3, int(os.environ["KB_QT2"]))
     if "KB_TILE" in os.environ:
         ops.set_option(2, int(os.environ["KB_TILE"]))
     gemms, convs, attns, gns, lns = collect()
