@@ -189,8 +189,9 @@ int gl_abi_version(void);
 int gl_sizeof_gemm_args(void);
 int gl_sizeof_conv_args(void);
 int gl_sizeof_attn_args(void);
-/* tuning knobs for A/B measurements: key 1 = GEMM/conv operand staging (1 = global_load_lds direct to LDS,
- * default; 0 = through registers); key 2 = tile shape policy (0 auto, 1 force 128x128, 2 prefer 128x160).
+/* tuning knobs for A/B measurements: key 1 = GEMM/conv pipeline (0 = BK 64, 2 LDS stages, default;
+ * 1 = BK 32, 3 stages with counted vmcnt); key 2 = tile shape policy (0 auto, 1 force 128x128, 2 prefer 128x160); key 3 = attention
+ * queries per wave (0 = 32, default; 1 = 64).
  * Results do not depend on these knobs beyond fp32 summation order in split-K. */
 int gl_set_option(int key, int value);
 /* one-time per-process setup (raises dynamic-LDS limits of the tiled kernels); idempotent */

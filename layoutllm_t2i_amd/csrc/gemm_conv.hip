@@ -4,28 +4,38 @@
 //
 // A is either a plain (optionally two-source, K-split) row-major matrix, or the implicit im2col view
 // of an NHWC feature map for a 3x3 / pad 1 convolution (stride 1, stride 2, or nearest-2x-upsampled
-// input).  One K-tile (64) never straddles a filter tap because Cin % 64 == 0.
+// input).  A K-tile never straddles a filter tap because Cin % 64 == 0.
 //
-// Tiling: 256 threads = 4 waves; block tile BM x BN x 64, each wave owns a 64 x 64 sub-tile as 2x2
-// MFMA 32x32 tiles (64 fp32 accumulators / lane).  Tiles are staged global -> registers -> LDS with
-// 16-byte accesses into a double-buffered, XOR-swizzled LDS image (chunk' = chunk ^ ((row >> 1) & 7),
-// conflict-free for the 16-lane groups of ds_read_b128 on 128-byte rows); the loads of tile t+1 are
-// issued before the MFMAs of tile t and written to LDS after them (one barrier per K-tile).
+// Tiling: 256 threads = 4 waves; block tile BM x BN (128x128, 128x160 or 256x64), MFMA 32x32 tiles,
+// fp32 accumulators.  Operand tiles go global -> LDS directly (global_load_lds_dwordx4: a wave's 64
+// lanes fill 1 KiB of consecutive LDS = 8 or 16 tile rows), so the LDS image is lane-linear and the
+// bank-conflict swizzle is applied to the per-lane GLOBAL source chunk and, identically, to the
+// fragment reads (chunk' = chunk ^ f(row); f = (row>>1)&7 for 128-byte rows, (row>>2)&3 for 64-byte
+// rows: conflict-free for the 16-lane groups of ds_read_b128).  Masked lanes (rows past M/N, the conv
+// halo) read a 16-byte zero page, since LDS-DMA cannot be predicated per lane.
 //
-// The MFMA is issued "swapped" (weights as the row operand, activations as the column operand), so a
-// lane ends up holding 4 consecutive output channels n for one output row m: the epilogue does 8-byte
-// loads/stores and the GEGLU pairing (x | gate in adjacent 32-wide MFMA tiles) is lane-local.
+// Two pipelines (gl_set_option key 1):
+//   BK=64, 2 LDS stages : (default) tile t+1 is requested before the MFMAs of tile t; s_waitcnt vmcnt(0) +
+//                         barrier per K-tile.  PMC on the level-0 convs: waves wait 39 % of their lifetime,
+//                         MFMA pipe 31 % busy.
+//   BK=32, 3 LDS stages : tiles t+1 and t+2 are in flight during the MFMAs of tile t; the wait before each
+//                         barrier is a COUNTED vmcnt (only tile t must have landed) and the barrier is a raw
+//                         s_barrier (a __syncthreads would drain the LDS-DMA queue).  Measured 15-25 % SLOWER
+//                         than BK=64 on every shape of this UNet (twice the barriers and fragment-read
+//                         restarts per K outweigh the deeper prefetch), so it is kept only as an A/B knob.
+//
+// The MFMA is issued "swapped" (weights as the row operand, activations as the column operand) and the
+// epilogue restages the fp32 tile through LDS so that outputs, residuals and row-biases move as
+// 16-byte row-contiguous accesses; GEGLU pairs x|gate columns that the weight packing interleaved.
 #include "common.h"
 #include "gligen_hip.h"
 
-// 16 zero bytes in global memory: the source of masked lanes (rows past M/N, conv halo) of the
-// direct-to-LDS loads, which cannot be predicated per lane.
+// 16 zero bytes in global memory: the source of masked lanes of the direct-to-LDS loads.
 __device__ uint4 g_zero16[4];
 
 namespace {
 
-constexpr int BK = 64;
-int g_opt_glds = 1;          // staging variant: 1 = global_load_lds (direct to LDS), 0 = via registers
+int g_opt_pipe = 0;          // 0 = BK 64 / 2-stage (default, faster), 1 = BK 32 / 3-stage counted-vmcnt pipeline
 int g_opt_tile = 0;          // 0 = auto; 1 = force 128x128 (N >= 256); 2 = prefer 128x160 whenever N % 160 == 0
 
 struct ConvGeom {
@@ -33,18 +43,49 @@ struct ConvGeom {
     int B, Hin, Win, Cin, Hout, Wout, stride, ups;
 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, bool GLDS>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
+
+__device__ __forceinline__ void glds16(const half_t* src, half_t* dst) {
+    __builtin_amdgcn_global_load_lds(
+        reinterpret_cast<const __attribute__((address_space(1))) void*>(reinterpret_cast<uintptr_t>(src)),
+        reinterpret_cast<__attribute__((address_space(3))) void*>(reinterpret_cast<uintptr_t>(dst)), 16, 0, 0);
+}
+
+template <int BM, int BN, int BKT, int NST>
+constexpr int lds_bytes() {
+    constexpr int pipe = NST * (BM + BN) * BKT * (int)sizeof(half_t);
+    constexpr int epi = 4 * 32 * 68 * (int)sizeof(float);     // epilogue staging: 4 waves x 32 rows x (64+4) fp32
+    return pipe > epi ? pipe : epi;
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, int BKT, int NST>
 __global__ __launch_bounds__(256) void gemm_kernel(gl_gemm_args p, ConvGeom cg, int splitk, int kt_per_split) {
     constexpr int TM = BM / WAVES_M / 32;
     constexpr int TN = BN / WAVES_N / 32;
-    constexpr int ACH = BM * (BK / 8) / 256;   // 16-byte chunks of the A tile per thread
-    constexpr int BCH = BN * (BK / 8) / 256;
+    constexpr int CPR = BKT / 8;                 // 16-byte chunks per tile row (8 or 4)
+    constexpr int RPP = 256 / CPR;               // tile rows covered by one pass of the 256 threads
+    constexpr int RPW = 64 / CPR;                // tile rows covered by one wave instruction (1 KiB)
+    constexpr int APASS = (BM + RPP - 1) / RPP;
+    constexpr int BPASS = (BN + RPP - 1) / RPP;
+    constexpr int KSTEPS = BKT / 16;
     static_assert(WAVES_M * WAVES_N == 4, "4 waves");
-    static_assert(TM >= 1 && TN >= 1 && ACH >= 1 && BCH >= 1, "tile");
+    static_assert(BM % RPW == 0 && BN % RPW == 0, "whole wave instructions");
+    static_assert(BKT == 64 || BKT == 32, "BK");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    half_t* As = reinterpret_cast<half_t*>(smem);   // [2][BM][BK]
-    half_t* Bs = As + 2 * BM * BK;                  // [2][BN][BK]
+    half_t* As = reinterpret_cast<half_t*>(smem);   // [NST][BM][BKT]
+    half_t* Bs = As + NST * BM * BKT;               // [NST][BN][BKT]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -55,22 +96,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(gl_gemm_args p, ConvGeom cg, 
     const int n0 = blockIdx.y * BN;
     const int M = p.M, N = p.N, K = p.K;
     const int kt_begin = blockIdx.z * kt_per_split;
-    const int kt_end = min(K / BK, kt_begin + kt_per_split);
+    const int kt_end = min(K / BKT, kt_begin + kt_per_split);
+    const int nkt = kt_end - kt_begin;
 
-    const int srow = tid >> 3;   // staging row 0..31 (+32 i)
-    const int skc = tid & 7;     // 16-byte chunk within the 128-byte tile row
+    const int srow = tid / CPR;      // staging row within a pass
+    const int skc = tid % CPR;       // LDS chunk slot within the row
+    auto swz = [](int r) -> int { return BKT == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3); };
 
     const half_t* __restrict__ Ag = reinterpret_cast<const half_t*>(p.a);
     const half_t* __restrict__ A2g = reinterpret_cast<const half_t*>(p.a2);
     const half_t* __restrict__ Wg = reinterpret_cast<const half_t*>(p.w);
+    const half_t* zsrc = reinterpret_cast<const half_t*>(g_zero16);
 
-    // per-thread staging rows
-    int cb[ACH], coy[ACH], cox[ACH];   // conv: sample, out-y, out-x (cb < 0: row out of range)
+    // per-thread staging rows of the A operand
+    int cb[APASS], coy[APASS], cox[APASS];   // conv: sample, out-y, out-x (cb < 0: row out of range)
     if constexpr (CONV) {
 #pragma unroll
-        for (int i = 0; i < ACH; ++i) {
-            const int m = m0 + srow + 32 * i;
-            if (m < M) {
+        for (int i = 0; i < APASS; ++i) {
+            const int m = m0 + srow + RPP * i;
+            if (m < M && srow + RPP * i < BM) {
                 const int hw = cg.Hout * cg.Wout;
                 const int b = m / hw;
                 const int r = m - b * hw;
@@ -83,80 +127,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(gl_gemm_args p, ConvGeom cg, 
         }
     }
 
-    uint4 ra[ACH], rb[BCH];
+    // number of LDS-DMA instructions THIS wave issues per tile (passes whose rows exist for this wave)
+    int my_loads = 0;
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) my_loads += (RPP * i + wave * RPW < BM) ? 1 : 0;
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) my_loads += (RPP * i + wave * RPW < BN) ? 1 : 0;
 
-    auto load_tile = [&](int kt) {
-        const int k0 = kt * BK;
-        if constexpr (CONV) {
-            const int tap = k0 / cg.Cin;
-            const int ci0 = k0 - tap * cg.Cin;
-            const int ky = tap / 3;
-            const int kx = tap - ky * 3;
-#pragma unroll
-            for (int i = 0; i < ACH; ++i) {
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (cb[i] >= 0) {
-                    int iy, ix;
-                    bool ok;
-                    if (cg.ups) {
-                        const int uy = coy[i] + ky - 1, ux = cox[i] + kx - 1;
-                        ok = (uy >= 0) && (uy < cg.Hout) && (ux >= 0) && (ux < cg.Wout);
-                        iy = uy >> 1; ix = ux >> 1;
-                    } else {
-                        iy = coy[i] * cg.stride + ky - 1;
-                        ix = cox[i] * cg.stride + kx - 1;
-                        ok = (iy >= 0) && (iy < cg.Hin) && (ix >= 0) && (ix < cg.Win);
-                    }
-                    if (ok) {
-                        const size_t off = ((size_t)(cb[i] * cg.Hin + iy) * cg.Win + ix) * cg.Cin + ci0 + skc * 8;
-                        v = ld16(cg.in + off);
-                    }
-                }
-                ra[i] = v;
-            }
-        } else {
-            const bool second = (A2g != nullptr) && (k0 >= p.ksplit);
-#pragma unroll
-            for (int i = 0; i < ACH; ++i) {
-                const int m = m0 + srow + 32 * i;
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (m < M) {
-                    const half_t* src = second ? (A2g + (size_t)m * p.lda2 + (k0 - p.ksplit))
-                                               : (Ag + (size_t)m * p.lda + k0);
-                    v = ld16(src + skc * 8);
-                }
-                ra[i] = v;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < BCH; ++i) {
-            const int n = n0 + srow + 32 * i;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (n < N) v = ld16(Wg + (size_t)n * K + k0 + skc * 8);
-            rb[i] = v;
-        }
-    };
-
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < ACH; ++i) {
-            const int r = srow + 32 * i;
-            st16(As + (size_t)(buf * BM + r) * BK + ((skc ^ ((r >> 1) & 7)) << 3), ra[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < BCH; ++i) {
-            const int r = srow + 32 * i;
-            st16(Bs + (size_t)(buf * BN + r) * BK + ((skc ^ ((r >> 1) & 7)) << 3), rb[i]);
-        }
-    };
-
-    // Direct-to-LDS staging (global_load_lds_dwordx4): a wave's 64 lanes fill 8 consecutive 128-byte
-    // tile rows (LDS destination = wave-uniform base + lane*16, i.e. linear), so the XOR swizzle is applied
-    // to the per-lane GLOBAL source chunk instead: LDS slot (row r, chunk c') receives global chunk
-    // c' ^ ((r >> 1) & 7) and the fragment reads below use the same involution.
     auto issue_tile = [&](int kt, int buf) {
-        const int k0 = kt * BK;
-        const half_t* zsrc = reinterpret_cast<const half_t*>(g_zero16);
+        const int k0 = kt * BKT;
         int ky = 0, kx = 0, ci0 = 0;
         if constexpr (CONV) {
             const int tap = k0 / cg.Cin;
@@ -166,9 +145,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(gl_gemm_args p, ConvGeom cg, 
         }
         const bool second = (!CONV) && (A2g != nullptr) && (k0 >= p.ksplit);
 #pragma unroll
-        for (int i = 0; i < ACH; ++i) {
-            const int r = srow + 32 * i;
-            const int gc = (skc ^ ((r >> 1) & 7)) << 3;
+        for (int i = 0; i < APASS; ++i) {
+            if (RPP * i + wave * RPW >= BM) continue;          // wave-uniform: this pass has no rows for this wave
+            const int r = srow + RPP * i;
+            const int gc = (skc ^ swz(r)) << 3;
             const half_t* src = zsrc;
             if constexpr (CONV) {
                 if (cb[i] >= 0) {
@@ -189,21 +169,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(gl_gemm_args p, ConvGeom cg, 
                 const int m = m0 + r;
                 if (m < M) src = second ? (A2g + (size_t)m * p.lda2 + (k0 - p.ksplit) + gc) : (Ag + (size_t)m * p.lda + k0 + gc);
             }
-            half_t* dst = As + (size_t)(buf * BM + 32 * i + wave * 8) * BK;
-            __builtin_amdgcn_global_load_lds(
-                reinterpret_cast<const __attribute__((address_space(1))) void*>(reinterpret_cast<uintptr_t>(src)),
-                reinterpret_cast<__attribute__((address_space(3))) void*>(reinterpret_cast<uintptr_t>(dst)), 16, 0, 0);
+            glds16(src, As + (size_t)(buf * BM + RPP * i + wave * RPW) * BKT);
         }
 #pragma unroll
-        for (int i = 0; i < BCH; ++i) {
-            const int r = srow + 32 * i;
-            const int gc = (skc ^ ((r >> 1) & 7)) << 3;
+        for (int i = 0; i < BPASS; ++i) {
+            if (RPP * i + wave * RPW >= BN) continue;
+            const int r = srow + RPP * i;
+            const int gc = (skc ^ swz(r)) << 3;
             const int n = n0 + r;
             const half_t* src = (n < N) ? (Wg + (size_t)n * K + k0 + gc) : zsrc;
-            half_t* dst = Bs + (size_t)(buf * BN + 32 * i + wave * 8) * BK;
-            __builtin_amdgcn_global_load_lds(
-                reinterpret_cast<const __attribute__((address_space(1))) void*>(reinterpret_cast<uintptr_t>(src)),
-                reinterpret_cast<__attribute__((address_space(3))) void*>(reinterpret_cast<uintptr_t>(dst)), 16, 0, 0);
+            glds16(src, Bs + (size_t)(buf * BN + RPP * i + wave * RPW) * BKT);
         }
     };
 
@@ -218,44 +193,67 @@ __global__ __launch_bounds__(256) void gemm_kernel(gl_gemm_args p, ConvGeom cg, 
     const int frow = lane & 31;
     const int fhi = lane >> 5;
 
-    if constexpr (GLDS) {
-        issue_tile(kt_begin, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    } else {
-        load_tile(kt_begin);
-        store_tile(0);
-        __syncthreads();
-    }
-
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const int buf = (kt - kt_begin) & 1;
-        if (kt + 1 < kt_end) {
-            if constexpr (GLDS) issue_tile(kt + 1, buf ^ 1); else load_tile(kt + 1);
-        }
+    auto compute_tile = [&](int buf) {
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
+        for (int ks = 0; ks < KSTEPS; ++ks) {
             half8_t xf[TM], wf[TN];
             const int c = ks * 2 + fhi;
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi) {
                 const int r = wm * (TM * 32) + mi * 32 + frow;
-                xf[mi] = *reinterpret_cast<const half8_t*>(As + (size_t)(buf * BM + r) * BK + ((c ^ ((r >> 1) & 7)) << 3));
+                xf[mi] = *reinterpret_cast<const half8_t*>(As + (size_t)(buf * BM + r) * BKT + ((c ^ swz(r)) << 3));
             }
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni) {
                 const int r = wn * (TN * 32) + ni * 32 + frow;
-                wf[ni] = *reinterpret_cast<const half8_t*>(Bs + (size_t)(buf * BN + r) * BK + ((c ^ ((r >> 1) & 7)) << 3));
+                wf[ni] = *reinterpret_cast<const half8_t*>(Bs + (size_t)(buf * BN + r) * BKT + ((c ^ swz(r)) << 3));
             }
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = mfma32(wf[ni], xf[mi], acc[mi][ni]);
         }
-        if constexpr (GLDS) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            if (kt + 1 < kt_end) store_tile(buf ^ 1);
+    };
+
+    if constexpr (NST == 2) {
+        issue_tile(kt_begin, 0);
+        wait_vmcnt<0>();
+        __syncthreads();
+        for (int it = 0; it < nkt; ++it) {
+            const int buf = it & 1;
+            if (it + 1 < nkt) issue_tile(kt_begin + it + 1, buf ^ 1);
+            compute_tile(buf);
+            wait_vmcnt<0>();
+            __syncthreads();
+        }
+    } else {
+        // 3-stage ring.  Invariant at the top of iteration `it`: tiles it and it+1 have been requested.
+        // The counted wait leaves the newest tile's loads (my_loads of them, per wave) in flight; loads
+        // retire in issue order, so tile `it` has landed for this wave, and after the barrier for all waves.
+        // The buffer refilled right after the barrier, (it+2) % 3, was last read in iteration it-1, which
+        // every wave has finished before arriving at this barrier.
+        issue_tile(kt_begin, 0);
+        if (nkt > 1) issue_tile(kt_begin + 1, 1);
+        int buf = 0;
+        for (int it = 0; it < nkt; ++it) {
+            if (it + 1 < nkt) {
+                switch (my_loads) {
+                    case 2: wait_vmcnt<2>(); break;
+                    case 3: wait_vmcnt<3>(); break;
+                    case 4: wait_vmcnt<4>(); break;
+                    case 5: wait_vmcnt<5>(); break;
+                    case 6: wait_vmcnt<6>(); break;
+                    default: wait_vmcnt<0>(); break;
+                }
+            } else {
+                wait_vmcnt<0>();
+            }
+            __builtin_amdgcn_s_barrier();
+            int nbuf = buf + 2;
+            if (nbuf >= 3) nbuf -= 3;
+            if (it + 2 < nkt) issue_tile(kt_begin + it + 2, nbuf);
+            compute_tile(buf);
+            buf = (buf == 2) ? 0 : buf + 1;
         }
         __syncthreads();
     }
@@ -463,7 +461,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(gl_gemm_args p, int 
 // How many K slices: only when the tile grid underfills the chip and K is long enough to amortise
 // the fp32 partial round trip.
 inline int choose_splitk(const gl_gemm_args& g, int tiles) {
-    const int nk = g.K / BK;
+    const int nk = g.K / 64;
     if (!g.workspace || g.epi == GL_EPI_GEGLU || g.out_mode != GL_OUT_F16_ROWMAJOR) return 1;
     if (tiles >= 200 || nk < 16) return 1;
     int s = (480 + tiles - 1) / tiles;
@@ -473,19 +471,16 @@ inline int choose_splitk(const gl_gemm_args& g, int tiles) {
     return s < 2 ? 1 : s;
 }
 
-template <int BM, int BN>
-constexpr int lds_bytes() { return 2 * (BM + BN) * BK * (int)sizeof(half_t); }
-
-template <int BM, int BN, int WM, int WN, bool CONV, bool GLDS>
+template <int BM, int BN, int WM, int WN, bool CONV, int BKT, int NST>
 int launch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     const int mt = gl_cdiv(g.M, BM), nt = gl_cdiv(g.N, BN);
-    const int nk = g.K / BK;
+    const int nk = g.K / BKT;
     const int splitk = choose_splitk(g, mt * nt);
-    const int kper = gl_cdiv(nk, splitk);
+    int kper = gl_cdiv(nk, splitk);
     const int zs = gl_cdiv(nk, kper);          // slices that actually have work
     dim3 grid(mt, nt, zs);
-    constexpr int lds = lds_bytes<BM, BN>();
-    gemm_kernel<BM, BN, WM, WN, CONV, GLDS><<<grid, dim3(256), lds, st>>>(g, cg, zs, kper);
+    constexpr int lds = lds_bytes<BM, BN, BKT, NST>();
+    gemm_kernel<BM, BN, WM, WN, CONV, BKT, NST><<<grid, dim3(256), lds, st>>>(g, cg, zs, kper);
     GL_CHECK_LAUNCH();
     if (zs > 1) {
         const size_t total = (size_t)g.M * (g.N / 4);
@@ -497,19 +492,10 @@ int launch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     return 0;
 }
 
-template <bool CONV>
-int dispatch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
-    if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K % BK) != 0 || (g.N % 4) != 0) return GL_ERR_BAD_ARG;
-    if (g.out_mode == GL_OUT_F16_ROWMAJOR && ((g.N % 8) != 0 || (g.ldc % 8) != 0)) return GL_ERR_BAD_ARG;
-    if (g.res != nullptr && (g.ldres % 8) != 0) return GL_ERR_BAD_ARG;
-    if (g.rowbias != nullptr && (g.ld_rowbias % 8) != 0) return GL_ERR_BAD_ARG;
-    if (g.epi == GL_EPI_GEGLU && (g.N % 64) != 0) return GL_ERR_BAD_ARG;
-    if (g.a2 != nullptr && (g.ksplit % BK) != 0) return GL_ERR_BAD_ARG;
-    if ((g.epi == GL_EPI_RES || g.epi == GL_EPI_GATE_RES) && g.res == nullptr) return GL_ERR_BAD_ARG;
-    if (g.epi == GL_EPI_GATE_RES && g.gate == nullptr) return GL_ERR_BAD_ARG;
-    if (g.epi == GL_EPI_ROWBIAS && (g.rowbias == nullptr || g.rows_per_sample <= 0)) return GL_ERR_BAD_ARG;
+template <bool CONV, int BKT, int NST>
+int dispatch_shape(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     // tile shape: 128x160 (4 waves x 32x160) when it divides N exactly -- N = 320/640/960/... are the
-    // channel widths of this UNet and 128-wide tiles would waste up to 17 % of the MFMA work there;
+    // channel widths of this UNet and 128-wide tiles would waste up to 17 % of the MFMA work there
     // (convs, whose K is long, prefer it even when 128 also divides N: measured 442 vs 408 and 607 vs 536 TF/s
     // at the 32x32 and 16x16 levels); otherwise 128x128; 256x64 only for narrow outputs.
     const bool geglu = (g.epi == GL_EPI_GEGLU);
@@ -517,14 +503,24 @@ int dispatch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     if (g.N < 256 && (g.N % 128) != 0) shape = 2;
     else if (!geglu && (g.N % 160) == 0 && ((g.N % 128) != 0 || CONV || g_opt_tile == 2)) shape = 1;
     if (g_opt_tile == 1 && g.N >= 256) shape = 0;
-    if (g_opt_glds) {
-        if (shape == 1) return launch<128, 160, 4, 1, CONV, true>(g, cg, st);
-        if (shape == 0) return launch<128, 128, 2, 2, CONV, true>(g, cg, st);
-        return launch<256, 64, 4, 1, CONV, true>(g, cg, st);
-    }
-    if (shape == 1) return launch<128, 160, 4, 1, CONV, false>(g, cg, st);
-    if (shape == 0) return launch<128, 128, 2, 2, CONV, false>(g, cg, st);
-    return launch<256, 64, 4, 1, CONV, false>(g, cg, st);
+    if (shape == 1) return launch<128, 160, 4, 1, CONV, BKT, NST>(g, cg, st);
+    if (shape == 0) return launch<128, 128, 2, 2, CONV, BKT, NST>(g, cg, st);
+    return launch<256, 64, 4, 1, CONV, BKT, NST>(g, cg, st);
+}
+
+template <bool CONV>
+int dispatch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
+    if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K % 64) != 0 || (g.N % 4) != 0) return GL_ERR_BAD_ARG;
+    if (g.out_mode == GL_OUT_F16_ROWMAJOR && ((g.N % 8) != 0 || (g.ldc % 8) != 0)) return GL_ERR_BAD_ARG;
+    if (g.res != nullptr && (g.ldres % 8) != 0) return GL_ERR_BAD_ARG;
+    if (g.rowbias != nullptr && (g.ld_rowbias % 8) != 0) return GL_ERR_BAD_ARG;
+    if (g.epi == GL_EPI_GEGLU && (g.N % 64) != 0) return GL_ERR_BAD_ARG;
+    if (g.a2 != nullptr && (g.ksplit % 64) != 0) return GL_ERR_BAD_ARG;
+    if ((g.epi == GL_EPI_RES || g.epi == GL_EPI_GATE_RES) && g.res == nullptr) return GL_ERR_BAD_ARG;
+    if (g.epi == GL_EPI_GATE_RES && g.gate == nullptr) return GL_ERR_BAD_ARG;
+    if (g.epi == GL_EPI_ROWBIAS && (g.rowbias == nullptr || g.rows_per_sample <= 0)) return GL_ERR_BAD_ARG;
+    if (g_opt_pipe) return dispatch_shape<CONV, 32, 3>(g, cg, st);
+    return dispatch_shape<CONV, 64, 2>(g, cg, st);
 }
 
 }  // namespace
@@ -537,7 +533,7 @@ extern "C" int gl_gemm(const gl_gemm_args* a, void* stream) {
 
 extern "C" int gl_conv3x3(const gl_conv_args* a, void* stream) {
     if (!a || !a->in || !a->g.w || !a->g.out) return GL_ERR_BAD_ARG;
-    if ((a->Cin % BK) != 0) return GL_ERR_BAD_ARG;
+    if ((a->Cin % 64) != 0) return GL_ERR_BAD_ARG;
     if (a->stride != 1 && a->stride != 2) return GL_ERR_BAD_ARG;
     if (a->upsample2x && (a->stride != 1 || a->Hout != 2 * a->Hin || a->Wout != 2 * a->Win)) return GL_ERR_BAD_ARG;
     gl_gemm_args g = a->g;
@@ -550,31 +546,30 @@ extern "C" int gl_conv3x3(const gl_conv_args* a, void* stream) {
     return dispatch<true>(g, cg, (hipStream_t)stream);
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BKT, int NST>
 int set_lds_attr() {
     hipError_t e;
-    const int lds = lds_bytes<BM, BN>();
-    e = hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WM, WN, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const int lds = lds_bytes<BM, BN, BKT, NST>();
+    e = hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WM, WN, false, BKT, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WM, WN, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WM, WN, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WM, WN, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    e = hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WM, WN, true, BKT, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
     return 0;
 }
 
 extern "C" int gl_init_gemm(void) {
-    int e = set_lds_attr<128, 128, 2, 2>();
-    if (e) return e;
-    e = set_lds_attr<128, 160, 4, 1>();
-    if (e) return e;
-    return set_lds_attr<256, 64, 4, 1>();
+    int e;
+    if ((e = set_lds_attr<128, 128, 2, 2, 32, 3>())) return e;
+    if ((e = set_lds_attr<128, 160, 4, 1, 32, 3>())) return e;
+    if ((e = set_lds_attr<256, 64, 4, 1, 32, 3>())) return e;
+    if ((e = set_lds_attr<128, 128, 2, 2, 64, 2>())) return e;
+    if ((e = set_lds_attr<128, 160, 4, 1, 64, 2>())) return e;
+    if ((e = set_lds_attr<256, 64, 4, 1, 64, 2>())) return e;
+    return 0;
 }
 
 extern "C" int gl_set_option_gemm(int key, int value) {
-    if (key == 1) { g_opt_glds = value ? 1 : 0; return 0; }
+    if (key == 1) { g_opt_pipe = value ? 1 : 0; return 0; }
     if (key == 2) { g_opt_tile = value; return 0; }
     return GL_ERR_BAD_ARG;
 }

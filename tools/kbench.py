@@ -102,8 +102,8 @@ def collect():
 def main():
     which = set(sys.argv[1:]) or {"gemm", "conv", "attn", "norm"}
     init_device()
-    if "KB_GLDS" in os.environ:
-        ops.set_option(1, int(os.environ["KB_GLDS"]))
+    if "KB_PIPE" in os.environ:
+        ops.set_option(1, int(os.environ["KB_PIPE"]))
     if "KB_QT2" in os.environ:
         ops.set_option(3, int(os.environ["KB_QT2"]))
     if "KB_TILE" in os.environ:
