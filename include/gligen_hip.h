@@ -10,7 +10,7 @@
  *
  * Activation layout is token-major ("NHWC"): a feature map is [B, H*W, C] fp16 with C contiguous, so
  * 1x1 convs and Linear layers are plain GEMMs and the 3x3 conv is an implicit GEMM.  Weights are fp16
- * [N, K] row-major (torch Linear layout); 3x3 conv weights are repacked to [Cout, 3, 3, Cin].
+ * [N, K] row-major (torch Linear layout); 3x3 conv weights are repacked to [Cout, Cin/64, 3, 3, 64].
  * Accumulation and all normalisation/softmax statistics are fp32.
  */
 #ifndef GLIGEN_HIP_H
@@ -74,7 +74,7 @@ typedef struct gl_gemm_args {
 
 /*
  * gl_conv3x3: 3x3, pad 1 convolution as implicit GEMM over NHWC fp16 input [B, Hin, Win, Cin]
- * (Cin % 64 == 0; weights [Cout, 3, 3, Cin]).  M = B*Hout*Wout, N = Cout, K = 9*Cin.
+ * (Cin % 64 == 0; weights [Cout, Cin/64, 3, 3, 64], i.e. K = (channel block, tap, channel)).  M = B*Hout*Wout, N = Cout, K = 9*Cin.
  *   stride 1            : ResBlock convs openaimodel.py:158,184; conv_in :299; out conv :388
  *   stride 2            : Downsample.op openaimodel.py:105-107,:114
  *   upsample2x != 0     : F.interpolate(nearest, x2) + conv, openaimodel.py:82-84 (input is Hout/2 x Wout/2)

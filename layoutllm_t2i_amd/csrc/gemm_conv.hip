@@ -92,9 +92,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(gl_gemm_args p, ConvGeom cg, 
     const int wave = tid >> 6;
     const int wm = wave / WAVES_N;
     const int wn = wave % WAVES_N;
-    const int m0 = blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
     const int M = p.M, N = p.N, K = p.K;
+    // Tile order: N-tiles fastest (tiles sharing an A panel / the same input pixels are co-scheduled), and
+    // an XCD-aware bijective remap of the hardware block id (block b runs on XCD b % 8, each XCD has its own
+    // 4 MiB L2): XCD x gets one CONTIGUOUS run of logical tiles, so an A panel is fetched into one L2 instead
+    // of eight and neighbouring conv tiles share their halo rows there.  Speed only, never correctness.
+    const int nt = (N + BN - 1) / BN;
+    int tile;
+    {
+        const int nwg = gridDim.x;
+        const int bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7;
+        const int xcd = bid & 7, local = bid >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
+    const int tm = tile / nt;
+    const int m0 = tm * BM;
+    const int n0 = (tile - tm * nt) * BN;
     const int kt_begin = blockIdx.z * kt_per_split;
     const int kt_end = min(K / BKT, kt_begin + kt_per_split);
     const int nkt = kt_end - kt_begin;
@@ -108,23 +122,58 @@ __global__ __launch_bounds__(256) void gemm_kernel(gl_gemm_args p, ConvGeom cg, 
     const half_t* __restrict__ Wg = reinterpret_cast<const half_t*>(p.w);
     const half_t* zsrc = reinterpret_cast<const half_t*>(g_zero16);
 
-    // per-thread staging rows of the A operand
-    int cb[APASS], coy[APASS], cox[APASS];   // conv: sample, out-y, out-x (cb < 0: row out of range)
-    if constexpr (CONV) {
+    // ---- per-thread staging state, computed ONCE: every K-tile then costs one pointer bump (plain) or one
+    // uniform tap offset + select (conv) per 16-byte LDS-DMA instead of rebuilding 64-bit addresses.
+    // Masked rows point at the zero page with a zero increment.
+    const half_t* aptr[APASS];       // plain: &A[m][k0 + chunk]   conv: &in[b][oy*stride][ox*stride][chunk]
+    int ainc[APASS];                 // plain: halfs to advance per K-tile (0 for masked rows)
+    unsigned cmask[APASS];           // conv: bit t set <=> filter tap t reads an in-bounds pixel
+    int cb[APASS], coy[APASS], cox[APASS];
+    const int k_first = kt_begin * BKT;
 #pragma unroll
-        for (int i = 0; i < APASS; ++i) {
-            const int m = m0 + srow + RPP * i;
-            if (m < M && srow + RPP * i < BM) {
+    for (int i = 0; i < APASS; ++i) {
+        const int r = srow + RPP * i;
+        const int gc = (skc ^ swz(r)) << 3;
+        const int m = m0 + r;
+        const bool rowok = (r < BM) && (m < M);
+        aptr[i] = zsrc; ainc[i] = 0; cmask[i] = 0u; cb[i] = -1; coy[i] = 0; cox[i] = 0;
+        if constexpr (CONV) {
+            if (rowok) {
                 const int hw = cg.Hout * cg.Wout;
                 const int b = m / hw;
-                const int r = m - b * hw;
-                cb[i] = b;
-                coy[i] = r / cg.Wout;
-                cox[i] = r - coy[i] * cg.Wout;
-            } else {
-                cb[i] = -1; coy[i] = 0; cox[i] = 0;
+                const int rr = m - b * hw;
+                const int oy = rr / cg.Wout;
+                const int ox = rr - oy * cg.Wout;
+                cb[i] = b; coy[i] = oy; cox[i] = ox;
+                if (!cg.ups) {
+                    unsigned mk = 0u;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const int iy = oy * cg.stride + t / 3 - 1, ix = ox * cg.stride + t % 3 - 1;
+                        if (iy >= 0 && iy < cg.Hin && ix >= 0 && ix < cg.Win) mk |= 1u << t;
+                    }
+                    cmask[i] = mk;
+                    aptr[i] = cg.in + ((size_t)(b * cg.Hin + oy * cg.stride) * cg.Win + ox * cg.stride) * cg.Cin + gc;
+                }
+            }
+        } else {
+            if (rowok) {
+                if (A2g != nullptr && k_first >= p.ksplit) aptr[i] = A2g + (size_t)m * p.lda2 + (k_first - p.ksplit) + gc;
+                else aptr[i] = Ag + (size_t)m * p.lda + k_first + gc;
+                ainc[i] = BKT;
             }
         }
+    }
+    const half_t* bptr[BPASS];
+    int binc[BPASS];
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) {
+        const int r = srow + RPP * i;
+        const int gc = (skc ^ swz(r)) << 3;
+        const int n = n0 + r;
+        const bool ok = (r < BN) && (n < N);
+        bptr[i] = ok ? (Wg + (size_t)n * K + k_first + gc) : zsrc;
+        binc[i] = ok ? BKT : 0;
     }
 
     // number of LDS-DMA instructions THIS wave issues per tile (passes whose rows exist for this wave)
@@ -136,49 +185,60 @@ __global__ __launch_bounds__(256) void gemm_kernel(gl_gemm_args p, ConvGeom cg, 
 
     auto issue_tile = [&](int kt, int buf) {
         const int k0 = kt * BKT;
-        int ky = 0, kx = 0, ci0 = 0;
         if constexpr (CONV) {
-            const int tap = k0 / cg.Cin;
-            ci0 = k0 - tap * cg.Cin;
-            ky = tap / 3;
-            kx = tap - ky * 3;
-        }
-        const bool second = (!CONV) && (A2g != nullptr) && (k0 >= p.ksplit);
+            // K is ordered (64-channel block, tap, channel): the 9 taps of one channel block are consecutive
+            // K-tiles, so they re-read the same [pixels + halo] x 64-channel slab while it is L1/L2-hot.
+            const int t64 = k0 >> 6;
+            const int cblk = t64 / 9;
+            const int tap = t64 - cblk * 9;
+            const int ci0 = (cblk << 6) + (k0 & 63);
+            const int ky = tap / 3;
+            const int kx = tap - ky * 3;
+            if (!cg.ups) {
+                const int off = ((ky - 1) * cg.Win + (kx - 1)) * cg.Cin + ci0;    // wave-uniform
 #pragma unroll
-        for (int i = 0; i < APASS; ++i) {
-            if (RPP * i + wave * RPW >= BM) continue;          // wave-uniform: this pass has no rows for this wave
-            const int r = srow + RPP * i;
-            const int gc = (skc ^ swz(r)) << 3;
-            const half_t* src = zsrc;
-            if constexpr (CONV) {
-                if (cb[i] >= 0) {
-                    int iy, ix;
-                    bool ok;
-                    if (cg.ups) {
-                        const int uy = coy[i] + ky - 1, ux = cox[i] + kx - 1;
-                        ok = (uy >= 0) && (uy < cg.Hout) && (ux >= 0) && (ux < cg.Wout);
-                        iy = uy >> 1; ix = ux >> 1;
-                    } else {
-                        iy = coy[i] * cg.stride + ky - 1;
-                        ix = cox[i] * cg.stride + kx - 1;
-                        ok = (iy >= 0) && (iy < cg.Hin) && (ix >= 0) && (ix < cg.Win);
-                    }
-                    if (ok) src = cg.in + ((size_t)(cb[i] * cg.Hin + iy) * cg.Win + ix) * cg.Cin + ci0 + gc;
+                for (int i = 0; i < APASS; ++i) {
+                    if (RPP * i + wave * RPW >= BM) continue;      // wave-uniform: pass has no rows for this wave
+                    const half_t* src = ((cmask[i] >> tap) & 1u) ? (aptr[i] + off) : zsrc;
+                    glds16(src, As + (size_t)(buf * BM + RPP * i + wave * RPW) * BKT);
                 }
             } else {
-                const int m = m0 + r;
-                if (m < M) src = second ? (A2g + (size_t)m * p.lda2 + (k0 - p.ksplit) + gc) : (Ag + (size_t)m * p.lda + k0 + gc);
+#pragma unroll
+                for (int i = 0; i < APASS; ++i) {
+                    if (RPP * i + wave * RPW >= BM) continue;
+                    const int r = srow + RPP * i;
+                    const int gc = (skc ^ swz(r)) << 3;
+                    const half_t* src = zsrc;
+                    if (cb[i] >= 0) {
+                        const int uy = coy[i] + ky - 1, ux = cox[i] + kx - 1;
+                        if ((uy >= 0) && (uy < cg.Hout) && (ux >= 0) && (ux < cg.Wout))
+                            src = cg.in + ((size_t)(cb[i] * cg.Hin + (uy >> 1)) * cg.Win + (ux >> 1)) * cg.Cin + ci0 + gc;
+                    }
+                    glds16(src, As + (size_t)(buf * BM + RPP * i + wave * RPW) * BKT);
+                }
             }
-            glds16(src, As + (size_t)(buf * BM + RPP * i + wave * RPW) * BKT);
+        } else {
+            if (A2g != nullptr && k0 == p.ksplit && k0 != k_first) {
+                // two-source A: crossing into the second matrix (th.cat folded into the GEMM), once per block
+#pragma unroll
+                for (int i = 0; i < APASS; ++i) {
+                    const int r = srow + RPP * i;
+                    const int m = m0 + r;
+                    if ((r < BM) && (m < M)) aptr[i] = A2g + (size_t)m * p.lda2 + ((skc ^ swz(r)) << 3);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < APASS; ++i) {
+                if (RPP * i + wave * RPW >= BM) continue;
+                glds16(aptr[i], As + (size_t)(buf * BM + RPP * i + wave * RPW) * BKT);
+                aptr[i] += ainc[i];
+            }
         }
 #pragma unroll
         for (int i = 0; i < BPASS; ++i) {
             if (RPP * i + wave * RPW >= BN) continue;
-            const int r = srow + RPP * i;
-            const int gc = (skc ^ swz(r)) << 3;
-            const int n = n0 + r;
-            const half_t* src = (n < N) ? (Wg + (size_t)n * K + k0 + gc) : zsrc;
-            glds16(src, Bs + (size_t)(buf * BN + RPP * i + wave * RPW) * BKT);
+            glds16(bptr[i], Bs + (size_t)(buf * BN + RPP * i + wave * RPW) * BKT);
+            bptr[i] += binc[i];
         }
     };
 
@@ -478,7 +538,7 @@ int launch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     const int splitk = choose_splitk(g, mt * nt);
     int kper = gl_cdiv(nk, splitk);
     const int zs = gl_cdiv(nk, kper);          // slices that actually have work
-    dim3 grid(mt, nt, zs);
+    dim3 grid(mt * nt, 1, zs);
     constexpr int lds = lds_bytes<BM, BN, BKT, NST>();
     gemm_kernel<BM, BN, WM, WN, CONV, BKT, NST><<<grid, dim3(256), lds, st>>>(g, cg, zs, kper);
     GL_CHECK_LAUNCH();

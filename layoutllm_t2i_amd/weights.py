@@ -4,7 +4,7 @@ The engine never sees torch modules; it consumes the flat dict this module produ
 layout work only (no arithmetic beyond dtype casts and tanh of the scalar gates):
 
   * Linear / 1x1-conv weights  [N, K]            -> fp16 [N, K]
-  * 3x3 conv weights [Cout, Cin, 3, 3]          -> fp16 [Cout, 9*Cin] tap-major/channel-minor (NHWC implicit GEMM);
+  * 3x3 conv weights [Cout, Cin, 3, 3]          -> fp16 [Cout, 9*Cin], K = (64-channel block, tap, channel) (NHWC implicit GEMM);
                                                    the 4-channel first conv is zero-padded to Cin = 64
   * GEGLU proj [8C, C] (x rows | gate rows)      -> rows interleaved in blocks of 32 (x32 | gate32 | x32 | ...)
                                                    so x_j and gate_j land in adjacent MFMA tiles (bias likewise)
@@ -41,11 +41,15 @@ def _h(x: torch.Tensor) -> torch.Tensor:
 
 
 def pack_conv3x3(w: torch.Tensor, cin_pad: int | None = None) -> torch.Tensor:
+    """[Cout, Cin, 3, 3] -> fp16 [Cout, 9*Cin] with K ordered (64-channel block, tap, channel-in-block): the
+    implicit-GEMM kernel then visits the 9 taps of one channel block back to back (cache-hot halo reuse)."""
     cout, cin = w.shape[0], w.shape[1]
-    wp = w.permute(0, 2, 3, 1)                       # [Cout, 3, 3, Cin]
     if cin_pad is not None and cin_pad > cin:
-        z = torch.zeros(cout, 3, 3, cin_pad - cin, dtype=w.dtype, device=w.device)
-        wp = torch.cat([wp, z], dim=-1)
+        z = torch.zeros(cout, cin_pad - cin, 3, 3, dtype=w.dtype, device=w.device)
+        w = torch.cat([w, z], dim=1)
+        cin = cin_pad
+    assert cin % 64 == 0, "conv input channels must be a multiple of 64 (pad the first conv)"
+    wp = w.reshape(cout, cin // 64, 64, 3, 3).permute(0, 1, 3, 4, 2)    # [Cout, Cin/64, 3, 3, 64]
     return _h(wp.reshape(cout, -1))
 
 

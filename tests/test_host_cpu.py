@@ -90,12 +90,17 @@ def test_geglu_interleave_layout():
 
 
 def test_conv_pack_layout():
-    w = torch.arange(2 * 3 * 9).float().reshape(2, 3, 3, 3)
-    p = pack_conv3x3(w, cin_pad=8).float().reshape(2, 3, 3, 8)
+    w = (torch.arange(2 * 128 * 9) % 1021).float().reshape(2, 128, 3, 3)   # exactly representable in fp16
+    p = pack_conv3x3(w).float().reshape(2, 2, 3, 3, 64)          # [Cout, channel block, ky, kx, channel]
+    for cb in range(2):
+        for ky in range(3):
+            for kx in range(3):
+                assert torch.equal(p[:, cb, ky, kx, :], w[:, cb * 64:(cb + 1) * 64, ky, kx])
+    w4 = torch.arange(2 * 3 * 9).float().reshape(2, 3, 3, 3) + 1
+    p4 = pack_conv3x3(w4, cin_pad=64).float().reshape(2, 1, 3, 3, 64)
     for ky in range(3):
         for kx in range(3):
-            assert torch.equal(p[:, ky, kx, :3], w[:, :, ky, kx])
-            assert float(p[:, ky, kx, 3:].abs().max()) == 0
+            assert torch.equal(p4[:, 0, ky, kx, :3], w4[:, :, ky, kx]) and float(p4[:, 0, ky, kx, 3:].abs().max()) == 0
 
 
 def test_pack_state_dict_cpu_tiny():
