@@ -164,8 +164,14 @@ def main():
     n_fwd = len(fwd_events)
     scale_flops = 1.0 if (side == 64 and not args.tiny) else float("nan")   # F_* are for the 64x64 full model only
     achieved = flops * scale_flops / (gpu_ms * 1e-3) / 1e12 if gpu_ms > 0 else float("nan")
+    # HBM traffic per forward launch: measured in separate rocprofv3 --pmc passes (profiles/r1_traffic.json)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
+    if os.path.exists(tpath) and side == 64 and not args.tiny and B == 4:
+        traffic = round(json.load(open(tpath))["traffic_bytes_per_forward"])
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "traffic_note": "bytes per forward launch from separate --pmc FETCH_SIZE/WRITE_SIZE passes (2*FETCH + WRITE, profiles/r1_traffic.json)",
                 "launch": "UNet forward of the 2B=8 [cond;uncond] batch (one hipGraph replay)",
                 "launches": n_fwd, "avg_launch_ms": round(gpu_ms / max(n_fwd, 1), 3),
                 "flops_per_launch": round(flops / max(n_fwd, 1)), "flop_model": "SURVEY 8d minimal (32 F_full + 70 F_off per image)"}
