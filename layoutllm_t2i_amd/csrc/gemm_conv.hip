@@ -36,6 +36,9 @@ __device__ uint4 g_zero16[4];
 namespace {
 
 int g_opt_pipe = 0;          // 0 = BK 64 / 2-stage (default, faster), 1 = BK 32 / 3-stage counted-vmcnt pipeline
+int g_opt_small = 400;       // use 64x128 tiles when the 128-row grid has fewer tiles than this (0 = never)
+int g_opt_splitk_tiles = 200; // split K only below this many tiles ...
+int g_opt_splitk_nk = 16;    // ... and at least this many 64-wide K tiles
 int g_opt_tile = 0;          // 0 = auto; 1 = force 128x128 (N >= 256); 2 = prefer 128x160 whenever N % 160 == 0
 
 struct ConvGeom {
@@ -523,7 +526,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(gl_gemm_args p, int 
 inline int choose_splitk(const gl_gemm_args& g, int tiles) {
     const int nk = g.K / 64;
     if (!g.workspace || g.epi == GL_EPI_GEGLU || g.out_mode != GL_OUT_F16_ROWMAJOR) return 1;
-    if (tiles >= 200 || nk < 16) return 1;
+    if (tiles >= g_opt_splitk_tiles || nk < g_opt_splitk_nk) return 1;
     int s = (480 + tiles - 1) / tiles;
     if (s > nk / 8) s = nk / 8;
     if (s > 16) s = 16;
@@ -559,10 +562,19 @@ int dispatch_shape(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     // (convs, whose K is long, prefer it even when 128 also divides N: measured 442 vs 408 and 607 vs 536 TF/s
     // at the 32x32 and 16x16 levels); otherwise 128x128; 256x64 only for narrow outputs.
     const bool geglu = (g.epi == GL_EPI_GEGLU);
-    int shape = 0;                                   // 0: 128x128, 1: 128x160, 2: 256x64
+    int shape = 0;                                   // 0: 128x128, 1: 128x160, 2: 256x64, 3: 64x128
     if (g.N < 256 && (g.N % 128) != 0) shape = 2;
     else if (!geglu && (g.N % 160) == 0 && ((g.N % 128) != 0 || CONV || g_opt_tile == 2)) shape = 1;
     if (g_opt_tile == 1 && g.N >= 256) shape = 0;
+    // few tiles (mid / low resolution levels): halve the tile height so the grid covers the 256 CUs at
+    // 2-3 blocks each instead of leaving half of them idle (M=8192,N=640 -> 256 tiles of 128x160 vs 640 of 64x128)
+    // (measured: helps the K <= 1280 projections, 22 -> 18 us; hurts long-K GEMMs and convs, whose
+    //  weight stream then gets re-read by twice as many row tiles)
+    if (g_opt_small && !CONV && g.K <= 1280 && shape != 2 && (g.N % 128) == 0) {
+        const long t128 = (long)gl_cdiv(g.M, 128) * gl_cdiv(g.N, shape == 1 ? 160 : 128);
+        if (t128 < g_opt_small) shape = 3;
+    }
+    if (shape == 3) return launch<64, 128, 2, 2, CONV, BKT, NST>(g, cg, st);
     if (shape == 1) return launch<128, 160, 4, 1, CONV, BKT, NST>(g, cg, st);
     if (shape == 0) return launch<128, 128, 2, 2, CONV, BKT, NST>(g, cg, st);
     return launch<256, 64, 4, 1, CONV, BKT, NST>(g, cg, st);
@@ -619,6 +631,8 @@ int set_lds_attr() {
 
 extern "C" int gl_init_gemm(void) {
     int e;
+    if ((e = set_lds_attr<64, 128, 2, 2, 32, 3>())) return e;
+    if ((e = set_lds_attr<64, 128, 2, 2, 64, 2>())) return e;
     if ((e = set_lds_attr<128, 128, 2, 2, 32, 3>())) return e;
     if ((e = set_lds_attr<128, 160, 4, 1, 32, 3>())) return e;
     if ((e = set_lds_attr<256, 64, 4, 1, 32, 3>())) return e;
@@ -631,5 +645,8 @@ extern "C" int gl_init_gemm(void) {
 extern "C" int gl_set_option_gemm(int key, int value) {
     if (key == 1) { g_opt_pipe = value ? 1 : 0; return 0; }
     if (key == 2) { g_opt_tile = value; return 0; }
+    if (key == 4) { g_opt_small = value; return 0; }
+    if (key == 5) { g_opt_splitk_tiles = value; return 0; }
+    if (key == 6) { g_opt_splitk_nk = value; return 0; }
     return GL_ERR_BAD_ARG;
 }

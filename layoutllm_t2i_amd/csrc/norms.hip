@@ -49,10 +49,28 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict_
 #pragma unroll
             for (int j = 0; j < 8; ++j) { s[j] = 0.0f; ss[j] = 0.0f; }
             const int c = vec * 8;
-            for (int pix = p0 + plane; pix < p1; pix += nplanes) {
-                int cl;
-                const half_t* base = src_ptr(x1, C1, x2, C2, (size_t)b * HW + pix, c, &cl);
-                uint4 raw = ld16(base + cl);
+            int cl;
+            const half_t* base = src_ptr(x1, C1, x2, C2, (size_t)b * HW + p0 + plane, c, &cl) + cl;
+            const size_t step = (size_t)nplanes * (c < C1 ? C1 : C2);
+            int pix = p0 + plane;
+            // 4 independent 16-byte loads in flight per thread
+            for (; pix + 3 * nplanes < p1; pix += 4 * nplanes, base += 4 * step) {
+                uint4 raw[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) raw[u] = ld16(base + u * step);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const half8_t hv = *reinterpret_cast<half8_t*>(&raw[u]);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float f = (float)hv[j];
+                        s[j] += f;
+                        ss[j] += f * f;
+                    }
+                }
+            }
+            for (; pix < p1; pix += nplanes, base += step) {
+                uint4 raw = ld16(base);
                 const half8_t hv = *reinterpret_cast<half8_t*>(&raw);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -94,17 +112,29 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float eps, int silu, half_t* __restrict__ out, int ppb) {
     __shared__ float mean_s[32], rstd_s[32];
+    __shared__ float red_s[8][32], red_q[8][32];
     const int C = C1 + C2;
     const int cpg = C / 32;
     const int nvec = C / 8;
     const int b = blockIdx.y;
-    if (threadIdx.x < 32) {
+    {
+        // fold the <= 64 per-chunk partials: 8 slices x 32 groups in parallel (independent loads), then a
+        // fixed-order sum over the slices -- the serial 64-step version cost ~25 us of dependent L2 latency
+        const int g = threadIdx.x & 31, sl = threadIdx.x >> 5;
         float s = 0.0f, ss = 0.0f;
-        for (int ch = 0; ch < nchunk; ++ch) {
-            const float* pp = partial + (((size_t)b * nchunk + ch) * 32 + threadIdx.x) * 2;
+        for (int ch = sl; ch < nchunk; ch += 8) {
+            const float* pp = partial + (((size_t)b * nchunk + ch) * 32 + g) * 2;
             s += pp[0];
             ss += pp[1];
         }
+        red_s[sl][g] = s;
+        red_q[sl][g] = ss;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float s = 0.0f, ss = 0.0f;
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl) { s += red_s[sl][threadIdx.x]; ss += red_q[sl][threadIdx.x]; }
         const float n = (float)cpg * (float)HW;
         const float mean = s / n;
         float var = ss / n - mean * mean;
@@ -136,7 +166,25 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
         const half_t* sp = src + ((size_t)b * HW + p0 + plane) * cs + cl;
         half_t* dp = out + ((size_t)b * HW + p0 + plane) * C + c;
         const size_t sstep = (size_t)nplanes * cs, dstep = (size_t)nplanes * C;
-        for (int pix = p0 + plane; pix < p1; pix += nplanes, sp += sstep, dp += dstep) {
+        int pix = p0 + plane;
+        for (; pix + 3 * nplanes < p1; pix += 4 * nplanes, sp += 4 * sstep, dp += 4 * dstep) {
+            uint4 raw[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) raw[u] = ld16(sp + u * sstep);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const half8_t hv = *reinterpret_cast<half8_t*>(&raw[u]);
+                half8_t ov;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float v = fmaf((float)hv[j], sc[j], sh[j]);
+                    if (silu) v = silu_f(v);
+                    ov[j] = (half_t)v;
+                }
+                st16(dp + u * dstep, *reinterpret_cast<uint4*>(&ov));
+            }
+        }
+        for (; pix < p1; pix += nplanes, sp += sstep, dp += dstep) {
             uint4 raw = ld16(sp);
             const half8_t hv = *reinterpret_cast<half8_t*>(&raw);
             half8_t ov;
@@ -227,7 +275,7 @@ extern "C" int gl_groupnorm_apply(const void* x1, int32_t C1, const void* x2, in
     // pixels per block: >= 2 pixels per pixel-lane, ~1-2k blocks at the 64x64 level
     const int nvec = C / 8;
     const int nplanes = 256 / (nvec < 256 ? nvec : 256);
-    int ppb = 8 * nplanes;
+    int ppb = 16 * nplanes;
     if (ppb < 16) ppb = 16;
     if (ppb > HW) ppb = HW;
     const int nblk = gl_cdiv(HW, ppb);

@@ -104,6 +104,9 @@ def main():
     init_device()
     if "KB_PIPE" in os.environ:
         ops.set_option(1, int(os.environ["KB_PIPE"]))
+    for k, env in ((4, "KB_SMALL"), (5, "KB_SKT"), (6, "KB_SKNK")):
+        if env in os.environ:
+            ops.set_option(k, int(os.environ[env]))
     if "KB_QT2" in os.environ:
         ops.set_option(3, int(os.environ["KB_QT2"]))
     if "KB_TILE" in os.environ:
