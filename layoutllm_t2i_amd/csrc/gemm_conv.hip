@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(gl_gemm_args p, ConvGeom cg, 
     constexpr int KSTEPS = BKT / 16;
     static_assert(WAVES_M * WAVES_N == 4, "4 waves");
     static_assert(BM % RPW == 0 && BN % RPW == 0, "whole wave instructions");
-    static_assert(BKT == 64 || BKT == 32, "BK");
+    static_assert(BKT == 128 || BKT == 64 || BKT == 32, "BK");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     half_t* As = reinterpret_cast<half_t*>(smem);   // [NST][BM][BKT]
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(gl_gemm_args p, ConvGeom cg, 
 
     const int srow = tid / CPR;      // staging row within a pass
     const int skc = tid % CPR;       // LDS chunk slot within the row
-    auto swz = [](int r) -> int { return BKT == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3); };
+    auto swz = [](int r) -> int { return BKT == 128 ? (r & 15) : (BKT == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3)); };
 
     const half_t* __restrict__ Ag = reinterpret_cast<const half_t*>(p.a);
     const half_t* __restrict__ A2g = reinterpret_cast<const half_t*>(p.a2);
@@ -577,7 +577,7 @@ int dispatch_shape(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     if (shape == 3) return launch<64, 128, 2, 2, CONV, BKT, NST>(g, cg, st);
     if (shape == 1) return launch<128, 160, 4, 1, CONV, BKT, NST>(g, cg, st);
     if (shape == 0) return launch<128, 128, 2, 2, CONV, BKT, NST>(g, cg, st);
-    return launch<256, 64, 4, 1, CONV, BKT, NST>(g, cg, st);
+    if constexpr (BKT == 128) return GL_ERR_UNSUPPORTED; else return launch<256, 64, 4, 1, CONV, BKT, NST>(g, cg, st);
 }
 
 template <bool CONV>
@@ -591,7 +591,10 @@ int dispatch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     if ((g.epi == GL_EPI_RES || g.epi == GL_EPI_GATE_RES) && g.res == nullptr) return GL_ERR_BAD_ARG;
     if (g.epi == GL_EPI_GATE_RES && g.gate == nullptr) return GL_ERR_BAD_ARG;
     if (g.epi == GL_EPI_ROWBIAS && (g.rowbias == nullptr || g.rows_per_sample <= 0)) return GL_ERR_BAD_ARG;
-    if (g_opt_pipe) return dispatch_shape<CONV, 32, 3>(g, cg, st);
+    if (g_opt_pipe == 1) return dispatch_shape<CONV, 32, 3>(g, cg, st);
+    if constexpr (!CONV) {
+        if (g_opt_pipe == 2 && (g.K % 128) == 0 && g.N >= 256) return dispatch_shape<false, 128, 2>(g, cg, st);
+    }
     return dispatch_shape<CONV, 64, 2>(g, cg, st);
 }
 
@@ -629,8 +632,18 @@ int set_lds_attr() {
     return 0;
 }
 
+template <int BM, int BN, int WM, int WN, int BKT, int NST>
+int set_lds_attr_plain() {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WM, WN, false, BKT, NST>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<BM, BN, BKT, NST>());
+    return e == hipSuccess ? 0 : (int)e;
+}
+
 extern "C" int gl_init_gemm(void) {
     int e;
+    if ((e = set_lds_attr_plain<64, 128, 2, 2, 128, 2>())) return e;
+    if ((e = set_lds_attr_plain<128, 128, 2, 2, 128, 2>())) return e;
+    if ((e = set_lds_attr_plain<128, 160, 4, 1, 128, 2>())) return e;
     if ((e = set_lds_attr<64, 128, 2, 2, 32, 3>())) return e;
     if ((e = set_lds_attr<64, 128, 2, 2, 64, 2>())) return e;
     if ((e = set_lds_attr<128, 128, 2, 2, 32, 3>())) return e;
@@ -643,7 +656,7 @@ extern "C" int gl_init_gemm(void) {
 }
 
 extern "C" int gl_set_option_gemm(int key, int value) {
-    if (key == 1) { g_opt_pipe = value ? 1 : 0; return 0; }
+    if (key == 1) { g_opt_pipe = value; return 0; }
     if (key == 2) { g_opt_tile = value; return 0; }
     if (key == 4) { g_opt_small = value; return 0; }
     if (key == 5) { g_opt_splitk_tiles = value; return 0; }
