@@ -37,7 +37,8 @@ namespace {
 
 int g_opt_pipe = 0;          // 0 = BK 64 / 2-stage (default, faster), 1 = BK 32 / 3-stage counted-vmcnt pipeline
 int g_opt_small = 400;       // use 64x128 tiles when the 128-row grid has fewer tiles than this (0 = never)
-int g_opt_splitk_tiles = 200; // split K only below this many tiles ...
+int g_opt_splitk_tiles = 300; // split K only below this many tiles (plain GEMM) ...
+int g_opt_splitk_tiles_conv = 450; // ... (conv)
 int g_opt_splitk_nk = 16;    // ... and at least this many 64-wide K tiles
 int g_opt_tile = 0;          // 0 = auto; 1 = force 128x128 (N >= 256); 2 = prefer 128x160 whenever N % 160 == 0
 
@@ -523,10 +524,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(gl_gemm_args p, int 
 
 // How many K slices: only when the tile grid underfills the chip and K is long enough to amortise
 // the fp32 partial round trip.
-inline int choose_splitk(const gl_gemm_args& g, int tiles) {
+inline int choose_splitk(const gl_gemm_args& g, int tiles, bool conv) {
     const int nk = g.K / 64;
     if (!g.workspace || g.epi == GL_EPI_GEGLU || g.out_mode != GL_OUT_F16_ROWMAJOR) return 1;
-    if (tiles >= g_opt_splitk_tiles || nk < g_opt_splitk_nk) return 1;
+    // convs (long K, weights streamed once per row tile) profit up to ~1.7 tiles per CU: the 32x32-level
+    // convs launch exactly 256 tiles and went 604 -> 694 TF/s with 2 K-slices; plain GEMMs only below ~300
+    if (tiles >= (conv ? g_opt_splitk_tiles_conv : g_opt_splitk_tiles) || nk < g_opt_splitk_nk) return 1;
     int s = (480 + tiles - 1) / tiles;
     if (s > nk / 8) s = nk / 8;
     if (s > 16) s = 16;
@@ -538,7 +541,7 @@ template <int BM, int BN, int WM, int WN, bool CONV, int BKT, int NST>
 int launch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     const int mt = gl_cdiv(g.M, BM), nt = gl_cdiv(g.N, BN);
     const int nk = g.K / BKT;
-    const int splitk = choose_splitk(g, mt * nt);
+    const int splitk = choose_splitk(g, mt * nt, CONV);
     int kper = gl_cdiv(nk, splitk);
     const int zs = gl_cdiv(nk, kper);          // slices that actually have work
     dim3 grid(mt * nt, 1, zs);
@@ -659,7 +662,7 @@ extern "C" int gl_set_option_gemm(int key, int value) {
     if (key == 1) { g_opt_pipe = value; return 0; }
     if (key == 2) { g_opt_tile = value; return 0; }
     if (key == 4) { g_opt_small = value; return 0; }
-    if (key == 5) { g_opt_splitk_tiles = value; return 0; }
+    if (key == 5) { g_opt_splitk_tiles = value; g_opt_splitk_tiles_conv = value; return 0; }
     if (key == 6) { g_opt_splitk_nk = value; return 0; }
     return GL_ERR_BAD_ARG;
 }

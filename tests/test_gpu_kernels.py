@@ -246,6 +246,16 @@ def test_attention(d, H, Nq, Nk, B):
     check(out, _attn_ref(q, k, v, H), f"attn_d{d}_q{Nq}_k{Nk}", rtol=2e-3, atol=2e-4)
 
 
+@pytest.mark.parametrize("d,H,Nq,Nk,B", [(40, 8, 256, 286, 1), (80, 8, 300, 1054, 1), (16, 4, 130, 200, 2), (40, 8, 4096, 4126, 1)])
+def test_attention_pipelined_variant(d, H, Nq, Nk, B):
+    """the software-pipelined kernel (gl_set_option(3, 2)) must agree with the same reference"""
+    ops.set_option(3, 2)
+    try:
+        test_attention(d, H, Nq, Nk, B)
+    finally:
+        ops.set_option(3, 0)
+
+
 def test_attention_strided_qkv_and_spike():
     """fused-QKV addressing (row stride 3C, batch stride (N+30)*3C, Nq < rows) and an outlier key that
     forces a late running-max jump in the online softmax."""
