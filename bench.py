@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--boxes", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tiny", action="store_true", help="debug: tiny UNet (not a valid benchmark)")
+    ap.add_argument("--no-vae", action="store_true", help="stop at the final latent (exclude the VAE decode stage from the step)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to smoke-test the path on one GPU)")
     return ap.parse_args()
 
@@ -80,7 +81,9 @@ def main():
     from layoutllm_t2i_amd.engine import UNetEngine
     from layoutllm_t2i_amd.interface import denoise
     from layoutllm_t2i_amd.model import GroundingNetInput, LatentDiffusion, UNetModel
-    from layoutllm_t2i_amd.weights import pack_state_dict, random_state_dict
+    from layoutllm_t2i_amd.arch import VAEConfig
+    from layoutllm_t2i_amd.vae import VAEDecoder
+    from layoutllm_t2i_amd.weights import pack_state_dict, random_state_dict, random_vae_state_dict
 
     cfg = TINY if args.tiny else UNetConfig()
     B, side = args.batch, args.latent
@@ -115,7 +118,10 @@ def main():
     model.fuser_scale, model.training, model._cond_key = 1.0, False, None
     model.engine = UNetEngine(packed)
     diffusion = LatentDiffusion(device=dev)
-    all_models = (model, None, None, diffusion, {})
+    vae = None
+    if not args.no_vae and not args.tiny:
+        vae = VAEDecoder(random_vae_state_dict(VAEConfig(), dev, seed=1 + rank), VAEConfig(), dev)   # 0.1 GB: built per rank
+    all_models = (model, vae, None, diffusion, {})
     setup_s = time.time() - t0
 
     # ---- synthetic inputs, resident on the device (seed 1234 + rank)
@@ -137,10 +143,20 @@ def main():
         return out
     eng.forward = timed_forward
 
+    vae_events = []
+
     def one_step():
         model.first_conv_type = "GLIGEN"
-        return denoise(all_models, inp["context"], inp["uc"], inp["relations"], batch, inp["x"], [0.3, 0.0, 0.7], 7.5,
-                       steps=args.plms_steps)
+        lat = denoise(all_models, inp["context"], inp["uc"], inp["relations"], batch, inp["x"], [0.3, 0.0, 0.7], 7.5,
+                      steps=args.plms_steps)
+        if vae is None:
+            return lat
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        img = vae.decode(lat)                      # fp32 [B, 3, 512, 512], what interface.py:541 hands to the PIL loop
+        e1.record()
+        vae_events.append((e0, e1))
+        return img
 
     def sync():
         torch.cuda.synchronize()
@@ -151,6 +167,7 @@ def main():
     for _ in range(args.warmup):
         out = one_step()
     fwd_events.clear()
+    vae_events.clear()
     sync()
     t1 = time.time()
     for _ in range(args.steps):
@@ -195,6 +212,8 @@ def main():
                    "images_per_gpu_per_step": B, "unet_forwards_per_image": 2 * (args.plms_steps + 1), "latent": [B, 4, side, side],
                    "parallelism": f"replicas x{world}, one weight broadcast, no per-step collectives"},
         "unet_step_ms": round(gpu_ms / max(n_fwd, 1), 3),
+        "vae_decode_ms_per_batch": (round(sum(a.elapsed_time(b) for a, b in vae_events) / max(len(vae_events), 1), 2) if vae_events else None),
+        "step_includes": "PLMS denoise (51 x 2B UNet forward)" + (" + VAE decode to fp32 images" if vae is not None else ""),
         "images_per_sec_per_gpu": round(value / world, 4),
         "roofline": roofline,
         "setup_s": round(setup_s, 1),

@@ -180,6 +180,17 @@ int gl_plms_update(const float* x, const float* e, const float* e1, const float*
 int gl_pack_latent(const float* x, int32_t B, int32_t C, int32_t hw, int32_t Cpad, int32_t reps, void* out,
                    void* stream);
 
+/*
+ * VAE decode stage (AutoencoderKL.decode autoencoder.py:40-44, Decoder.forward model.py:535-568).
+ * It reuses gl_conv3x3 / gl_gemm / gl_groupnorm_* ; only two extra kernels exist:
+ *   gl_latent_affine_pack : z fp32 NCHW -> fp16 NHWC (channel-padded) of post_quant_conv(z / scale_factor)
+ *   gl_softmax_rows       : in-place row softmax(scale * x) over fp16 [rows, n]: the d = 512 single-head
+ *                           AttnBlock (model.py:150-202) is two GEMMs around it.
+ */
+int gl_latent_affine_pack(const float* z, const float* w, const float* bias, float pre, int32_t B, int32_t C,
+                          int32_t hw, int32_t Cpad, void* out, void* stream);
+int gl_softmax_rows(void* x, int32_t rows, int32_t n, int32_t ld, float scale, void* stream);
+
 int gl_gemm(const gl_gemm_args* a, void* stream);
 int gl_conv3x3(const gl_conv_args* a, void* stream);
 int gl_attention(const gl_attn_args* a, void* stream);

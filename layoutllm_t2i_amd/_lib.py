@@ -81,6 +81,8 @@ PROTOTYPES = {
     "gl_cfg_combine": (i32, [fp, f32, i64, fp, vp]),
     "gl_plms_update": (i32, [fp, fp, fp, fp, fp, f32, f32, f32, f32, f32, f32, f32, f32, f32, i64, fp, vp]),
     "gl_pack_latent": (i32, [fp, i32, i32, i32, i32, i32, vp, vp]),
+    "gl_latent_affine_pack": (i32, [fp, fp, fp, f32, i32, i32, i32, i32, vp, vp]),
+    "gl_softmax_rows": (i32, [vp, i32, i32, i32, f32, vp]),
     "gl_abi_version": (i32, []),
     "gl_sizeof_gemm_args": (i32, []),
     "gl_sizeof_conv_args": (i32, []),

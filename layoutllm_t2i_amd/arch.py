@@ -271,3 +271,52 @@ def count_params(cfg: UNetConfig) -> int:
             k *= s
         n += k
     return n
+
+
+# --------------------------------------------------------------------------- VAE decoder
+@dataclass(frozen=True)
+class VAEConfig:
+    """AutoencoderKL decoder hyper-parameters; defaults are GLIGEN/configs/coco2014.yaml:33-53."""
+    ch: int = 128
+    ch_mult: Tuple[int, ...] = (1, 2, 4, 4)
+    num_res_blocks: int = 2
+    z_channels: int = 4
+    out_ch: int = 3
+    embed_dim: int = 4
+    scale_factor: float = 0.18215
+
+
+VAE_TINY = VAEConfig(ch=64, ch_mult=(1, 2), num_res_blocks=1)
+
+
+def vae_decoder_param_shapes(cfg: VAEConfig) -> Dict[str, Tuple[int, ...]]:
+    """state_dict name -> shape of everything AutoencoderKL.decode touches (autoencoder.py:40-44,
+    model.py:462-568), in the reference's naming (post_quant_conv.*, decoder.*)."""
+    out: Dict[str, Tuple[int, ...]] = {}
+    out.update(conv_params("post_quant_conv", cfg.embed_dim, cfg.z_channels, 1))
+    nres = len(cfg.ch_mult)
+    block_in = cfg.ch * cfg.ch_mult[nres - 1]
+    out.update(conv_params("decoder.conv_in", cfg.z_channels, block_in))
+
+    def resnet(p, cin, cout):
+        out.update(norm_params(p + ".norm1", cin))
+        out.update(conv_params(p + ".conv1", cin, cout))
+        out.update(norm_params(p + ".norm2", cout))
+        out.update(conv_params(p + ".conv2", cout, cout))
+        if cin != cout:
+            out.update(conv_params(p + ".nin_shortcut", cin, cout, 1))
+    resnet("decoder.mid.block_1", block_in, block_in)
+    out.update(norm_params("decoder.mid.attn_1.norm", block_in))
+    for n in ("q", "k", "v", "proj_out"):
+        out.update(conv_params(f"decoder.mid.attn_1.{n}", block_in, block_in, 1))
+    resnet("decoder.mid.block_2", block_in, block_in)
+    for lvl in reversed(range(nres)):
+        block_out = cfg.ch * cfg.ch_mult[lvl]
+        for i in range(cfg.num_res_blocks + 1):
+            resnet(f"decoder.up.{lvl}.block.{i}", block_in, block_out)
+            block_in = block_out
+        if lvl != 0:
+            out.update(conv_params(f"decoder.up.{lvl}.upsample.conv", block_in, block_in))
+    out.update(norm_params("decoder.norm_out", block_in))
+    out.update(conv_params("decoder.conv_out", block_in, cfg.out_ch))
+    return out

@@ -585,7 +585,7 @@ int dispatch_shape(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
 
 template <bool CONV>
 int dispatch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
-    if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K % 64) != 0 || (g.N % 4) != 0) return GL_ERR_BAD_ARG;
+    if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K % 64) != 0) return GL_ERR_BAD_ARG;
     if (g.out_mode == GL_OUT_F16_ROWMAJOR && ((g.N % 8) != 0 || (g.ldc % 8) != 0)) return GL_ERR_BAD_ARG;
     if (g.res != nullptr && (g.ldres % 8) != 0) return GL_ERR_BAD_ARG;
     if (g.rowbias != nullptr && (g.ld_rowbias % 8) != 0) return GL_ERR_BAD_ARG;

@@ -99,6 +99,66 @@ __global__ void pack_latent_kernel(const float* __restrict__ x, int B, int C, in
     }
 }
 
+// Row softmax in place over fp16 [rows, n] (row stride ld): the single-head d = C mid-block attention of
+// the VAE decoder (model.py:180-186) runs as two GEMMs around this kernel because its head dim (512)
+// exceeds the flash kernel's register budget; it runs once per image, not per step.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(half_t* __restrict__ x, int n, int ld, float scale) {
+    __shared__ float red[4];
+    half_t* row = x + (size_t)blockIdx.x * ld;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float mx = -INFINITY;
+    for (int i = threadIdx.x * 8; i < n; i += 256 * 8) {
+        uint4 raw = ld16(row + i);
+        const half8_t v = *reinterpret_cast<half8_t*>(&raw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mx = fmaxf(mx, (float)v[j]);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * scale;
+    __syncthreads();
+    float sum = 0.0f;
+    for (int i = threadIdx.x * 8; i < n; i += 256 * 8) {
+        uint4 raw = ld16(row + i);
+        const half8_t v = *reinterpret_cast<half8_t*>(&raw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += __expf((float)v[j] * scale - mx);
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+    for (int i = threadIdx.x * 8; i < n; i += 256 * 8) {
+        uint4 raw = ld16(row + i);
+        const half8_t v = *reinterpret_cast<half8_t*>(&raw);
+        half8_t o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (half_t)(__expf((float)v[j] * scale - mx) * inv);
+        st16(row + i, *reinterpret_cast<uint4*>(&o));
+    }
+}
+
+// z fp32 [B, C, hw] -> fp16 [B, hw, Cpad]: out[:, :, co] = bias[co] + sum_ci w[co, ci] * (z[:, ci, :] * pre),
+// zero for co >= C.  AutoencoderKL.decode's 1/scale_factor and 1x1 post_quant_conv (autoencoder.py:41-42).
+__global__ void latent_affine_pack_kernel(const float* __restrict__ z, const float* __restrict__ w,
+                                          const float* __restrict__ bias, float pre, int B, int C, int hw, int Cpad,
+                                          half_t* __restrict__ out) {
+    const size_t total = (size_t)B * hw * Cpad;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % Cpad);
+        const size_t t = i / Cpad;
+        const int p = (int)(t % hw);
+        const int b = (int)(t / hw);
+        float v = 0.0f;
+        if (co < C) {
+            v = bias[co];
+            for (int ci = 0; ci < C; ++ci) v += w[co * C + ci] * (z[((size_t)b * C + ci) * hw + p] * pre);
+        }
+        out[i] = (half_t)v;
+    }
+}
+
 int ew_blocks(size_t n) {
     size_t b = (n + 255) / 256;
     return (int)(b > 2048 ? 2048 : (b == 0 ? 1 : b));
@@ -153,6 +213,22 @@ extern "C" int gl_pack_latent(const float* x, int32_t B, int32_t C, int32_t hw, 
     if (!x || !out || B <= 0 || C <= 0 || hw <= 0 || Cpad < C || reps <= 0) return GL_ERR_BAD_ARG;
     pack_latent_kernel<<<dim3(ew_blocks((size_t)reps * B * hw * Cpad)), dim3(256), 0, (hipStream_t)stream>>>(
         x, B, C, hw, Cpad, reps, reinterpret_cast<half_t*>(out));
+    GL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gl_softmax_rows(void* x, int32_t rows, int32_t n, int32_t ld, float scale, void* stream) {
+    if (!x || rows <= 0 || n <= 0 || (n % 8) || (ld % 8)) return GL_ERR_BAD_ARG;
+    softmax_rows_kernel<<<dim3(rows), dim3(256), 0, (hipStream_t)stream>>>(reinterpret_cast<half_t*>(x), n, ld, scale);
+    GL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gl_latent_affine_pack(const float* z, const float* w, const float* bias, float pre, int32_t B, int32_t C,
+                                     int32_t hw, int32_t Cpad, void* out, void* stream) {
+    if (!z || !w || !bias || !out || B <= 0 || C <= 0 || hw <= 0 || Cpad < C) return GL_ERR_BAD_ARG;
+    latent_affine_pack_kernel<<<dim3(ew_blocks((size_t)B * hw * Cpad)), dim3(256), 0, (hipStream_t)stream>>>(
+        z, w, bias, pre, B, C, hw, Cpad, reinterpret_cast<half_t*>(out));
     GL_CHECK_LAUNCH();
     return 0;
 }

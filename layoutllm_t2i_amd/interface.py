@@ -33,7 +33,9 @@ import torch
 
 from . import host
 from .arch import UNetConfig
+from .arch import VAEConfig
 from .model import GroundingNetInput, LatentDiffusion, UNetModel, load_sd_first_conv
+from .vae import VAEDecoder
 from .sampler import PLMSSampler
 
 MAX_OBJS = 30
@@ -73,12 +75,21 @@ def load_ckpt(ckpt_path, device="cuda"):
     dparams = config["diffusion"].get("params", {})
     diffusion = LatentDiffusion(linear_start=dparams.get("linear_start", 0.00085), linear_end=dparams.get("linear_end", 0.012),
                                 timesteps=dparams.get("timesteps", 1000), device=device)
-    autoencoder = _instantiate_reference(config["autoencoder"]).to(device).eval()
+    if os.environ.get("GLIGEN_REFERENCE_VAE"):
+        autoencoder = _instantiate_reference(config["autoencoder"]).to(device).eval()
+        autoencoder.load_state_dict(saved_ckpt["autoencoder"])
+    else:
+        # decode stage on the HIP kernels; only `.decode(z)` is used on this path (interface.py:541)
+        ap = config["autoencoder"].get("params", {})
+        dd = ap.get("ddconfig", {})
+        vcfg = VAEConfig(ch=dd.get("ch", 128), ch_mult=tuple(dd.get("ch_mult", (1, 2, 4, 4))),
+                         num_res_blocks=dd.get("num_res_blocks", 2), z_channels=dd.get("z_channels", 4),
+                         out_ch=dd.get("out_ch", 3), embed_dim=ap.get("embed_dim", 4), scale_factor=ap.get("scale_factor", 0.18215))
+        autoencoder = VAEDecoder(saved_ckpt["autoencoder"], vcfg, device)
     text_encoder = _instantiate_reference(config["text_encoder"]).to(device).eval()
-    autoencoder.load_state_dict(saved_ckpt["autoencoder"])
     text_encoder.load_state_dict(saved_ckpt["text_encoder"])
     for m in (autoencoder, text_encoder):
-        if "device" in vars(m):
+        if not isinstance(m, VAEDecoder) and "device" in vars(m):
             m.device = device
     return model, autoencoder, text_encoder, diffusion, config
 

@@ -167,7 +167,11 @@ def attention(q: torch.Tensor, q_bstride: int, ldq: int, k: torch.Tensor, k_bstr
 
 
 def gn_nchunk(HW: int) -> int:
-    return max(1, min(64, HW // 4))
+    """pixel chunks per sample for the GroupNorm partial sums: 64 for the UNet's maps (<= 64x64), more for the
+    VAE decoder's large maps so the statistics pass still fills the chip"""
+    if HW <= 4096:
+        return max(1, min(64, HW // 4))
+    return min(512, HW // 512)
 
 
 def groupnorm(x1: torch.Tensor, x2: Optional[torch.Tensor], B: int, HW: int, gamma: torch.Tensor, beta: torch.Tensor,
@@ -288,6 +292,25 @@ def pack_latent(x: torch.Tensor, Cpad: int, reps: int, out: torch.Tensor):
     _req(out, F16, "out")
     B, Cc, h, w = x.shape
     check(_lib.lib().gl_pack_latent(x.data_ptr(), B, Cc, h * w, Cpad, reps, out.data_ptr(), _stream()), "gl_pack_latent")
+    return out
+
+
+def softmax_rows(x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    """in-place softmax(scale * x) over the last dim of a 2-D fp16 tensor"""
+    _req(x, F16, "x")
+    rows, n, ld = _rows(x, "x")
+    check(_lib.lib().gl_softmax_rows(x.data_ptr(), rows, n, ld, scale, _stream()), "gl_softmax_rows")
+    return x
+
+
+def latent_affine_pack(z: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, pre: float, Cpad: int, out: torch.Tensor):
+    """z fp32 [B, C, h, w] -> out fp16 [B*h*w, Cpad] = post_quant_conv(z * pre), zero-padded channels"""
+    for t, n in ((z, "z"), (w, "w"), (bias, "bias")):
+        _req(t, F32, n, 4)
+    _req(out, F16, "out")
+    B, Cc, h, ww = z.shape
+    check(_lib.lib().gl_latent_affine_pack(z.data_ptr(), w.data_ptr(), bias.data_ptr(), pre, B, Cc, h * ww, Cpad,
+                                           out.data_ptr(), _stream()), "gl_latent_affine_pack")
     return out
 
 

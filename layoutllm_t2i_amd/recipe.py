@@ -19,7 +19,7 @@ from typing import Dict, Tuple
 
 import numpy as np
 
-from .arch import UNetConfig, param_shapes
+from .arch import UNetConfig, VAEConfig, param_shapes, vae_decoder_param_shapes
 
 
 def _key(name: str, seed: int) -> int:
@@ -60,7 +60,7 @@ def tensor(name: str, shape: Tuple[int, ...], seed: int = 0) -> np.ndarray:
     if leaf.startswith("null_"):
         return uniform(name, shape, seed) * np.float32(0.5)
     is_norm = (".norm" in name or "in_layers.0" in name or "out_layers.0" in name
-               or name.startswith("out.0"))
+               or name.startswith("out.0") or "norm_out" in name)
     if is_norm and len(shape) == 1:
         if leaf == "weight":
             return np.float32(1.0) + np.float32(0.1) * uniform(name, shape, seed)
@@ -80,6 +80,11 @@ def state_dict(cfg: UNetConfig, seed: int = 0, only_prefix: str | None = None) -
             continue
         out[name] = tensor(name, shape, seed)
     return out
+
+
+def vae_state_dict(cfg: VAEConfig, seed: int = 0) -> Dict[str, np.ndarray]:
+    """Recipe weights of the VAE decode path (reference names), float32."""
+    return {n: tensor("vae." + n, shp, seed) for n, shp in vae_decoder_param_shapes(cfg).items()}
 
 
 def sd_first_conv(cfg: UNetConfig, seed: int = 0) -> Dict[str, np.ndarray]:

@@ -205,3 +205,25 @@ def random_state_dict(cfg: UNetConfig, device, seed: int = 0) -> Dict[str, torch
             t = u() * math.sqrt(3.0 / max(fan_in, 1))
         out[name] = t
     return out
+
+
+@torch.no_grad()
+def random_vae_state_dict(cfg, device, seed: int = 1) -> Dict[str, torch.Tensor]:
+    """On-device random VAE-decoder weights with the recipe's scaling rules (benchmark only)."""
+    from .arch import vae_decoder_param_shapes
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    out: Dict[str, torch.Tensor] = {}
+    for name, shape in vae_decoder_param_shapes(cfg).items():
+        u = torch.rand(shape, generator=gen, device=device, dtype=torch.float32) * 2 - 1
+        leaf = name.rsplit(".", 1)[-1]
+        if "norm" in name and len(shape) == 1:
+            out[name] = 1.0 + 0.1 * u if leaf == "weight" else 0.05 * u
+        elif leaf == "bias":
+            out[name] = 0.02 * u
+        else:
+            fan_in = 1
+            for s_ in shape[1:]:
+                fan_in *= s_
+            out[name] = u * math.sqrt(3.0 / max(fan_in, 1))
+    return out

@@ -98,6 +98,7 @@ CASES = [
     dict(name="unet_tiny_null", kind="unet", B=2, hw=16, t=[401, 401], grounding="null", scale=1.0, sdconv=False),
     dict(name="unet_tiny_s0_sd", kind="unet", B=2, hw=16, t=[21, 21], grounding="real", scale=0.0, sdconv=True),
     dict(name="plms_tiny", kind="plms", B=2, hw=16, S=10, guidance=7.5, alpha_type=[0.3, 0.0, 0.7]),
+    dict(name="vae_tiny", kind="vae", B=2, hw=8),
 ]
 
 
@@ -157,4 +158,6 @@ def case_inputs(case):
         return dict(x=rnd(f"{nm}.x", (case["B"], case["C"], case["hw"], case["hw"])))
     if k in ("unet", "plms"):
         return unet_inputs(case)
+    if k == "vae":
+        return dict(z=rnd(f"{nm}.z", (case["B"], 4, case["hw"], case["hw"])) * np.float32(0.18215 * 2.0))
     return {}

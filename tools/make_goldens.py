@@ -29,7 +29,7 @@ import numpy as np
 import torch
 
 from layoutllm_t2i_amd import recipe
-from layoutllm_t2i_amd.arch import TINY
+from layoutllm_t2i_amd.arch import TINY, VAE_TINY
 import golden_cases as gc
 
 from ldm.modules.diffusionmodules.openaimodel import UNetModel, ResBlock, Upsample, Downsample
@@ -170,6 +170,19 @@ def run_case(case):
         shape = (case["B"], 4, case["hw"], case["hw"])
         out = sampler.sample(S=case["S"], shape=shape, input=d, uc=inp["uc"], guidance_scale=case["guidance"])
         return dict(out=out.numpy())
+    if k == "vae":
+        import contextlib
+        import io
+        from ldm.models.autoencoder import AutoencoderKL
+        cfg = VAE_TINY
+        dd = dict(double_z=True, z_channels=cfg.z_channels, resolution=256, in_channels=3, out_ch=cfg.out_ch, ch=cfg.ch,
+                  ch_mult=list(cfg.ch_mult), num_res_blocks=cfg.num_res_blocks, attn_resolutions=[], dropout=0.0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = AutoencoderKL(dd, cfg.embed_dim, scale_factor=cfg.scale_factor).eval()
+        sd = {n: T(np.asarray(v)) for n, v in recipe.vae_state_dict(cfg, 0).items()}
+        missing, unexpected = m.load_state_dict(sd, strict=False)
+        assert not unexpected and all(x.startswith(("encoder.", "quant_conv.")) for x in missing), (missing[:3], unexpected)
+        return dict(out=m.decode(inp["z"]).numpy())
     raise ValueError(k)
 
 
