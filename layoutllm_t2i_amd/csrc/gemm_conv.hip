@@ -36,6 +36,7 @@ __device__ uint4 g_zero16[4];
 namespace {
 
 int g_opt_pipe = 0;          // 0 = BK 64 / 2-stage (default, faster), 1 = BK 32 / 3-stage counted-vmcnt pipeline
+int g_opt_big = 0;            // >0: use the 8-wave 256-row / 3-stage kernels when that grid has at least this many tiles
 int g_opt_small = 400;       // use 64x128 tiles when the 128-row grid has fewer tiles than this (0 = never)
 int g_opt_splitk_tiles = 300; // split K only below this many tiles (plain GEMM) ...
 int g_opt_splitk_tiles_conv = 450; // ... (conv)
@@ -66,24 +67,25 @@ __device__ __forceinline__ void glds16(const half_t* src, half_t* dst) {
         reinterpret_cast<__attribute__((address_space(3))) void*>(reinterpret_cast<uintptr_t>(dst)), 16, 0, 0);
 }
 
-template <int BM, int BN, int BKT, int NST>
+template <int BM, int BN, int BKT, int NST, int NW = 4>
 constexpr int lds_bytes() {
     constexpr int pipe = NST * (BM + BN) * BKT * (int)sizeof(half_t);
-    constexpr int epi = 4 * 32 * 68 * (int)sizeof(float);     // epilogue staging: 4 waves x 32 rows x (64+4) fp32
+    constexpr int epi = NW * 32 * 68 * (int)sizeof(float);    // epilogue staging: NW waves x 32 rows x (64+4) fp32
     return pipe > epi ? pipe : epi;
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, int BKT, int NST>
-__global__ __launch_bounds__(256) void gemm_kernel(gl_gemm_args p, ConvGeom cg, int splitk, int kt_per_split) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(gl_gemm_args p, ConvGeom cg, int splitk, int kt_per_split) {
+    constexpr int NTHR = 64 * WAVES_M * WAVES_N;  // 4 waves (256 threads) or 8 waves (512 threads, 256-row tiles)
     constexpr int TM = BM / WAVES_M / 32;
     constexpr int TN = BN / WAVES_N / 32;
     constexpr int CPR = BKT / 8;                 // 16-byte chunks per tile row (8 or 4)
-    constexpr int RPP = 256 / CPR;               // tile rows covered by one pass of the 256 threads
+    constexpr int RPP = NTHR / CPR;              // tile rows covered by one pass of the block's threads
     constexpr int RPW = 64 / CPR;                // tile rows covered by one wave instruction (1 KiB)
     constexpr int APASS = (BM + RPP - 1) / RPP;
     constexpr int BPASS = (BN + RPP - 1) / RPP;
     constexpr int KSTEPS = BKT / 16;
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+    static_assert(WAVES_M * WAVES_N == 4 || WAVES_M * WAVES_N == 8, "4 or 8 waves");
     static_assert(BM % RPW == 0 && BN % RPW == 0, "whole wave instructions");
     static_assert(BKT == 128 || BKT == 64 || BKT == 32, "BK");
 
@@ -307,6 +309,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(gl_gemm_args p, ConvGeom cg, 
                     case 4: wait_vmcnt<4>(); break;
                     case 5: wait_vmcnt<5>(); break;
                     case 6: wait_vmcnt<6>(); break;
+                    case 7: wait_vmcnt<7>(); break;
+                    case 8: wait_vmcnt<8>(); break;
                     default: wait_vmcnt<0>(); break;
                 }
             } else {
@@ -545,8 +549,8 @@ int launch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     int kper = gl_cdiv(nk, splitk);
     const int zs = gl_cdiv(nk, kper);          // slices that actually have work
     dim3 grid(mt * nt, 1, zs);
-    constexpr int lds = lds_bytes<BM, BN, BKT, NST>();
-    gemm_kernel<BM, BN, WM, WN, CONV, BKT, NST><<<grid, dim3(256), lds, st>>>(g, cg, zs, kper);
+    constexpr int lds = lds_bytes<BM, BN, BKT, NST, WM * WN>();
+    gemm_kernel<BM, BN, WM, WN, CONV, BKT, NST><<<grid, dim3(64 * WM * WN), lds, st>>>(g, cg, zs, kper);
     GL_CHECK_LAUNCH();
     if (zs > 1) {
         const size_t total = (size_t)g.M * (g.N / 4);
@@ -576,6 +580,18 @@ int dispatch_shape(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     if (g_opt_small && !CONV && g.K <= 1280 && shape != 2 && (g.N % 128) == 0) {
         const long t128 = (long)gl_cdiv(g.M, 128) * gl_cdiv(g.N, shape == 1 ? 160 : 128);
         if (t128 < g_opt_small) shape = 3;
+    }
+    // deep-prefetch variant for the big level-0 / wide-N problems: 8 waves share a 256-row tile, BK 64 with a
+    // 3-stage ring (loads get TWO tile-times to land instead of one) at the same 2 waves/SIMD occupancy
+    if constexpr (BKT == 64 && NST == 2) {
+        if (g_opt_big && shape != 2 && g.M >= 256) {
+            const int bn = (shape == 1) ? 160 : 128;
+            const long t256 = (long)gl_cdiv(g.M, 256) * gl_cdiv(g.N, bn);
+            if (t256 >= g_opt_big) {
+                if (shape == 1) return launch<256, 160, 8, 1, CONV, 64, 3>(g, cg, st);
+                if (shape == 0) return launch<256, 128, 4, 2, CONV, 64, 3>(g, cg, st);
+            }
+        }
     }
     if (shape == 3) return launch<64, 128, 2, 2, CONV, BKT, NST>(g, cg, st);
     if (shape == 1) return launch<128, 160, 4, 1, CONV, BKT, NST>(g, cg, st);
@@ -627,7 +643,7 @@ extern "C" int gl_conv3x3(const gl_conv_args* a, void* stream) {
 template <int BM, int BN, int WM, int WN, int BKT, int NST>
 int set_lds_attr() {
     hipError_t e;
-    const int lds = lds_bytes<BM, BN, BKT, NST>();
+    const int lds = lds_bytes<BM, BN, BKT, NST, WM * WN>();
     e = hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WM, WN, false, BKT, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WM, WN, true, BKT, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -638,7 +654,7 @@ int set_lds_attr() {
 template <int BM, int BN, int WM, int WN, int BKT, int NST>
 int set_lds_attr_plain() {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WM, WN, false, BKT, NST>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<BM, BN, BKT, NST>());
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<BM, BN, BKT, NST, WM * WN>());
     return e == hipSuccess ? 0 : (int)e;
 }
 
@@ -647,6 +663,8 @@ extern "C" int gl_init_gemm(void) {
     if ((e = set_lds_attr_plain<64, 128, 2, 2, 128, 2>())) return e;
     if ((e = set_lds_attr_plain<128, 128, 2, 2, 128, 2>())) return e;
     if ((e = set_lds_attr_plain<128, 160, 4, 1, 128, 2>())) return e;
+    if ((e = set_lds_attr<256, 160, 8, 1, 64, 3>())) return e;
+    if ((e = set_lds_attr<256, 128, 4, 2, 64, 3>())) return e;
     if ((e = set_lds_attr<64, 128, 2, 2, 32, 3>())) return e;
     if ((e = set_lds_attr<64, 128, 2, 2, 64, 2>())) return e;
     if ((e = set_lds_attr<128, 128, 2, 2, 32, 3>())) return e;
@@ -662,6 +680,7 @@ extern "C" int gl_set_option_gemm(int key, int value) {
     if (key == 1) { g_opt_pipe = value; return 0; }
     if (key == 2) { g_opt_tile = value; return 0; }
     if (key == 4) { g_opt_small = value; return 0; }
+    if (key == 7) { g_opt_big = value; return 0; }
     if (key == 5) { g_opt_splitk_tiles = value; g_opt_splitk_tiles_conv = value; return 0; }
     if (key == 6) { g_opt_splitk_nk = value; return 0; }
     return GL_ERR_BAD_ARG;

@@ -127,6 +127,24 @@ def test_gemm_split_k(M, N, K, epi):
     check(out, ref, f"gemm_splitk_{M}x{N}x{K}_{epi}")
 
 
+def test_gemm_conv_8wave_variant():
+    """the 8-wave / 256-row / 3-stage kernels (gl_set_option(7, n)) against the same references"""
+    ops.set_option(7, 1)
+    try:
+        test_gemm_bias(512, 1280, 640)
+        test_gemm_bias(1024, 960, 320)
+        test_gemm_bias(300, 320, 320)
+        test_gemm_epilogues()
+        test_gemm_geglu(320)
+        test_gemm_two_source()
+        test_conv3x3("s1", 320, 320, 16)
+        test_conv3x3("s2", 320, 320, 16)
+        test_conv3x3("up", 64, 128, 8)
+        test_conv3x3_epilogues()
+    finally:
+        ops.set_option(7, 0)
+
+
 def test_gemm_two_source():
     M, K1, K2, N = 260, 128, 192, 256
     a1, a1d = h16(rnd("ta1", (M, K1)))
