@@ -47,7 +47,25 @@ __global__ __launch_bounds__(256) void rela_pool_kernel(const half_t* __restrict
             float s[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) s[j] = 0.0f;
-            for (int q = plane; q < npix; q += nplanes) {
+            int q = plane;
+            // 4 independent 16-byte loads in flight per thread (rectangles can span 2k+ pixels)
+            for (; q + 3 * nplanes < npix; q += 4 * nplanes) {
+                uint4 raw[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int qq = q + u * nplanes;
+                    const int py = top + qq / rw;
+                    const int px = left + qq % rw;
+                    raw[u] = ld16(hid + (((size_t)b * H + py) * W + px) * C + vec * 8);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const half8_t hv = *reinterpret_cast<half8_t*>(&raw[u]);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) s[j] += (float)hv[j];
+                }
+            }
+            for (; q < npix; q += nplanes) {
                 const int py = top + q / rw;
                 const int px = left + q % rw;
                 uint4 raw = ld16(hid + (((size_t)b * H + py) * W + px) * C + vec * 8);
