@@ -35,6 +35,7 @@ __device__ uint4 g_zero16[4];
 
 namespace {
 
+int g_opt_geglu32 = 1;      // 1 = short-K GEGLU GEMMs use the 4-blocks/CU BK 32 variant
 int g_opt_pipe = 0;          // 0 = BK 64 / 2-stage (default, faster), 1 = BK 32 / 3-stage counted-vmcnt pipeline
 int g_opt_big = 0;            // >0: use the 8-wave 256-row / 3-stage kernels when that grid has at least this many tiles
 int g_opt_small = 400;       // use 64x128 tiles when the 128-row grid has fewer tiles than this (0 = never)
@@ -74,8 +75,17 @@ constexpr int lds_bytes() {
     return pipe > epi ? pipe : epi;
 }
 
+// occupancy hint: the 3-stage BK=32 128x128 kernel needs 48 KiB of LDS (3 blocks/CU) but ~178 registers;
+// asking for 3 waves/SIMD makes the compiler fit 170 so that the third block is actually resident.
+template <int BM, int BN, int BKT, int NST>
+constexpr int min_waves() {
+    if (BKT != 32) return 1;
+    if (BM * BN <= 128 * 128) return NST == 2 ? 4 : 3;
+    return NST == 2 ? 3 : 1;
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, int BKT, int NST>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(gl_gemm_args p, ConvGeom cg, int splitk, int kt_per_split) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (min_waves<BM, BN, BKT, NST>())) void gemm_kernel(gl_gemm_args p, ConvGeom cg, int splitk, int kt_per_split) {
     constexpr int NTHR = 64 * WAVES_M * WAVES_N;  // 4 waves (256 threads) or 8 waves (512 threads, 256-row tiles)
     constexpr int TM = BM / WAVES_M / 32;
     constexpr int TN = BN / WAVES_N / 32;
@@ -611,6 +621,13 @@ int dispatch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     if (g.epi == GL_EPI_GATE_RES && g.gate == nullptr) return GL_ERR_BAD_ARG;
     if (g.epi == GL_EPI_ROWBIAS && (g.rowbias == nullptr || g.rows_per_sample <= 0)) return GL_ERR_BAD_ARG;
     if (g_opt_pipe == 1) return dispatch_shape<CONV, 32, 3>(g, cg, st);
+    if (g_opt_pipe == 3) return dispatch_shape<CONV, 32, 2>(g, cg, st);
+    // GEGLU with a short K (levels 0/1: K = 320/640, 5-10 k-tiles) spends a large share of each block in its
+    // erf epilogue; BK 32 / 2-stage needs 35 KiB of LDS and 114 registers, so 4 blocks/CU are resident and
+    // one block's epilogue overlaps the others' main loops (measured 150 -> 135 us and 109 -> 100 us; long-K
+    // GEMMs and convs lose 10-20 % to the doubled barrier count, so they stay on BK 64)
+    if (!CONV && g_opt_pipe == 0 && g_opt_geglu32 && g.epi == GL_EPI_GEGLU && g.K <= 640)
+        return dispatch_shape<CONV, 32, 2>(g, cg, st);
     if constexpr (!CONV) {
         if (g_opt_pipe == 2 && (g.K % 128) == 0 && g.N >= 256) return dispatch_shape<false, 128, 2>(g, cg, st);
     }
@@ -667,6 +684,10 @@ extern "C" int gl_init_gemm(void) {
     if ((e = set_lds_attr<256, 128, 4, 2, 64, 3>())) return e;
     if ((e = set_lds_attr<64, 128, 2, 2, 32, 3>())) return e;
     if ((e = set_lds_attr<64, 128, 2, 2, 64, 2>())) return e;
+    if ((e = set_lds_attr<64, 128, 2, 2, 32, 2>())) return e;
+    if ((e = set_lds_attr<128, 128, 2, 2, 32, 2>())) return e;
+    if ((e = set_lds_attr<128, 160, 4, 1, 32, 2>())) return e;
+    if ((e = set_lds_attr<256, 64, 4, 1, 32, 2>())) return e;
     if ((e = set_lds_attr<128, 128, 2, 2, 32, 3>())) return e;
     if ((e = set_lds_attr<128, 160, 4, 1, 32, 3>())) return e;
     if ((e = set_lds_attr<256, 64, 4, 1, 32, 3>())) return e;
@@ -681,6 +702,7 @@ extern "C" int gl_set_option_gemm(int key, int value) {
     if (key == 2) { g_opt_tile = value; return 0; }
     if (key == 4) { g_opt_small = value; return 0; }
     if (key == 7) { g_opt_big = value; return 0; }
+    if (key == 8) { g_opt_geglu32 = value; return 0; }
     if (key == 5) { g_opt_splitk_tiles = value; g_opt_splitk_tiles_conv = value; return 0; }
     if (key == 6) { g_opt_splitk_nk = value; return 0; }
     return GL_ERR_BAD_ARG;
