@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tiny", action="store_true", help="debug: tiny UNet (not a valid benchmark)")
     ap.add_argument("--no-vae", action="store_true", help="stop at the final latent (exclude the VAE decode stage from the step)")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
+                    help="gl_set_option tuning knob for same-box A/B runs (see include/gligen_hip.h), repeatable")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to smoke-test the path on one GPU)")
     return ap.parse_args()
 
@@ -87,6 +89,11 @@ def main():
 
     cfg = TINY if args.tiny else UNetConfig()
     B, side = args.batch, args.latent
+    if args.opt:
+        from layoutllm_t2i_amd import ops as _ops
+        for kv in args.opt:
+            k, v = kv.split("=")
+            _ops.set_option(int(k), int(v))
 
     # ---- weights: rank 0 builds + packs, one RCCL broadcast to the others (timed separately)
     t0 = time.time()

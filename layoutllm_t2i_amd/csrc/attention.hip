@@ -3,7 +3,8 @@
 // Replaces SelfAttention.forward (attention.py:164-176) and CrossAttention.forward (:128-141), which
 // materialise `sim` as (B*8) x N x N fp32 (2.1 GB at the 64x64 level for B=4).
 //
-// Work decomposition: grid = (ceil(Nq/128), H, B); 256 threads = 4 waves, each wave owns 32 queries.
+// Work decomposition: one block per (128- or 256-query slab, head, batch), 4 or 8 waves, each wave owns 32
+// queries; the 1-D grid is remapped so that all slabs of one (batch, head) run on the same XCD / L2.
 // Per 64-key tile the block stages K [64][d] and V^T [d][64] in LDS (register-prefetched one tile
 // ahead), then every wave runs
 //   S^T = K . Q^T   as mfma_32x32x16(A = K rows, B = Q rows): lane (q = lane&31, hi = lane>>5) ends up
@@ -26,8 +27,11 @@ int g_attn_qt2 = 0;
 constexpr int KT = 64;          // keys per tile
 constexpr int VSTR = KT + 4;    // V^T LDS row stride in halfs (136 B: odd number of 8-byte slots)
 
-template <int DQK, int QT>
-__global__ __launch_bounds__(256) void attn_kernel(gl_attn_args p) {
+template <int DQK, int QT, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_kernel(gl_attn_args p) {
+    // NW = waves per block: 4 (128 queries share each staged K/V tile) or 8 (256 queries: half the L2 -> LDS
+    // traffic per query at the same registers per wave)
+    constexpr int NTHR = 64 * NW;
     // QT = 32-query sub-tiles per wave: 2 for small head dims (256 queries per block: every K/V tile
     // staged in LDS and every K/V fragment read from LDS is reused twice), 1 where the O accumulator
     // (NDT x 16 registers per sub-tile) is too large.
@@ -36,10 +40,10 @@ __global__ __launch_bounds__(256) void attn_kernel(gl_attn_args p) {
     constexpr int KSTR = DQK + 8;            // K LDS row stride in halfs (odd number of 16-byte slots)
     constexpr int KCH = DQK / 8;             // 16-byte chunks per K row
     constexpr int K_ITEMS = KT * KCH;        // chunks in a K tile
-    constexpr int K_PER_T = (K_ITEMS + 255) / 256;
+    constexpr int K_PER_T = (K_ITEMS + NTHR - 1) / NTHR;
     constexpr int V_ITEMS = NDT * 32 * (KT / 8);
-    constexpr int V_PER_T = (V_ITEMS + 255) / 256;
-    constexpr int QBLK = 4 * 32 * QT;        // queries per block
+    constexpr int V_PER_T = (V_ITEMS + NTHR - 1) / NTHR;
+    constexpr int QBLK = NW * 32 * QT;        // queries per block
     // If the padded head-dim tile has a spare row, V^T row OC is kept at 1.0 so that the P.V MFMA also
     // produces the softmax denominator (sum_k P) in O column OC: saves 32 VALU adds per tile.
     constexpr bool ONES = (NDT * 32 > DQK);
@@ -56,9 +60,21 @@ __global__ __launch_bounds__(256) void attn_kernel(gl_attn_args p) {
     const int wave = tid >> 6;
     const int ql = lane & 31;
     const int hi = lane >> 5;
-    const int b = blockIdx.z;
-    const int h = blockIdx.y;
-    const int q0 = blockIdx.x * QBLK + wave * (32 * QT);
+    // 1-D grid, XCD-aware: hardware block id L goes to XCD L % 8, each with its own 4 MB L2.  Give every XCD a
+    // contiguous range of logical blocks (bijective also when the count is not a multiple of 8) so that all
+    // query blocks of one (batch, head) -- which stream the same K / V^T -- hit the same L2.
+    const int nqb = (p.Nq + QBLK - 1) / QBLK;
+    int logical;
+    {
+        const int total = gridDim.x, L = blockIdx.x;
+        const int xcd = L & 7, qd = total >> 3, rm = total & 7;
+        logical = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (L >> 3);
+    }
+    const int qb = logical % nqb;
+    const int bh = logical / nqb;
+    const int h = bh % p.H;
+    const int b = bh / p.H;
+    const int q0 = qb * QBLK + wave * (32 * QT);
     const int d = p.d, Nq = p.Nq, Nk = p.Nk;
 
     const half_t* __restrict__ Qg = reinterpret_cast<const half_t*>(p.q) + (size_t)b * p.q_bstride + (size_t)h * d;
@@ -102,7 +118,7 @@ __global__ __launch_bounds__(256) void attn_kernel(gl_attn_args p) {
     bool kok[K_PER_T], vok[V_PER_T], vone[V_PER_T];
 #pragma unroll
     for (int i = 0; i < K_PER_T; ++i) {
-        const int idx = tid + 256 * i;
+        const int idx = tid + NTHR * i;
         const int row = idx / KCH;
         const int c = idx - row * KCH;
         krow[i] = row;
@@ -112,7 +128,7 @@ __global__ __launch_bounds__(256) void attn_kernel(gl_attn_args p) {
     }
 #pragma unroll
     for (int i = 0; i < V_PER_T; ++i) {
-        const int idx = tid + 256 * i;
+        const int idx = tid + NTHR * i;
         const int row = idx >> 3;      // head-dim column
         const int c = idx & 7;         // 8-key chunk
         vok[i] = (idx < V_ITEMS) && (row < d);
@@ -144,10 +160,10 @@ __global__ __launch_bounds__(256) void attn_kernel(gl_attn_args p) {
         half_t* Vsw = Vsm + buf * VBUF;
 #pragma unroll
         for (int i = 0; i < K_PER_T; ++i)
-            if (tid + 256 * i < K_ITEMS) st16(Ksw + klds[i], rk[i]);
+            if (tid + NTHR * i < K_ITEMS) st16(Ksw + klds[i], rk[i]);
 #pragma unroll
         for (int i = 0; i < V_PER_T; ++i)
-            if (tid + 256 * i < V_ITEMS) {
+            if (tid + NTHR * i < V_ITEMS) {
                 uint2* dst = reinterpret_cast<uint2*>(Vsw + vlds[i]);   // 8-byte aligned only
                 dst[0] = make_uint2(rv[i].x, rv[i].y);
                 dst[1] = make_uint2(rv[i].z, rv[i].w);
@@ -534,10 +550,10 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const half_t* __restri
     }
 }
 
-template <int DQK, int QT>
+template <int DQK, int QT, int NW = 4>
 int launch_attn(const gl_attn_args& a, hipStream_t st) {
-    dim3 grid(gl_cdiv(a.Nq, 128 * QT), a.H, a.B);
-    attn_kernel<DQK, QT><<<grid, dim3(256), 0, st>>>(a);
+    dim3 grid(gl_cdiv(a.Nq, 32 * NW * QT) * a.H * a.B);
+    attn_kernel<DQK, QT, NW><<<grid, dim3(64 * NW), 0, st>>>(a);
     GL_CHECK_LAUNCH();
     return 0;
 }
@@ -549,6 +565,10 @@ int launch_attn_auto(const gl_attn_args& a, hipStream_t st) {
     // 479 us for QT = 1 at 3 waves/SIMD; occupancy beats staging reuse here, so QT = 2 stays opt-in.
     if constexpr (DQK <= 80) {
         if (g_attn_qt2 == 1 && a.Nq >= 256) return launch_attn<DQK, 2>(a, st);
+        // 8 waves (256 queries) per block halve the K / V^T tile traffic per query: 355 -> 326 us at d = 40,
+        // N = 4096 (with the XCD-aware block order); no effect on the 77-key text cross-attention
+        if ((g_attn_qt2 == 3 && a.Nq >= 256) || (g_attn_qt2 == 0 && a.Nq >= 512 && a.Nk >= 512))
+            return launch_attn<DQK, 1, 8>(a, st);
         if (g_attn_qt2 == 2 && a.Nk > 128) {
             dim3 grid(gl_cdiv(a.Nq, 128), a.H, a.B);
             attn_pipe_kernel<DQK><<<grid, dim3(256), 0, st>>>(a);

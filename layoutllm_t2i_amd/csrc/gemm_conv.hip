@@ -35,6 +35,7 @@ __device__ uint4 g_zero16[4];
 
 namespace {
 
+int g_opt_big_kind = 1;     // which 256-row variant g_opt_big selects: 0 = 8 waves BK 64 / 3-stage, 1 = 4 waves BK 32 / 2-stage
 int g_opt_geglu32 = 1;      // 1 = short-K GEGLU GEMMs use the 4-blocks/CU BK 32 variant
 int g_opt_pipe = 0;          // 0 = BK 64 / 2-stage (default, faster), 1 = BK 32 / 3-stage counted-vmcnt pipeline
 int g_opt_big = 0;            // >0: use the 8-wave 256-row / 3-stage kernels when that grid has at least this many tiles
@@ -80,6 +81,7 @@ constexpr int lds_bytes() {
 template <int BM, int BN, int BKT, int NST>
 constexpr int min_waves() {
     if (BKT != 32) return 1;
+    if (BM * BN >= 256 * 128) return NST == 2 ? 2 : 1;
     if (BM * BN <= 128 * 128) return NST == 2 ? 4 : 3;
     return NST == 2 ? 3 : 1;
 }
@@ -598,6 +600,10 @@ int dispatch_shape(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
             const int bn = (shape == 1) ? 160 : 128;
             const long t256 = (long)gl_cdiv(g.M, 256) * gl_cdiv(g.N, bn);
             if (t256 >= g_opt_big) {
+                if (g_opt_big_kind == 1) {   // 4 waves with 64-row wave tiles: 0.7-0.75 LDS fragment reads per MFMA
+                    if (shape == 1) return launch<256, 160, 4, 1, CONV, 32, 2>(g, cg, st);
+                    if (shape == 0) return launch<256, 128, 4, 1, CONV, 32, 2>(g, cg, st);
+                }
                 if (shape == 1) return launch<256, 160, 8, 1, CONV, 64, 3>(g, cg, st);
                 if (shape == 0) return launch<256, 128, 4, 2, CONV, 64, 3>(g, cg, st);
             }
@@ -688,6 +694,8 @@ extern "C" int gl_init_gemm(void) {
     if ((e = set_lds_attr<128, 128, 2, 2, 32, 2>())) return e;
     if ((e = set_lds_attr<128, 160, 4, 1, 32, 2>())) return e;
     if ((e = set_lds_attr<256, 64, 4, 1, 32, 2>())) return e;
+    if ((e = set_lds_attr<256, 160, 4, 1, 32, 2>())) return e;
+    if ((e = set_lds_attr<256, 128, 4, 1, 32, 2>())) return e;
     if ((e = set_lds_attr<128, 128, 2, 2, 32, 3>())) return e;
     if ((e = set_lds_attr<128, 160, 4, 1, 32, 3>())) return e;
     if ((e = set_lds_attr<256, 64, 4, 1, 32, 3>())) return e;
@@ -703,6 +711,7 @@ extern "C" int gl_set_option_gemm(int key, int value) {
     if (key == 4) { g_opt_small = value; return 0; }
     if (key == 7) { g_opt_big = value; return 0; }
     if (key == 8) { g_opt_geglu32 = value; return 0; }
+    if (key == 9) { g_opt_big_kind = value; return 0; }
     if (key == 5) { g_opt_splitk_tiles = value; g_opt_splitk_tiles_conv = value; return 0; }
     if (key == 6) { g_opt_splitk_nk = value; return 0; }
     return GL_ERR_BAD_ARG;

@@ -127,8 +127,11 @@ def test_gemm_split_k(M, N, K, epi):
     check(out, ref, f"gemm_splitk_{M}x{N}x{K}_{epi}")
 
 
-def test_gemm_conv_8wave_variant():
-    """the 8-wave / 256-row / 3-stage kernels (gl_set_option(7, n)) against the same references"""
+@pytest.mark.parametrize("kind", [0, 1])
+def test_gemm_conv_256row_variants(kind):
+    """the opt-in 256-row kernels (gl_set_option(7, n); option 9: 0 = 8 waves BK64/3-stage, 1 = 4 waves with
+    64-row wave tiles BK32/2-stage) against the same references"""
+    ops.set_option(9, kind)
     ops.set_option(7, 1)
     try:
         test_gemm_bias(512, 1280, 640)
@@ -143,6 +146,25 @@ def test_gemm_conv_8wave_variant():
         test_conv3x3_epilogues()
     finally:
         ops.set_option(7, 0)
+        ops.set_option(9, 1)
+
+
+@pytest.mark.parametrize("pipe", [1, 3])
+def test_gemm_conv_bk32_variants(pipe):
+    """BK 32 pipelines (gl_set_option(1, 1|3)): 3-stage counted-vmcnt and 2-stage / 4 blocks per CU"""
+    ops.set_option(1, pipe)
+    try:
+        test_gemm_bias(512, 1280, 640)
+        test_gemm_bias(300, 320, 320)
+        test_gemm_bias(77, 64, 768)
+        test_gemm_epilogues()
+        test_gemm_geglu(320)
+        test_gemm_two_source()
+        test_conv3x3("s1", 320, 320, 16)
+        test_conv3x3("s2", 320, 320, 16)
+        test_conv3x3_epilogues()
+    finally:
+        ops.set_option(1, 0)
 
 
 def test_gemm_two_source():
@@ -270,6 +292,17 @@ def test_attention_pipelined_variant(d, H, Nq, Nk, B):
     ops.set_option(3, 2)
     try:
         test_attention(d, H, Nq, Nk, B)
+    finally:
+        ops.set_option(3, 0)
+
+
+@pytest.mark.parametrize("opt", [3, 4])
+def test_attention_block_size_variants(opt):
+    """8-wave (256-query) and 4-wave blocks forced via gl_set_option(3, 3|4); includes a ragged last slab"""
+    ops.set_option(3, opt)
+    try:
+        test_attention(40, 8, 600, 1054, 1)
+        test_attention(80, 8, 300, 1054, 1)
     finally:
         ops.set_option(3, 0)
 
