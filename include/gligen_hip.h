@@ -204,7 +204,8 @@ int gl_sizeof_attn_args(void);
  * 1 = BK 32, 3 stages with counted vmcnt; 3 = BK 32, 2 stages at 4 blocks/CU); key 2 = tile shape policy (0 auto, 1 force 128x128, 2 prefer 128x160); key 3 = attention
  * variant (0 = auto: 32 queries/wave, 8-wave blocks for long sequences; 1 = 64 queries/wave; 2 = software-pipelined;
  * 3 = always 8-wave blocks; 4 = always 4-wave blocks); keys 4-7 = small-tile / split-K / 8-wave thresholds; key 8 = short-K
- * GEGLU GEMMs on the BK 32 / 4-blocks-per-CU variant (1 default, 0 off); key 9 = which 256-row GEMM variant key 7 selects.
+ * GEGLU GEMMs on the BK 32 / 4-blocks-per-CU variant (1 default, 0 off); key 9 = which 256-row GEMM variant key 7 selects;
+ * key 10 = s_setprio around the attention MFMA clusters (-1 auto, 0 off, 1 on).
  * Results do not depend on these knobs beyond fp32 summation order in split-K. */
 int gl_set_option(int key, int value);
 /* one-time per-process setup (raises dynamic-LDS limits of the tiled kernels); idempotent */

@@ -24,14 +24,17 @@
 namespace {
 
 int g_attn_qt2 = 0;
+int g_attn_setprio = -1;     // s_setprio(1) around the MFMA clusters: -1 auto (head dim <= 48: +6 %; d = 80: -4 %), 0 off, 1 on
 constexpr int KT = 64;          // keys per tile
-constexpr int VSTR = KT + 4;    // V^T LDS row stride in halfs (136 B: odd number of 8-byte slots)
+constexpr int VSTR = KT + 4;    // V^T LDS row stride in halfs (136 B: odd number of 8-byte slots), pipelined variant
+constexpr int VSTR2 = KT + 8;   // main kernel: 144 B rows = 9 x 16 B, conflict-free 16-byte fragment reads
 
 template <int DQK, int QT, int NW>
-__global__ __launch_bounds__(64 * NW) void attn_kernel(gl_attn_args p) {
+__global__ __launch_bounds__(64 * NW) void attn_kernel(gl_attn_args p, int flags) {
     // NW = waves per block: 4 (128 queries share each staged K/V tile) or 8 (256 queries: half the L2 -> LDS
     // traffic per query at the same registers per wave)
     constexpr int NTHR = 64 * NW;
+    const bool SETPRIO = (flags & 1) != 0;
     // QT = 32-query sub-tiles per wave: 2 for small head dims (256 queries per block: every K/V tile
     // staged in LDS and every K/V fragment read from LDS is reused twice), 1 where the O accumulator
     // (NDT x 16 registers per sub-tile) is too large.
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(gl_attn_args p) {
 
     // double-buffered K / V^T tiles: one barrier per 64-key tile
     constexpr int KBUF = KT * KSTR;
-    constexpr int VBUF = NDT * 32 * VSTR;
+    constexpr int VBUF = NDT * 32 * VSTR2;
     __shared__ __attribute__((aligned(16))) half_t Ksm[2 * KBUF];
     __shared__ __attribute__((aligned(16))) half_t Vsm[2 * VBUF];
 
@@ -133,7 +136,9 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(gl_attn_args p) {
         const int c = idx & 7;         // 8-key chunk
         vok[i] = (idx < V_ITEMS) && (row < d);
         vone[i] = ONES && (idx < V_ITEMS) && (row == OC);
-        vlds[i] = row * VSTR + c * 8;
+        // LDS image of a V^T row: per 16-key group [keys 0-3, 8-11 | keys 4-7, 12-15], i.e. the 8 keys a lane
+        // half feeds to one P.V MFMA k-step are contiguous -> ONE 16-byte read per fragment
+        vlds[i] = row * VSTR2 + 16 * (c >> 1) + 4 * (c & 1);
         vptr[i] = Vg + (size_t)row * p.ldvt + c * 8;
     }
     const size_t kstep = (size_t)KT * p.ldk;
@@ -164,9 +169,9 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(gl_attn_args p) {
 #pragma unroll
         for (int i = 0; i < V_PER_T; ++i)
             if (tid + NTHR * i < V_ITEMS) {
-                uint2* dst = reinterpret_cast<uint2*>(Vsw + vlds[i]);   // 8-byte aligned only
-                dst[0] = make_uint2(rv[i].x, rv[i].y);
-                dst[1] = make_uint2(rv[i].z, rv[i].w);
+                uint2* dst = reinterpret_cast<uint2*>(Vsw + vlds[i]);
+                dst[0] = make_uint2(rv[i].x, rv[i].y);      // keys 8c .. 8c+3  -> lane half 0
+                dst[2] = make_uint2(rv[i].z, rv[i].w);      // keys 8c+4 .. 8c+7 -> lane half 1 (+16 bytes)
             }
     };
 
@@ -184,6 +189,7 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(gl_attn_args p) {
         // ---- S^T = K . Q^T : two 32-key halves, K fragments shared by the QT query sub-tiles
         f32x16 s[QT][2];
         const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
@@ -192,6 +198,7 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(gl_attn_args p) {
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt) s[qt][kh] = mfma32(kf, qf[qt][ks], ks == 0 ? zero16 : s[qt][kh]);
             }
+        if (SETPRIO) __builtin_amdgcn_s_setprio(0);
         // ---- online softmax (this lane: query ql of each sub-tile, keys kh*32 + (r&3) + 8*(r>>2) + 4*hi).
         // VALU-lean form (the first version spent 32 VALU instructions per MFMA): the row max is taken on the
         // raw scores, the softmax scale rides in one FMA with the exp2 argument, pairs are converted with
@@ -247,19 +254,17 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(gl_attn_args p) {
             if constexpr (!ONES) l_run[qt] += psum;
         }
         // ---- O^T += V^T . P^T : k-step j covers keys 16j..16j+15 in the order (e&3) + 8*(e>>2) + 4*hi
+        if (SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) {
-                const half_t* vrow = Vs + (dt * 32 + ql) * VSTR + 16 * j + 4 * hi;
-                const uint2 lo = *reinterpret_cast<const uint2*>(vrow);
-                const uint2 hi8 = *reinterpret_cast<const uint2*>(vrow + 8);
-                uint4 v4 = make_uint4(lo.x, lo.y, hi8.x, hi8.y);
-                const half8_t vf = *reinterpret_cast<half8_t*>(&v4);
+                const half8_t vf = *reinterpret_cast<const half8_t*>(Vs + (dt * 32 + ql) * VSTR2 + 16 * j + 8 * hi);
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt) o[qt][dt] = mfma32(vf, *reinterpret_cast<const half8_t*>(&pf[qt][j]), o[qt][dt]);
             }
         }
+        if (SETPRIO) __builtin_amdgcn_s_setprio(0);
         if (t + 1 < ntiles) store_tile((t + 1) & 1);   // other buffer: last read one iteration ago, before the barrier
         __syncthreads();
     }
@@ -553,7 +558,7 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const half_t* __restri
 template <int DQK, int QT, int NW = 4>
 int launch_attn(const gl_attn_args& a, hipStream_t st) {
     dim3 grid(gl_cdiv(a.Nq, 32 * NW * QT) * a.H * a.B);
-    attn_kernel<DQK, QT, NW><<<grid, dim3(64 * NW), 0, st>>>(a);
+    attn_kernel<DQK, QT, NW><<<grid, dim3(64 * NW), 0, st>>>(a, g_attn_setprio < 0 ? (DQK <= 48 ? 1 : 0) : g_attn_setprio);
     GL_CHECK_LAUNCH();
     return 0;
 }
@@ -599,6 +604,7 @@ extern "C" int gl_attention(const gl_attn_args* a, void* stream) {
 
 extern "C" int gl_set_option_attn(int key, int value) {
     if (key == 3) { g_attn_qt2 = value; return 0; }
+    if (key == 10) { g_attn_setprio = value; return 0; }
     return GL_ERR_BAD_ARG;
 }
 

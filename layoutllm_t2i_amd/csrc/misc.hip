@@ -237,7 +237,7 @@ extern "C" int gl_init_gemm(void);
 extern "C" int gl_set_option_gemm(int key, int value);
 extern "C" int gl_set_option_attn(int key, int value);
 extern "C" int gl_set_option(int key, int value) {
-    return key == 3 ? gl_set_option_attn(key, value) : gl_set_option_gemm(key, value);   // 1,2,4-9: GEMM knobs
+    return (key == 3 || key == 10) ? gl_set_option_attn(key, value) : gl_set_option_gemm(key, value);   // 1,2,4-9: GEMM knobs
 }
 
 extern "C" int gl_abi_version(void) { return GL_ABI_VERSION; }

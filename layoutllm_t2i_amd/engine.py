@@ -103,12 +103,12 @@ class UNetEngine:
             c[f"objs.{li}"] = ops.gemm(objs, W[f"{t}.fuser.linear.w"], self.buf(f"hoist.objs.{li}", (Bn * mo, C)), W[f"{t}.fuser.linear.b"])
             # attn2 K/V of the text context (attention.py:124-125)
             kv = ops.gemm(ctx16, W[f"{t}.attn2.kv.w"], self.buf(f"hoist.kvctx.{li}", (Bn * Lc, 2 * C)))
-            vt = self.buf(f"hoist.vtctx.{li}", (Bn, H, d, _rup(Lc, 64)))
+            vt = self.buf(f"hoist.vtctx.{li}", (Bn, H, d, ops.vt_ld(Lc)))
             ops.transpose_v(kv[:, C:], Lc * 2 * C, 2 * C, vt, Bn, H, d, Lc)
             c[f"kvctx.{li}"], c[f"vtctx.{li}"] = kv, vt
             # rela_fuse K/V of the relation tokens (attention.py:348-349)
             kvr = ops.gemm(rel16, W[f"{t}.rela_fuse.attn.kv.w"], self.buf(f"hoist.kvrel.{li}", (Bn * R, 2 * C)))
-            vtr = self.buf(f"hoist.vtrel.{li}", (Bn, H, d, _rup(R, 64)))
+            vtr = self.buf(f"hoist.vtrel.{li}", (Bn, H, d, ops.vt_ld(R)))
             ops.transpose_v(kvr[:, C:], R * 2 * C, 2 * C, vtr, Bn, H, d, R)
             c[f"kvrel.{li}"], c[f"vtrel.{li}"] = kvr, vtr
         # --- integer rectangles per resolution (host, fp32; attention.py:321-346)
@@ -176,7 +176,7 @@ class UNetEngine:
         """src [Bn*rows_per_b, C] (already normalised) -> attention output [Bn*Nq, C] (before to_out)."""
         Bn, H = self.cond["Bn"], self.cfg.num_heads
         qkv = ops.gemm(src, self.W[wp + ".qkv.w"], self.buf(tagp + ".qkv", (Bn * rows_per_b, 3 * C)))
-        vt = self.buf(tagp + ".vt", (Bn, H, d, _rup(Nk, 64)))
+        vt = self.buf(tagp + ".vt", (Bn, H, d, ops.vt_ld(Nk)))
         ops.transpose_v(qkv[:, 2 * C:], rows_per_b * 3 * C, 3 * C, vt, Bn, H, d, Nk)
         att = self.buf(tagp + ".att", (Bn * Nq, C))
         ops.attention(qkv, rows_per_b * 3 * C, 3 * C, qkv[:, C:], rows_per_b * 3 * C, 3 * C, vt, att, Nq * C, C,

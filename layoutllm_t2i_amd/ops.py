@@ -138,6 +138,14 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, B: int, Hin: in
     return out
 
 
+def vt_ld(Nk: int) -> int:
+    """Row stride (keys) for a V^T buffer: Nk rounded up to the 64-key tile, plus one tile when that is a multiple of
+    512 keys -- a 1 KiB-multiple row stride maps the d rows of every V^T tile onto the same L1 sets / channels
+    (measured 307 vs 277 us at N = 4096, d = 40)."""
+    n = (Nk + 63) // 64 * 64
+    return n + 64 if n % 512 == 0 else n
+
+
 def transpose_v(v: torch.Tensor, v_bstride: int, ldv: int, vt: torch.Tensor, B: int, H: int, d: int, Nk: int):
     """v: fp16 view whose element (b, key, h*d + c) sits at v.data_ptr + b*v_bstride + key*ldv + h*d + c.
     vt: [B, H, d, ldvt] fp16 contiguous, ldvt >= roundup(Nk, 64)."""

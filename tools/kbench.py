@@ -104,7 +104,7 @@ def main():
     init_device()
     if "KB_PIPE" in os.environ:
         ops.set_option(1, int(os.environ["KB_PIPE"]))
-    for k, env in ((4, "KB_SMALL"), (5, "KB_SKT"), (6, "KB_SKNK"), (7, "KB_BIG"), (8, "KB_GEGLU32"), (9, "KB_BIGKIND")):
+    for k, env in ((4, "KB_SMALL"), (5, "KB_SKT"), (6, "KB_SKNK"), (7, "KB_BIG"), (8, "KB_GEGLU32"), (9, "KB_BIGKIND"), (10, "KB_ATTNPRIO")):
         if env in os.environ:
             ops.set_option(k, int(os.environ[env]))
     if "KB_QT2" in os.environ:
@@ -159,7 +159,7 @@ def main():
             d, Nq, Nk = key[:3]
             H, C = 8, 8 * d
             q, k, v = h(B2, Nq, C), h(B2, Nk, C), h(B2, Nk, C)
-            ldvt = (Nk + 63) // 64 * 64
+            ldvt = ops.vt_ld(Nk) if not os.environ.get("KB_VTPOW2") else (Nk + 63) // 64 * 64
             vt = torch.empty(B2, H, d, ldvt, dtype=torch.float16, device=DEV)
             ops.transpose_v(v, Nk * C, C, vt, B2, H, d, Nk)
             out = torch.empty(B2, Nq, C, dtype=torch.float16, device=DEV)
