@@ -137,14 +137,33 @@ def get_clip_feature(model, processor, input, device, is_image=False):
     return outputs.text_model_output.pooler_output
 
 
-def _one_sample_grounding(phrases, locations, model, processor, max_objs, device):
+def get_clip_features_batched(model, processor, phrases, device):
+    """Conditioning-prep batching.  The reference calls ``get_clip_feature`` once per phrase,
+    sequentially (interface.py:446-448: B x n_boxes CLIP forwards, each also running the vision tower on a
+    placeholder image).  Here every DISTINCT phrase of the whole batch goes through ONE padded forward; CLIP's
+    text tower is causal and the pooled feature is read at the EOS position, so padding after EOS cannot change
+    it (checked against the per-phrase path in tests/test_host_cpu.py).  Returns {phrase: [1, 768] feature}."""
+    uniq = [p for p in dict.fromkeys(phrases) if p is not None]
+    if not uniq:
+        return {}
+    inputs = processor(text=uniq, return_tensors="pt", padding=True)
+    inputs["input_ids"] = inputs["input_ids"].to(device)
+    inputs["pixel_values"] = torch.ones(1, 3, 224, 224).to(device)       # placeholder, as interface.py:136
+    inputs["attention_mask"] = inputs["attention_mask"].to(device)
+    pooled = model(**inputs).text_model_output.pooler_output
+    return {p: pooled[i:i + 1] for i, p in enumerate(uniq)}
+
+
+def _one_sample_grounding(phrases, locations, model, processor, max_objs, device, feature_cache=None):
     boxes = torch.zeros(max_objs, 4)
     masks = torch.zeros(max_objs)
     text_masks = torch.zeros(max_objs)
     image_masks = torch.zeros(max_objs)
     text_embeddings = torch.zeros(max_objs, 768)
     image_embeddings = torch.zeros(max_objs, 768)
-    feats = [get_clip_feature(model, processor, ph, device, is_image=False) for ph in phrases]
+    if feature_cache is None:
+        feature_cache = get_clip_features_batched(model, processor, phrases, device)
+    feats = [None if ph is None else feature_cache[ph] for ph in phrases]
     for idx, (box, feat) in enumerate(zip(locations, feats)):
         boxes[idx] = torch.tensor(box)
         masks[idx] = 1
@@ -175,8 +194,9 @@ def prepare_batch_multiple(meta, model, processor, batch=1, max_objs=MAX_OBJS, d
     phrases_batch = meta.get("phrases")
     assert batch == len(phrases_batch)
     cols = [[] for _ in range(6)]
+    cache = get_clip_features_batched(model, processor, [ph for phrases in phrases_batch for ph in phrases], device)
     for i, phrases in enumerate(phrases_batch):
-        parts = _one_sample_grounding(phrases, meta["locations"][i], model, processor, max_objs, device)
+        parts = _one_sample_grounding(phrases, meta["locations"][i], model, processor, max_objs, device, cache)
         parts = list(parts)
         parts[2] = parts[2].unsqueeze(0) * complete_mask(meta.get("text_mask"), max_objs)
         parts[3] = parts[3].unsqueeze(0) * complete_mask(meta.get("image_mask"), max_objs)
@@ -188,24 +208,41 @@ def prepare_batch_multiple(meta, model, processor, batch=1, max_objs=MAX_OBJS, d
     return {n: torch.cat(c, dim=0).to(device) for n, c in zip(names, cols)}
 
 
-@torch.no_grad()
-def prepare_relation_phrases(prompt, batch_size=1, max_relas=5, text_encoder=None, device=None):
-    """interface.py:221-252: scene-graph triplets -> CLIP pooled embeddings, 'PAD' first, each relation
-    listed twice, truncated / zero-padded to max_relas."""
+def _relation_phrases(prompt, max_relas):
+    """interface.py:221-240: scene-graph triplets "subject relation object"; 'PAD' first, each relation listed
+    twice, truncated to max_relas.  [] when the prompt has no relation."""
     import sng_parser   # same optional dependency as the reference (interface.py:8)
     graph = sng_parser.parse(prompt)
     entities = graph["entities"]
     triplets = []
     for r in graph.get("relations", []):
         triplets.append(" ".join([entities[r["subject"]]["lemma_head"], r["relation"], entities[r["object"]]["lemma_head"]]))
-    if not triplets:
-        emb = torch.zeros(max_relas, 768)
-    else:
-        relations = (["PAD"] + triplets + triplets)[:max_relas]
-        _, pooled = text_encoder.encode(relations, return_pooler_output=True)
-        emb = torch.zeros(max_relas, 768)
-        emb[:len(relations), :] = pooled
-    return emb.unsqueeze(0).repeat(batch_size, 1, 1).to(device)
+    return (["PAD"] + triplets + triplets)[:max_relas] if triplets else []
+
+
+@torch.no_grad()
+def prepare_relation_phrases_batch(prompts, max_relas=5, text_encoder=None, device=None, parse=_relation_phrases):
+    """One ``text_encoder.encode`` call for the relation phrases of ALL prompts (the reference encodes them prompt
+    by prompt, interface.py:490-496).  FrozenCLIPEmbedder pads every row to 77 tokens (modules.py:159-161), so
+    batching cannot change a row's pooled embedding.  Returns [len(prompts), max_relas, 768], zero-padded."""
+    lists = [parse(p, max_relas) for p in prompts]
+    flat = [ph for l in lists for ph in l]
+    emb = torch.zeros(len(prompts), max_relas, 768)
+    if flat:
+        _, pooled = text_encoder.encode(flat, return_pooler_output=True)
+        pooled = pooled.to(emb.dtype).cpu()
+        k = 0
+        for i, l in enumerate(lists):
+            emb[i, :len(l), :] = pooled[k:k + len(l)]
+            k += len(l)
+    return emb.to(device)
+
+
+@torch.no_grad()
+def prepare_relation_phrases(prompt, batch_size=1, max_relas=5, text_encoder=None, device=None):
+    """interface.py:221-252: one prompt's relation embeddings repeated batch_size times."""
+    emb = prepare_relation_phrases_batch([prompt], max_relas, text_encoder, device)
+    return emb.repeat(batch_size, 1, 1)
 
 
 def _postprocess(samples):
@@ -245,12 +282,12 @@ def _run(all_models, args, meta, starting_noise, clip_model, clip_processor, dev
     if multiple:
         batch = prepare_batch_multiple(meta, clip_model, clip_processor, bs, device=device)
         context = text_encoder.encode(meta["prompts"])
-        relations = torch.cat([prepare_relation_phrases(p, 1, max_rel, text_encoder, device=device) for p in meta["prompts"]], dim=0)
+        relations = prepare_relation_phrases_batch(meta["prompts"], max_rel, text_encoder, device=device)
     else:
         batch = prepare_batch(meta, clip_model, clip_processor, bs, device=device)
         context = text_encoder.encode([meta["prompt"]] * bs)
         relations = prepare_relation_phrases(meta["prompt"], bs, max_rel, text_encoder, device=device)
-    uc = text_encoder.encode(bs * [""])
+    uc = text_encoder.encode([""]).repeat(bs, 1, 1)          # the reference encodes bs copies of "" (interface.py:496)
     samples = denoise(all_models, context, uc, relations, batch, starting_noise, meta.get("alpha_type"), cfg.guidance_scale)
     return _postprocess(autoencoder.decode(samples))
 

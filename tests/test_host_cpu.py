@@ -211,3 +211,92 @@ def test_interface_surface_matches_reference_names():
     m = M()
     I.set_alpha_scale(m, 0)
     assert m.fuser_scale == 0
+
+
+# ---------------------------------------------------------------- conditioning prep batching
+class _ToyProcessor:
+    """whitespace tokenizer with CLIP's conventions: BOS first, EOS = highest id, padded with EOS, mask 0 on pads"""
+    BOS, EOS = 98, 99
+
+    def __call__(self, text, return_tensors="pt", padding=True):
+        import torch
+        if isinstance(text, str):
+            text = [text]
+        rows = [[self.BOS] + [1 + (sum(map(ord, w)) % 90) for w in t.split()] + [self.EOS] for t in text]
+        n = max(map(len, rows))
+        ids = torch.tensor([r + [self.EOS] * (n - len(r)) for r in rows])
+        am = torch.tensor([[1] * len(r) + [0] * (n - len(r)) for r in rows])
+        return {"input_ids": ids, "attention_mask": am}
+
+
+def _toy_clip():
+    import torch
+    from transformers import CLIPConfig, CLIPModel
+    torch.manual_seed(0)
+    cfg = CLIPConfig(text_config=dict(hidden_size=768, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                                      vocab_size=100, max_position_embeddings=16, eos_token_id=99, bos_token_id=98,
+                                      pad_token_id=99),
+                     vision_config=dict(hidden_size=32, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2,
+                                        image_size=224, patch_size=112), projection_dim=768)
+    return CLIPModel(cfg).eval()
+
+
+def test_batched_phrase_features_equal_per_phrase_reference_semantics():
+    """prepare_batch_multiple with ONE padded CLIP forward for the whole batch must reproduce the reference's
+    one-forward-per-phrase loop (interface.py:424-475): same boxes / masks, embeddings equal to fp32 rounding."""
+    import torch
+    from layoutllm_t2i_amd import interface as itf
+    model, proc = _toy_clip(), _ToyProcessor()
+    calls = {"n": 0}
+    fwd = model.forward
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return fwd(*a, **k)
+    model.forward = counting
+    meta = {"phrases": [["a red dog", "tree", "a very tall old tree"], ["tree", "sky"]],
+            "locations": [[[0.1, 0.1, 0.5, 0.5], [0.2, 0.3, 0.9, 0.8], [0.0, 0.0, 1.0, 1.0]], [[0.3, 0.3, 0.6, 0.6], [0.0, 0.0, 1.0, 0.4]]]}
+    with torch.no_grad():
+        out = itf.prepare_batch_multiple(meta, model, proc, batch=2, max_objs=30, device="cpu")
+        assert calls["n"] == 1                       # 4 distinct phrases, one forward (reference: 5 forwards)
+        for b, phrases in enumerate(meta["phrases"]):
+            for i, ph in enumerate(phrases):
+                ref = itf.get_clip_feature(model, proc, ph, "cpu")          # the reference's per-phrase call
+                torch.testing.assert_close(out["text_embeddings"][b, i:i + 1], ref, rtol=1e-5, atol=1e-5)
+            n = len(phrases)
+            assert out["masks"][b].tolist() == [1.0] * n + [0.0] * (30 - n)
+            assert out["text_masks"][b].tolist() == [1.0] * n + [0.0] * (30 - n)
+            assert torch.equal(out["boxes"][b, :n], torch.tensor(meta["locations"][b]))
+            assert float(out["text_embeddings"][b, n:].abs().max()) == 0.0
+        assert out["image_masks"].abs().max() == 0 and out["image_embeddings"].abs().max() == 0
+        one = itf.prepare_batch({"phrases": meta["phrases"][0], "locations": meta["locations"][0]}, model, proc, batch=3, device="cpu")
+        torch.testing.assert_close(one["text_embeddings"][2], out["text_embeddings"][0], rtol=1e-5, atol=1e-5)
+
+
+def test_relation_phrases_batched_equals_per_prompt():
+    """all prompts' triplets in one encode call == the reference's prompt-by-prompt encode (interface.py:221-252)"""
+    import torch
+    from layoutllm_t2i_amd import interface as itf
+
+    class Enc:                                   # deterministic stand-in for FrozenCLIPEmbedder.encode
+        calls = 0
+
+        def encode(self, texts, return_pooler_output=False):
+            Enc.calls += 1
+            pooled = torch.stack([torch.full((768,), float(sum(map(ord, t)) % 97)) + torch.arange(768) * 1e-3 for t in texts])
+            z = pooled[:, None, :].repeat(1, 77, 1)
+            return (z, pooled) if return_pooler_output else z
+
+    table = {"a cat on a mat": ["cat on mat"], "nothing here": [], "a dog under a tree near a car": ["dog under tree", "tree near car"]}
+    parse = lambda prompt, max_relas: ((["PAD"] + table[prompt] * 2)[:max_relas] if table[prompt] else [])
+    prompts = list(table)
+    enc = Enc()
+    out = itf.prepare_relation_phrases_batch(prompts, 4, enc, "cpu", parse=parse)
+    assert Enc.calls == 1 and out.shape == (3, 4, 768)
+    for i, p in enumerate(prompts):
+        one = itf.prepare_relation_phrases_batch([p], 4, enc, "cpu", parse=parse)
+        assert torch.equal(out[i], one[0])
+        n = len(parse(p, 4))
+        assert float(out[i, n:].abs().max() if n < 4 else 0.0) == 0.0
+    assert float(out[1].abs().max()) == 0.0                       # no relation -> all-zero rows (interface.py:241-243)
+    assert torch.equal(out[2, 0], out[2, 0]) and out[2, 3, 0] == out[2, 1, 0]   # PAD, r1, r2, r1 (truncated at 4)
