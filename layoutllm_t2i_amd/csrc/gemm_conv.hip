@@ -36,6 +36,7 @@ __device__ uint4 g_zero16[4];
 namespace {
 
 int g_opt_big_kind = 1;     // which 256-row variant g_opt_big selects: 0 = 8 waves BK 64 / 3-stage, 1 = 4 waves BK 32 / 2-stage
+int g_opt_dbg = 0;           // measurement-only loop ablation, see the NST == 2 main loop
 int g_opt_geglu32 = 1;      // 1 = short-K GEGLU GEMMs use the 4-blocks/CU BK 32 variant
 int g_opt_pipe = 0;          // 0 = BK 64 / 2-stage (default, faster), 1 = BK 32 / 3-stage counted-vmcnt pipeline
 int g_opt_big = 0;            // >0: use the 8-wave 256-row / 3-stage kernels when that grid has at least this many tiles
@@ -87,7 +88,7 @@ constexpr int min_waves() {
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, int BKT, int NST>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (min_waves<BM, BN, BKT, NST>())) void gemm_kernel(gl_gemm_args p, ConvGeom cg, int splitk, int kt_per_split) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (min_waves<BM, BN, BKT, NST>())) void gemm_kernel(gl_gemm_args p, ConvGeom cg, int splitk, int kt_per_split, int dbg) {
     constexpr int NTHR = 64 * WAVES_M * WAVES_N;  // 4 waves (256 threads) or 8 waves (512 threads, 256-row tiles)
     constexpr int TM = BM / WAVES_M / 32;
     constexpr int TN = BN / WAVES_N / 32;
@@ -294,13 +295,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (min_waves<BM, BN, BKT, NST
     };
 
     if constexpr (NST == 2) {
+        // dbg (gl_set_option 12, measurement only -- results are garbage): bit 0 skips the MFMA / fragment-read
+        // half of the loop, bit 1 skips the global -> LDS half; isolates which side bounds a shape
         issue_tile(kt_begin, 0);
         wait_vmcnt<0>();
         __syncthreads();
         for (int it = 0; it < nkt; ++it) {
             const int buf = it & 1;
-            if (it + 1 < nkt) issue_tile(kt_begin + it + 1, buf ^ 1);
-            compute_tile(buf);
+            if (it + 1 < nkt && !(dbg & 2)) issue_tile(kt_begin + it + 1, buf ^ 1);
+            if (!(dbg & 1)) compute_tile(buf);
             wait_vmcnt<0>();
             __syncthreads();
         }
@@ -398,12 +401,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (min_waves<BM, BN, BKT, NST
     float* stage = reinterpret_cast<float*>(smem) + wave * (32 * EPS);
     half_t* outp = reinterpret_cast<half_t*>(p.out);
     const bool geglu = (epi == GL_EPI_GEGLU);
+    // one block barrier (every wave is done reading the operand buffers); after it each wave only touches its own
+    // staging slab, and LDS operations of one wave execute in order, so the passes need no further barriers
+    __syncthreads();
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
         const int mbase = m0 + wm * (TM * 32) + mi * 32;
 #pragma unroll
         for (int np = 0; np < NPASS; ++np) {
-            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int ni = np * 2 + t;
@@ -414,7 +421,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (min_waves<BM, BN, BKT, NST
                             make_float4(acc[mi][ni][rg * 4], acc[mi][ni][rg * 4 + 1], acc[mi][ni][rg * 4 + 2], acc[mi][ni][rg * 4 + 3]);
                 }
             }
-            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
             const int nbase = n0 + wn * (TN * 32) + np * 64;   // first (packed) column of this pass
             if (geglu) {
                 // 32 output columns per pass, 8 per lane: 4 lanes per row, 16 rows per sweep
@@ -562,7 +570,7 @@ int launch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     const int zs = gl_cdiv(nk, kper);          // slices that actually have work
     dim3 grid(mt * nt, 1, zs);
     constexpr int lds = lds_bytes<BM, BN, BKT, NST, WM * WN>();
-    gemm_kernel<BM, BN, WM, WN, CONV, BKT, NST><<<grid, dim3(64 * WM * WN), lds, st>>>(g, cg, zs, kper);
+    gemm_kernel<BM, BN, WM, WN, CONV, BKT, NST><<<grid, dim3(64 * WM * WN), lds, st>>>(g, cg, zs, kper, g_opt_dbg);
     GL_CHECK_LAUNCH();
     if (zs > 1) {
         const size_t total = (size_t)g.M * (g.N / 4);
@@ -712,6 +720,7 @@ extern "C" int gl_set_option_gemm(int key, int value) {
     if (key == 7) { g_opt_big = value; return 0; }
     if (key == 8) { g_opt_geglu32 = value; return 0; }
     if (key == 9) { g_opt_big_kind = value; return 0; }
+    if (key == 12) { g_opt_dbg = value; return 0; }
     if (key == 5) { g_opt_splitk_tiles = value; g_opt_splitk_tiles_conv = value; return 0; }
     if (key == 6) { g_opt_splitk_nk = value; return 0; }
     return GL_ERR_BAD_ARG;
