@@ -39,7 +39,7 @@ int g_opt_big_kind = 1;     // which 256-row variant g_opt_big selects: 0 = 8 wa
 int g_opt_dbg = 0;           // measurement-only loop ablation, see the NST == 2 main loop
 int g_opt_geglu32 = 1;      // 1 = short-K GEGLU GEMMs use the 4-blocks/CU BK 32 variant
 int g_opt_pipe = 0;          // 0 = BK 64 / 2-stage (default, faster), 1 = BK 32 / 3-stage counted-vmcnt pipeline
-int g_opt_big = 0;            // >0: use the 8-wave 256-row / 3-stage kernels when that grid has at least this many tiles
+int g_opt_big = 300;          // problems with >= this many 256-row tiles use the 256-row variant (B=4: neutral; B=16: +5-7 %); 0 = off
 int g_opt_small = 400;       // use 64x128 tiles when the 128-row grid has fewer tiles than this (0 = never)
 int g_opt_splitk_tiles = 300; // split K only below this many tiles (plain GEMM) ...
 int g_opt_splitk_tiles_conv = 450; // ... (conv)

@@ -145,7 +145,7 @@ def test_gemm_conv_256row_variants(kind):
         test_conv3x3("up", 64, 128, 8)
         test_conv3x3_epilogues()
     finally:
-        ops.set_option(7, 0)
+        ops.set_option(7, 300)      # library defaults
         ops.set_option(9, 1)
 
 
