@@ -207,3 +207,36 @@ def test_full_width_level_vs_oracle(name, cfg, hw, B):
     assert r < 6e-3, r
     del model
     torch.cuda.empty_cache()
+
+
+def test_full_unet_config2_vs_oracle():
+    """The WHOLE config-2 UNet (1.26 B parameters, 64x64 latent, 8 boxes, fuser on) against the oracle evaluated on
+    the host CPU with the same weights: (a) oracle with fp16-rounded matrices (isolates arithmetic error), (b) the
+    unrounded fp32 weights (what a user sees against the fp32 reference, weight quantisation included)."""
+    from layoutllm_t2i_amd.weights import random_state_dict
+    cfg = UNetConfig()
+    sd = random_state_dict(cfg, torch.device(DEV), seed=3)
+    model = UNetModel(cfg, sd, device=DEV)
+    sd_cpu = {k: v.detach().float().cpu() for k, v in sd.items()}
+    del sd
+    torch.cuda.empty_cache()
+    B, hw = 1, 64
+    inp = cond_inputs(cfg, B, hw, n_boxes=8)
+    eng = model.engine
+    eng.set_conditioning(inp["context"], inp["relations"], inp["boxes"], inp["masks"], inp["positive_embeddings"], hw)
+    out = eng.forward(inp["x"].to(DEV), 481.0, 1.0, False, 1).clone()
+    t = torch.full((B,), 481, dtype=torch.long)
+    torch.set_num_threads(min(32, max(1, os.cpu_count() or 1)))
+    with torch.no_grad():
+        sd_h = {k: (v.half().float() if v.dim() >= 2 else v) for k, v in sd_cpu.items()}
+        ref_h = unet_ref.unet_forward(sd_h, cfg, inp["x"].half().float(), t, inp["context"].half().float(),
+                                      inp["relations"].half().float(), inp["boxes"], inp["masks"], inp["positive_embeddings"])
+        del sd_h
+        ref_f = unet_ref.unet_forward(sd_cpu, cfg, inp["x"], t, inp["context"], inp["relations"], inp["boxes"], inp["masks"],
+                                      inp["positive_embeddings"])
+    r_h = report("full_unet_fp16_rounded_weights", out, ref_h)
+    r_f = report("full_unet_fp32_weights", out, ref_f)
+    assert r_h < 5e-3, r_h          # measured 1.68e-3
+    assert r_f < 6e-3, r_f          # measured 1.98e-3
+    del model
+    torch.cuda.empty_cache()
