@@ -259,3 +259,45 @@ def test_full_unet_config2_vs_oracle():
     assert torch.equal(o2[0], o2[1])
     del model
     torch.cuda.empty_cache()
+
+
+def test_full_size_plms_5step_cfg_vs_oracle():
+    """End to end at the full size: 5 PLMS steps (6 guided evaluations = 12 UNet forwards of the 1.26 B model, CFG 7.5,
+    alpha_type [0.3, 0, 0.7] so the fuser is skipped and the SD first conv switched in from step 2 on) through
+    ``denoise`` on the GPU vs the oracle's PLMS loop driving the oracle UNet on the host CPU (about a minute)."""
+    from layoutllm_t2i_amd.weights import random_state_dict
+    cfg = UNetConfig()
+    dev = torch.device(DEV)
+    sd = random_state_dict(cfg, dev, seed=5)
+    fc = {"weight": torch.randn(cfg.model_channels, cfg.in_channels, 3, 3, device=dev) * 0.16, "bias": torch.zeros(cfg.model_channels, device=dev)}
+    model = UNetModel(cfg, sd, device=DEV, sd_first_conv={k: v.cpu().numpy() for k, v in fc.items()})
+    model.grounding_tokenizer_input = GroundingNetInput()
+    sd_cpu = {k: (v.detach().float().cpu().half().float() if v.dim() >= 2 else v.detach().float().cpu()) for k, v in sd.items()}
+    fc_cpu = {k: v.float().cpu().half().float() if v.dim() >= 2 else v.float().cpu() for k, v in fc.items()}
+    del sd
+    torch.cuda.empty_cache()
+    S, guidance, alpha_type, hw = 5, 7.5, [0.3, 0.0, 0.7], 64
+    inp = cond_inputs(cfg, 1, hw, n_boxes=8, seed=99)
+    batch = dict(boxes=inp["boxes"], masks=inp["masks"], text_embeddings=inp["positive_embeddings"])
+    out = denoise((model, None, None, LatentDiffusion(device=DEV), {}), inp["context"], inp["uc"], inp["relations"], batch,
+                  inp["x"].to(DEV), alpha_type, guidance, steps=S).cpu()
+    assert model.first_conv_type == "SD"
+    torch.set_num_threads(min(32, max(1, os.cpu_count() or 1)))
+    z = torch.zeros_like
+    state = dict(sd=False)
+
+    def eps_fn(x, t, i, alpha):
+        if alpha == 0:
+            state["sd"] = True                       # permanent, like restore_first_conv_from_SD (openaimodel.py:393-411)
+        first = fc_cpu if state["sd"] else None
+        with torch.no_grad():
+            e_c = unet_ref.unet_forward(sd_cpu, cfg, x, t, inp["context"], inp["relations"], inp["boxes"], inp["masks"],
+                                        inp["positive_embeddings"], fuser_scale=float(alpha), first_conv=first)
+            e_u = unet_ref.unet_forward(sd_cpu, cfg, x, t, inp["uc"], inp["relations"], z(inp["boxes"]), z(inp["masks"]),
+                                        z(inp["positive_embeddings"]), fuser_scale=float(alpha), first_conv=first)
+        return e_u + guidance * (e_c - e_u)
+    ref = plms_ref.plms_sample(eps_fn, inp["x"], S, alpha_type)
+    r = report("full_size_plms_5step", out, ref)
+    assert r < 1e-2, r              # measured 2.6e-3
+    del model
+    torch.cuda.empty_cache()
