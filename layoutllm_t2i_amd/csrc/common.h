@@ -20,13 +20,16 @@ __device__ __forceinline__ f32x16 mfma32(half8_t a, half8_t b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// v_rcp_f32 (1 ulp) instead of an IEEE division (v_div_scale / v_rcp / 4 FMA / v_div_fmas / v_div_fixup): the result is
+// rounded to fp16 right after, 2^13 times coarser
+__device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float silu_f(float x) { return x * rcp_fast(1.0f + __expf(-x)); }
 // erf via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32-roundoff class and ~3000x below the fp16
 // resolution of the value it feeds): 1 rcp + 1 exp + 7 FMA instead of libm erff's ~50 instructions.  The
 // GEGLU epilogue evaluates 8192 of these per 128x128 tile, which at K = 320 cost as much as the MFMA loop.
 __device__ __forceinline__ float erf_fast(float x) {
     const float ax = fabsf(x);
-    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    const float t = rcp_fast(fmaf(0.3275911f, ax, 1.0f));
     float p = fmaf(1.061405429f, t, -1.453152027f);
     p = fmaf(p, t, 1.421413741f);
     p = fmaf(p, t, -0.284496736f);
