@@ -509,12 +509,27 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(gl_gemm_args p, int 
     half_t* out = reinterpret_cast<half_t*>(p.out);
     float gate = 1.0f;
     if (p.epi == GL_EPI_GATE_RES) gate = p.gate[0];
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const int m = (int)(idx / nq);
-        const int n = (int)(idx - (size_t)m * nq) * 4;
-        float4 a = *reinterpret_cast<const float4*>(ws + (size_t)m * N + n);
-        for (int z = 1; z < splitk; ++z) {
-            const float4 b = *reinterpret_cast<const float4*>(ws + ((size_t)z * M + m) * N + n);
+    const size_t zstride = (size_t)M * N;
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < (unsigned)total; idx += gridDim.x * 256u) {
+        const int m = (int)(idx / (unsigned)nq);
+        const int n = (int)(idx - (unsigned)m * (unsigned)nq) * 4;
+        const float* src = ws + (size_t)m * N + n;
+        float4 a = *reinterpret_cast<const float4*>(src);
+        // slices are added in index order (deterministic); 4 independent loads in flight per step instead of a
+        // load -> wait -> add chain per slice
+        int z = 1;
+        for (; z + 3 < splitk; z += 4) {
+            const float4 b0 = *reinterpret_cast<const float4*>(src + (size_t)z * zstride);
+            const float4 b1 = *reinterpret_cast<const float4*>(src + (size_t)(z + 1) * zstride);
+            const float4 b2 = *reinterpret_cast<const float4*>(src + (size_t)(z + 2) * zstride);
+            const float4 b3 = *reinterpret_cast<const float4*>(src + (size_t)(z + 3) * zstride);
+            a.x += b0.x; a.y += b0.y; a.z += b0.z; a.w += b0.w;
+            a.x += b1.x; a.y += b1.y; a.z += b1.z; a.w += b1.w;
+            a.x += b2.x; a.y += b2.y; a.z += b2.z; a.w += b2.w;
+            a.x += b3.x; a.y += b3.y; a.z += b3.z; a.w += b3.w;
+        }
+        for (; z < splitk; ++z) {
+            const float4 b = *reinterpret_cast<const float4*>(src + (size_t)z * zstride);
             a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
         }
         float v[4] = {a.x, a.y, a.z, a.w};
