@@ -301,3 +301,44 @@ def test_full_size_plms_5step_cfg_vs_oracle():
     assert r < 1e-2, r              # measured 2.6e-3
     del model
     torch.cuda.empty_cache()
+
+
+def test_config3_768px_level_vs_oracle():
+    """configs[2] (768x768 -> 96x96 latent): the level-0 block at N = 9216 tokens, a token count that is not a power
+    of two (72 query slabs of 128, 144 key tiles), one sample, 16 boxes."""
+    cfg = UNetConfig(image_size=96, model_channels=320, channel_mult=(1,), attention_resolutions=(1,), num_res_blocks=1)
+    hw, B = 96, 1
+    sd = recipe.state_dict(cfg, 0)
+    model = UNetModel(cfg, sd, device=DEV)
+    inp = cond_inputs(cfg, B, hw, n_boxes=16)
+    eng = model.engine
+    eng.set_conditioning(inp["context"], inp["relations"], inp["boxes"], inp["masks"], inp["positive_embeddings"], hw)
+    out = eng.forward(inp["x"].to(DEV), 481.0, 1.0, False, 1).clone()
+    t = torch.full((B,), 481, dtype=torch.long)
+    with torch.no_grad():
+        torch.set_num_threads(min(32, max(1, os.cpu_count() or 1)))
+        ref = unet_ref.unet_forward(oracle_sd(sd), cfg, inp["x"].half().float(), t, inp["context"].half().float(),
+                                    inp["relations"].half().float(), inp["boxes"], inp["masks"], inp["positive_embeddings"])
+    r = report("L0_c320_d40_96x96", out, ref)
+    assert r < 6e-3, r
+    del model
+    torch.cuda.empty_cache()
+
+
+def test_tiny_unet_max_boxes_max_relations_vs_oracle():
+    """Edge of the conditioning ranges: all 30 grounding slots valid and all 10 relation rows non-zero (the reference's
+    max_objs / max_relations), batch of 3 so the samples use different box sets."""
+    model, sd = get_model(TINY)
+    model.first_conv_type = "GLIGEN"
+    B, hw = 3, 16
+    inp = {k: T(v) for k, v in recipe.synth_inputs(TINY, B, hw, n_boxes=30, n_rel=10, seed=77).items()}
+    eng = model.engine
+    eng.set_conditioning(inp["context"], inp["relations"], inp["boxes"], inp["masks"], inp["positive_embeddings"], hw)
+    out = eng.forward(inp["x"].to(DEV), 250.0, 1.0, False, 1).clone()
+    t = torch.full((B,), 250, dtype=torch.long)
+    with torch.no_grad():
+        ref = unet_ref.unet_forward(oracle_sd(sd), TINY, inp["x"].half().float(), t, inp["context"].half().float(),
+                                    inp["relations"].half().float(), inp["boxes"], inp["masks"], inp["positive_embeddings"])
+    r = report("tiny_30boxes_10relations", out, ref)
+    assert float(inp["masks"].sum()) == 90.0
+    assert r < 6e-3, r
