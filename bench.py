@@ -208,6 +208,33 @@ def main():
                 "launches": n_fwd, "avg_launch_ms": round(gpu_ms / max(n_fwd, 1), 3),
                 "flops_per_launch": round(flops / max(n_fwd, 1)), "flop_model": "SURVEY 8d minimal (32 F_full + 70 F_off per image)"}
 
+    # ---- the single hottest kernel shape, timed standalone with HIP events on the launch stream: the implicit-GEMM
+    # 3x3 conv 320 -> 320 at the 64x64 level of the 2B batch (gemm_kernel<128,160,4,1,true,64,2>, 7 launches per forward;
+    # that instantiation is the top line of profiles/r1_kernel_stats.csv, where its average covers all conv shapes)
+    if rank == 0 and side == 64 and not args.tiny:
+        from layoutllm_t2i_amd import ops as _o
+        Bn = 2 * B
+        xa = torch.randn(Bn * side * side, 320, device=dev).to(torch.float16)
+        wa = (torch.randn(320, 9 * 320, device=dev) * 0.02).to(torch.float16)   # packed [Cout, Cin/64, 3, 3, 64] flattened
+        oa = torch.empty(Bn * side * side, 320, dtype=torch.float16, device=dev)
+        ba = torch.zeros(320, device=dev)
+        for _ in range(5):
+            _o.conv3x3(xa, wa, oa, Bn, side, side, ba)
+        k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        nrep = 50
+        k0.record()
+        for _ in range(nrep):
+            _o.conv3x3(xa, wa, oa, Bn, side, side, ba)
+        k1.record()
+        sync()
+        k_us = k0.elapsed_time(k1) / nrep * 1e3
+        k_flops = 2.0 * Bn * side * side * 320 * 9 * 320
+        k_tf = k_flops / (k_us * 1e-6) / 1e12
+        roofline["hot_kernel"] = {"kernel": "gemm_kernel<128,160,4,1,true,64,2> as 3x3 conv 320->320 @64x64, 2B=%d" % Bn,
+                                  "avg_us": round(k_us, 1), "flops": k_flops, "achieved": round(k_tf, 1), "unit": "TFLOP/s",
+                                  "frac": round(k_tf / MFMA_PEAK_TFLOPS, 4), "launches_per_forward": 7}
+        del xa, wa, oa
+
     images = args.steps * B * world
     value = images / elapsed
     result = {
