@@ -36,6 +36,7 @@ __device__ uint4 g_zero16[4];
 namespace {
 
 int g_opt_big_kind = 1;     // which 256-row variant g_opt_big selects: 0 = 8 waves BK 64 / 3-stage, 1 = 4 waves BK 32 / 2-stage
+int g_opt_ksplit = 1;        // intra-block K-split variants (64-row wave tiles): 0 off, 1 auto (long K, no split-K), 2 always
 int g_opt_dbg = 0;           // measurement-only loop ablation, see the NST == 2 main loop
 int g_opt_geglu32 = 1;      // 1 = short-K GEGLU GEMMs use the 4-blocks/CU BK 32 variant
 int g_opt_pipe = 0;          // 0 = BK 64 / 2-stage (default, faster), 1 = BK 32 / 3-stage counted-vmcnt pipeline
@@ -79,17 +80,23 @@ constexpr int lds_bytes() {
 
 // occupancy hint: the 3-stage BK=32 128x128 kernel needs 48 KiB of LDS (3 blocks/CU) but ~178 registers;
 // asking for 3 waves/SIMD makes the compiler fit 170 so that the third block is actually resident.
-template <int BM, int BN, int BKT, int NST>
+template <int BM, int BN, int BKT, int NST, int WK = 1>
 constexpr int min_waves() {
+    if (WK > 1) return 2;
     if (BKT != 32) return 1;
     if (BM * BN >= 256 * 128) return NST == 2 ? 2 : 1;
     if (BM * BN <= 128 * 128) return NST == 2 ? 4 : 3;
     return NST == 2 ? 3 : 1;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, int BKT, int NST>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (min_waves<BM, BN, BKT, NST>())) void gemm_kernel(gl_gemm_args p, ConvGeom cg, int splitk, int kt_per_split, int dbg) {
-    constexpr int NTHR = 64 * WAVES_M * WAVES_N;  // 4 waves (256 threads) or 8 waves (512 threads, 256-row tiles)
+// WK = 2: intra-block K split.  The waves form two groups that own the SAME output rows/columns but alternate
+// halves of every K-tile's k-steps, so a wave's tile is twice as tall (64 x BN instead of 32 x BN at 4 waves):
+// (TM + TN) / (TM * TN) LDS fragment reads per MFMA drop from 1.2 to 0.7 (128x160) -- the CU's LDS port, shared by
+// the LDS-DMA writes and the fragment reads, is what bounds the main loop (loop ablation).  The two
+// partial accumulators are exchanged through LDS in the epilogue: each wave ends up finalising 32 rows.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, int BKT, int NST, int WK = 1>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT, NST, WK>())) void gemm_kernel(gl_gemm_args p, ConvGeom cg, int splitk, int kt_per_split, int dbg) {
+    constexpr int NTHR = 64 * WAVES_M * WAVES_N * WK;  // 4 waves (256 threads) or 8 waves (512 threads, 256-row tiles)
     constexpr int TM = BM / WAVES_M / 32;
     constexpr int TN = BN / WAVES_N / 32;
     constexpr int CPR = BKT / 8;                 // 16-byte chunks per tile row (8 or 4)
@@ -98,7 +105,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (min_waves<BM, BN, BKT, NST
     constexpr int APASS = (BM + RPP - 1) / RPP;
     constexpr int BPASS = (BN + RPP - 1) / RPP;
     constexpr int KSTEPS = BKT / 16;
-    static_assert(WAVES_M * WAVES_N == 4 || WAVES_M * WAVES_N == 8, "4 or 8 waves");
+    static_assert(WAVES_M * WAVES_N * WK == 4 || WAVES_M * WAVES_N * WK == 8, "4 or 8 waves");
+    static_assert(WK == 1 || (WK == 2 && TM == 2 && KSTEPS % 2 == 0), "K-split: two groups, two 32-row tiles per wave");
     static_assert(BM % RPW == 0 && BN % RPW == 0, "whole wave instructions");
     static_assert(BKT == 128 || BKT == 64 || BKT == 32, "BK");
 
@@ -109,8 +117,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (min_waves<BM, BN, BKT, NST
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave / WAVES_N;
-    const int wn = wave % WAVES_N;
+    const int wk = wave / (WAVES_M * WAVES_N);          // K group (0 when WK == 1)
+    const int wmn = wave - wk * (WAVES_M * WAVES_N);
+    const int wm = wmn / WAVES_N;
+    const int wn = wmn % WAVES_N;
     const int M = p.M, N = p.N, K = p.K;
     // Tile order: N-tiles fastest (tiles sharing an A panel / the same input pixels are co-scheduled), and
     // an XCD-aware bijective remap of the hardware block id (block b runs on XCD b % 8, each XCD has its own
@@ -145,9 +155,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (min_waves<BM, BN, BKT, NST
     // uniform tap offset + select (conv) per 16-byte LDS-DMA instead of rebuilding 64-bit addresses.
     // Masked rows point at the zero page with a zero increment.
     const half_t* aptr[APASS];       // plain: &A[m][k0 + chunk]   conv: &in[b][oy*stride][ox*stride][chunk]
-    int ainc[APASS];                 // plain: halfs to advance per K-tile (0 for masked rows)
+    unsigned amask = 0u, bmask = 0u; // bit i set <=> pass i stages a real row (its pointer advances by BKT per K-tile)
     unsigned cmask[APASS];           // conv: bit t set <=> filter tap t reads an in-bounds pixel
-    int cb[APASS], coy[APASS], cox[APASS];
+    int cbyx[APASS];                 // conv + upsample: (sample << 20) | (oy << 10) | ox, -1 for masked rows
     const int k_first = kt_begin * BKT;
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
@@ -155,7 +165,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (min_waves<BM, BN, BKT, NST
         const int gc = (skc ^ swz(r)) << 3;
         const int m = m0 + r;
         const bool rowok = (r < BM) && (m < M);
-        aptr[i] = zsrc; ainc[i] = 0; cmask[i] = 0u; cb[i] = -1; coy[i] = 0; cox[i] = 0;
+        aptr[i] = zsrc; cmask[i] = 0u; cbyx[i] = -1;
         if constexpr (CONV) {
             if (rowok) {
                 const int hw = cg.Hout * cg.Wout;
@@ -163,7 +173,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (min_waves<BM, BN, BKT, NST
                 const int rr = m - b * hw;
                 const int oy = rr / cg.Wout;
                 const int ox = rr - oy * cg.Wout;
-                cb[i] = b; coy[i] = oy; cox[i] = ox;
+                cbyx[i] = (b << 20) | (oy << 10) | ox;
                 if (!cg.ups) {
                     unsigned mk = 0u;
 #pragma unroll
@@ -179,12 +189,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (min_waves<BM, BN, BKT, NST
             if (rowok) {
                 if (A2g != nullptr && k_first >= p.ksplit) aptr[i] = A2g + (size_t)m * p.lda2 + (k_first - p.ksplit) + gc;
                 else aptr[i] = Ag + (size_t)m * p.lda + k_first + gc;
-                ainc[i] = BKT;
+                amask |= 1u << i;
             }
         }
     }
     const half_t* bptr[BPASS];
-    int binc[BPASS];
 #pragma unroll
     for (int i = 0; i < BPASS; ++i) {
         const int r = srow + RPP * i;
@@ -192,7 +201,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (min_waves<BM, BN, BKT, NST
         const int n = n0 + r;
         const bool ok = (r < BN) && (n < N);
         bptr[i] = ok ? (Wg + (size_t)n * K + k_first + gc) : zsrc;
-        binc[i] = ok ? BKT : 0;
+        if (ok) bmask |= 1u << i;
     }
 
     // number of LDS-DMA instructions THIS wave issues per tile (passes whose rows exist for this wave)
@@ -228,10 +237,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (min_waves<BM, BN, BKT, NST
                     const int r = srow + RPP * i;
                     const int gc = (skc ^ swz(r)) << 3;
                     const half_t* src = zsrc;
-                    if (cb[i] >= 0) {
-                        const int uy = coy[i] + ky - 1, ux = cox[i] + kx - 1;
+                    if (cbyx[i] >= 0) {
+                        const int uy = ((cbyx[i] >> 10) & 1023) + ky - 1, ux = (cbyx[i] & 1023) + kx - 1;
                         if ((uy >= 0) && (uy < cg.Hout) && (ux >= 0) && (ux < cg.Wout))
-                            src = cg.in + ((size_t)(cb[i] * cg.Hin + (uy >> 1)) * cg.Win + (ux >> 1)) * cg.Cin + ci0 + gc;
+                            src = cg.in + ((size_t)((cbyx[i] >> 20) * cg.Hin + (uy >> 1)) * cg.Win + (ux >> 1)) * cg.Cin + ci0 + gc;
                     }
                     glds16(src, As + (size_t)(buf * BM + RPP * i + wave * RPW) * BKT);
                 }
@@ -250,14 +259,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (min_waves<BM, BN, BKT, NST
             for (int i = 0; i < APASS; ++i) {
                 if (RPP * i + wave * RPW >= BM) continue;
                 glds16(aptr[i], As + (size_t)(buf * BM + RPP * i + wave * RPW) * BKT);
-                aptr[i] += ainc[i];
+                aptr[i] += ((amask >> i) & 1u) ? BKT : 0;
             }
         }
 #pragma unroll
         for (int i = 0; i < BPASS; ++i) {
             if (RPP * i + wave * RPW >= BN) continue;
             glds16(bptr[i], Bs + (size_t)(buf * BN + RPP * i + wave * RPW) * BKT);
-            bptr[i] += binc[i];
+            bptr[i] += ((bmask >> i) & 1u) ? BKT : 0;
         }
     };
 
@@ -274,23 +283,35 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (min_waves<BM, BN, BKT, NST
 
     auto compute_tile = [&](int buf) {
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
+        for (int kq = 0; kq < KSTEPS / WK; ++kq) {
             half8_t xf[TM], wf[TN];
+            const int ks = wk * (KSTEPS / WK) + kq;
             const int c = ks * 2 + fhi;
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi) {
                 const int r = wm * (TM * 32) + mi * 32 + frow;
                 xf[mi] = *reinterpret_cast<const half8_t*>(As + (size_t)(buf * BM + r) * BKT + ((c ^ swz(r)) << 3));
             }
+            if constexpr (WK == 2) {
+                // 160 accumulator registers: keep ONE weight fragment live at a time (each feeds both m-tiles)
 #pragma unroll
-            for (int ni = 0; ni < TN; ++ni) {
-                const int r = wn * (TN * 32) + ni * 32 + frow;
-                wf[ni] = *reinterpret_cast<const half8_t*>(Bs + (size_t)(buf * BN + r) * BKT + ((c ^ swz(r)) << 3));
+                for (int ni = 0; ni < TN; ++ni) {
+                    const int r = wn * (TN * 32) + ni * 32 + frow;
+                    wf[0] = *reinterpret_cast<const half8_t*>(Bs + (size_t)(buf * BN + r) * BKT + ((c ^ swz(r)) << 3));
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi) acc[mi][ni] = mfma32(wf[0], xf[mi], acc[mi][ni]);
+                }
+            } else {
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) {
+                    const int r = wn * (TN * 32) + ni * 32 + frow;
+                    wf[ni] = *reinterpret_cast<const half8_t*>(Bs + (size_t)(buf * BN + r) * BKT + ((c ^ swz(r)) << 3));
+                }
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = mfma32(wf[ni], xf[mi], acc[mi][ni]);
             }
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = mfma32(wf[ni], xf[mi], acc[mi][ni]);
         }
     };
 
@@ -343,7 +364,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (min_waves<BM, BN, BKT, NST
 
     if (splitk > 1) {
         // split-K slice: raw fp32 partial tile -> workspace[z][m][n]; epilogue happens in splitk_reduce_kernel
-        float* ws = reinterpret_cast<float*>(p.workspace) + (size_t)blockIdx.z * M * N;
+        float* ws = reinterpret_cast<float*>(p.workspace) + (size_t)(blockIdx.z * WK + wk) * M * N;   // K groups = extra slices
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) {
             const int m = m0 + wm * (TM * 32) + mi * 32 + frow;
@@ -369,7 +390,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (min_waves<BM, BN, BKT, NST
     float gate = 1.0f;
     if (epi == GL_EPI_GATE_RES) gate = p.gate[0];
 
-    if (p.out_mode == GL_OUT_F32_NCHW) {
+    if (WK == 1 && p.out_mode == GL_OUT_F32_NCHW) {
         // out conv only (N = 4): lane holds row m = ..+(lane&31) and channels 8*rg + 4*(lane>>5) + {0..3}
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) {
@@ -406,9 +427,42 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (min_waves<BM, BN, BKT, NST
     __syncthreads();
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
+        // K-split: group wk finalises m-tile mi == wk of the shared 64 rows (mi is a compile-time constant after
+        // unrolling; the skip is wave-uniform, and both groups execute the same number of block barriers)
+        if (WK == 2 && mi != wk) continue;
         const int mbase = m0 + wm * (TM * 32) + mi * 32;
 #pragma unroll
         for (int np = 0; np < NPASS; ++np) {
+            if constexpr (WK == 2) {
+                // hand the partner group the half it finalises (my acc[1 - mi]), take its acc[mi] and add: both in
+                // the MFMA register layout, so every lane meets exactly its own elements
+                constexpr int WMN = WAVES_M * WAVES_N;
+                const float* pstage = reinterpret_cast<const float*>(smem) + (wave < WMN ? wave + WMN : wave - WMN) * (32 * EPS);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int ni = np * 2 + t;
+                    if (ni < TN) {
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg)
+                            *reinterpret_cast<float4*>(stage + frow * EPS + t * 32 + 8 * rg + 4 * fhi) =
+                                make_float4(acc[1 - mi][ni][rg * 4], acc[1 - mi][ni][rg * 4 + 1], acc[1 - mi][ni][rg * 4 + 2], acc[1 - mi][ni][rg * 4 + 3]);
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int ni = np * 2 + t;
+                    if (ni < TN) {
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) {
+                            const float4 o4 = *reinterpret_cast<const float4*>(pstage + frow * EPS + t * 32 + 8 * rg + 4 * fhi);
+                            acc[mi][ni][rg * 4] += o4.x; acc[mi][ni][rg * 4 + 1] += o4.y;
+                            acc[mi][ni][rg * 4 + 2] += o4.z; acc[mi][ni][rg * 4 + 3] += o4.w;
+                        }
+                    }
+                }
+                __syncthreads();      // the partner has read my slab: it can be reused as my staging area
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -576,22 +630,24 @@ inline int choose_splitk(const gl_gemm_args& g, int tiles, bool conv) {
     return s < 2 ? 1 : s;
 }
 
-template <int BM, int BN, int WM, int WN, bool CONV, int BKT, int NST>
+template <int BM, int BN, int WM, int WN, bool CONV, int BKT, int NST, int WK = 1>
 int launch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     const int mt = gl_cdiv(g.M, BM), nt = gl_cdiv(g.N, BN);
     const int nk = g.K / BKT;
-    const int splitk = choose_splitk(g, mt * nt, CONV);
+    int splitk = choose_splitk(g, mt * nt, CONV);
+    if (WK > 1)                                  // each K group writes its own partial slice
+        while (splitk > 1 && (int64_t)splitk * WK * g.M * g.N * 4 > g.workspace_bytes) --splitk;
     int kper = gl_cdiv(nk, splitk);
     const int zs = gl_cdiv(nk, kper);          // slices that actually have work
     dim3 grid(mt * nt, 1, zs);
-    constexpr int lds = lds_bytes<BM, BN, BKT, NST, WM * WN>();
-    gemm_kernel<BM, BN, WM, WN, CONV, BKT, NST><<<grid, dim3(64 * WM * WN), lds, st>>>(g, cg, zs, kper, g_opt_dbg);
+    constexpr int lds = lds_bytes<BM, BN, BKT, NST, WM * WN * WK>();
+    gemm_kernel<BM, BN, WM, WN, CONV, BKT, NST, WK><<<grid, dim3(64 * WM * WN * WK), lds, st>>>(g, cg, zs, kper, g_opt_dbg);
     GL_CHECK_LAUNCH();
     if (zs > 1) {
         const size_t total = (size_t)g.M * (g.N / 4);
         int nblk = (int)((total + 255) / 256);
         if (nblk > 2048) nblk = 2048;
-        splitk_reduce_kernel<<<dim3(nblk), dim3(256), 0, st>>>(g, zs);
+        splitk_reduce_kernel<<<dim3(nblk), dim3(256), 0, st>>>(g, zs * WK);
         GL_CHECK_LAUNCH();
     }
     return 0;
@@ -615,6 +671,23 @@ int dispatch_shape(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     if (g_opt_small && !CONV && g.K <= 1280 && shape != 2 && (g.N % 128) == 0) {
         const long t128 = (long)gl_cdiv(g.M, 128) * gl_cdiv(g.N, shape == 1 ? 160 : 128);
         if (t128 < g_opt_small) shape = 3;
+    }
+    // intra-block K-split (64-row wave tiles, 0.7-0.75 LDS fragment reads per MFMA): +13-18 % on long-K problems
+    // that run without split-K slices (convs at the 64x64 / 32x32 levels, K >= 2k GEMMs); its accumulator exchange in
+    // the epilogue costs 5-40 % on short K and its extra partial slices hurt split-K problems, so those stay on the
+    // 4 x (32 x BN) kernels (per-shape A/B in DESIGN.md)
+    if constexpr (BKT == 64 && NST == 2) {
+        if (g_opt_ksplit && g.out_mode == GL_OUT_F16_ROWMAJOR && (shape == 0 || shape == 1)) {
+            const int tiles = gl_cdiv(g.M, 128) * gl_cdiv(g.N, shape == 1 ? 160 : 128);
+            const int nk = g.K / 64;
+            bool use = (g_opt_ksplit == 2);
+            if (g_opt_ksplit == 1 && choose_splitk(g, tiles, CONV) == 1)
+                use = CONV ? (nk >= 40) : (shape == 0 ? nk >= 16 : nk >= 28);
+            if (use) {
+                if (shape == 1) return launch<128, 160, 2, 1, CONV, 64, 2, 2>(g, cg, st);
+                return launch<128, 128, 2, 1, CONV, 64, 2, 2>(g, cg, st);
+            }
+        }
     }
     // deep-prefetch variant for the big level-0 / wide-N problems: 8 waves share a 256-row tile, BK 64 with a
     // 3-stage ring (loads get TWO tile-times to land instead of one) at the same 2 waves/SIMD occupancy
@@ -686,13 +759,13 @@ extern "C" int gl_conv3x3(const gl_conv_args* a, void* stream) {
     return dispatch<true>(g, cg, (hipStream_t)stream);
 }
 
-template <int BM, int BN, int WM, int WN, int BKT, int NST>
+template <int BM, int BN, int WM, int WN, int BKT, int NST, int WK = 1>
 int set_lds_attr() {
     hipError_t e;
-    const int lds = lds_bytes<BM, BN, BKT, NST, WM * WN>();
-    e = hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WM, WN, false, BKT, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const int lds = lds_bytes<BM, BN, BKT, NST, WM * WN * WK>();
+    e = hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WM, WN, false, BKT, NST, WK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WM, WN, true, BKT, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    e = hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WM, WN, true, BKT, NST, WK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
     return 0;
 }
@@ -725,6 +798,8 @@ extern "C" int gl_init_gemm(void) {
     if ((e = set_lds_attr<128, 128, 2, 2, 64, 2>())) return e;
     if ((e = set_lds_attr<128, 160, 4, 1, 64, 2>())) return e;
     if ((e = set_lds_attr<256, 64, 4, 1, 64, 2>())) return e;
+    if ((e = set_lds_attr<128, 160, 2, 1, 64, 2, 2>())) return e;
+    if ((e = set_lds_attr<128, 128, 2, 1, 64, 2, 2>())) return e;
     return 0;
 }
 
@@ -736,6 +811,7 @@ extern "C" int gl_set_option_gemm(int key, int value) {
     if (key == 8) { g_opt_geglu32 = value; return 0; }
     if (key == 9) { g_opt_big_kind = value; return 0; }
     if (key == 12) { g_opt_dbg = value; return 0; }
+    if (key == 13) { g_opt_ksplit = value; return 0; }
     if (key == 5) { g_opt_splitk_tiles = value; g_opt_splitk_tiles_conv = value; return 0; }
     if (key == 6) { g_opt_splitk_nk = value; return 0; }
     return GL_ERR_BAD_ARG;

@@ -149,6 +149,29 @@ def test_gemm_conv_256row_variants(kind):
         ops.set_option(9, 1)
 
 
+def test_gemm_conv_ksplit_variant():
+    """intra-block K-split kernels (gl_set_option(13, 2) forces them everywhere; 1 = the default per-shape rule): 64-row wave tiles, partial accumulators exchanged in the
+    epilogue; includes split-K + K-split (extra workspace slices) and ragged M / N edges"""
+    ops.set_option(13, 2)
+    try:
+        test_gemm_bias(512, 1280, 640)
+        test_gemm_bias(300, 320, 320)
+        test_gemm_bias(240, 512, 832)
+        test_gemm_bias(1024, 960, 320)
+        test_gemm_epilogues()
+        test_gemm_geglu(320)
+        test_gemm_two_source()
+        test_gemm_split_k(512, 1280, 5120, "res")
+        test_gemm_split_k(100, 640, 2048, "rowbias")
+        test_conv3x3("s1", 320, 320, 16)
+        test_conv3x3("s2", 320, 320, 16)
+        test_conv3x3("up", 64, 128, 8)
+        test_conv3x3("s1", 1280, 1280, 8)
+        test_conv3x3_epilogues()
+    finally:
+        ops.set_option(13, 1)
+
+
 @pytest.mark.parametrize("pipe", [1, 3])
 def test_gemm_conv_bk32_variants(pipe):
     """BK 32 pipelines (gl_set_option(1, 1|3)): 3-stage counted-vmcnt and 2-stage / 4 blocks per CU"""
