@@ -362,12 +362,53 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
         __syncthreads();
     }
 
+    // K-split exchange of one 64-column pass (2 MFMA tiles): hand the partner group the half it finalises (my
+    // acc[1 - mi]), take its acc[mi] and add -- both in the MFMA register layout, so every lane meets exactly its own
+    // elements.  Called with compile-time (mi, np) from unrolled loops; two block barriers per call.
+    constexpr int XEPS = 64 + 4;
+    auto kgroup_exchange = [&](const int mi, const int np) __attribute__((always_inline)) {
+        constexpr int WMN = WAVES_M * WAVES_N;
+        float* mine = reinterpret_cast<float*>(smem) + wave * (32 * XEPS);
+        const float* theirs = reinterpret_cast<const float*>(smem) + (wave < WMN ? wave + WMN : wave - WMN) * (32 * XEPS);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int ni = np * 2 + t;
+            if (ni < TN) {
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+                    *reinterpret_cast<float4*>(mine + frow * XEPS + t * 32 + 8 * rg + 4 * fhi) =
+                        make_float4(acc[1 - mi][ni][rg * 4], acc[1 - mi][ni][rg * 4 + 1], acc[1 - mi][ni][rg * 4 + 2], acc[1 - mi][ni][rg * 4 + 3]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int ni = np * 2 + t;
+            if (ni < TN) {
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const float4 o4 = *reinterpret_cast<const float4*>(theirs + frow * XEPS + t * 32 + 8 * rg + 4 * fhi);
+                    acc[mi][ni][rg * 4] += o4.x; acc[mi][ni][rg * 4 + 1] += o4.y;
+                    acc[mi][ni][rg * 4 + 2] += o4.z; acc[mi][ni][rg * 4 + 3] += o4.w;
+                }
+            }
+        }
+        __syncthreads();      // the partner has read my slab: it can be reused (staging area / next pass)
+    };
+
     if (splitk > 1) {
-        // split-K slice: raw fp32 partial tile -> workspace[z][m][n]; epilogue happens in splitk_reduce_kernel
-        float* ws = reinterpret_cast<float*>(p.workspace) + (size_t)(blockIdx.z * WK + wk) * M * N;   // K groups = extra slices
+        // split-K slice: raw fp32 partial tile -> workspace[z][m][n]; epilogue happens in splitk_reduce_kernel.
+        // With K groups the two halves are first combined through LDS, so a block still writes ONE slice.
+        float* ws = reinterpret_cast<float*>(p.workspace) + (size_t)blockIdx.z * M * N;
+        if constexpr (WK == 2) __syncthreads();          // every wave is done reading the operand buffers
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) {
+            if (WK == 2 && mi != wk) continue;           // group wk finalises m-tile wk (wave-uniform, see the epilogue)
             const int m = m0 + wm * (TM * 32) + mi * 32 + frow;
+            if constexpr (WK == 2) {
+#pragma unroll
+                for (int np = 0; np < (TN + 1) / 2; ++np) kgroup_exchange(mi, np);
+            }
             if (m >= M) continue;
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni)
@@ -433,36 +474,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
         const int mbase = m0 + wm * (TM * 32) + mi * 32;
 #pragma unroll
         for (int np = 0; np < NPASS; ++np) {
-            if constexpr (WK == 2) {
-                // hand the partner group the half it finalises (my acc[1 - mi]), take its acc[mi] and add: both in
-                // the MFMA register layout, so every lane meets exactly its own elements
-                constexpr int WMN = WAVES_M * WAVES_N;
-                const float* pstage = reinterpret_cast<const float*>(smem) + (wave < WMN ? wave + WMN : wave - WMN) * (32 * EPS);
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int ni = np * 2 + t;
-                    if (ni < TN) {
-#pragma unroll
-                        for (int rg = 0; rg < 4; ++rg)
-                            *reinterpret_cast<float4*>(stage + frow * EPS + t * 32 + 8 * rg + 4 * fhi) =
-                                make_float4(acc[1 - mi][ni][rg * 4], acc[1 - mi][ni][rg * 4 + 1], acc[1 - mi][ni][rg * 4 + 2], acc[1 - mi][ni][rg * 4 + 3]);
-                    }
-                }
-                __syncthreads();
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int ni = np * 2 + t;
-                    if (ni < TN) {
-#pragma unroll
-                        for (int rg = 0; rg < 4; ++rg) {
-                            const float4 o4 = *reinterpret_cast<const float4*>(pstage + frow * EPS + t * 32 + 8 * rg + 4 * fhi);
-                            acc[mi][ni][rg * 4] += o4.x; acc[mi][ni][rg * 4 + 1] += o4.y;
-                            acc[mi][ni][rg * 4 + 2] += o4.z; acc[mi][ni][rg * 4 + 3] += o4.w;
-                        }
-                    }
-                }
-                __syncthreads();      // the partner has read my slab: it can be reused as my staging area
-            }
+            if constexpr (WK == 2) kgroup_exchange(mi, np);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -635,8 +647,6 @@ int launch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     const int mt = gl_cdiv(g.M, BM), nt = gl_cdiv(g.N, BN);
     const int nk = g.K / BKT;
     int splitk = choose_splitk(g, mt * nt, CONV);
-    if (WK > 1)                                  // each K group writes its own partial slice
-        while (splitk > 1 && (int64_t)splitk * WK * g.M * g.N * 4 > g.workspace_bytes) --splitk;
     int kper = gl_cdiv(nk, splitk);
     const int zs = gl_cdiv(nk, kper);          // slices that actually have work
     dim3 grid(mt * nt, 1, zs);
@@ -647,7 +657,7 @@ int launch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
         const size_t total = (size_t)g.M * (g.N / 4);
         int nblk = (int)((total + 255) / 256);
         if (nblk > 2048) nblk = 2048;
-        splitk_reduce_kernel<<<dim3(nblk), dim3(256), 0, st>>>(g, zs * WK);
+        splitk_reduce_kernel<<<dim3(nblk), dim3(256), 0, st>>>(g, zs);
         GL_CHECK_LAUNCH();
     }
     return 0;
@@ -672,17 +682,15 @@ int dispatch_shape(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
         const long t128 = (long)gl_cdiv(g.M, 128) * gl_cdiv(g.N, shape == 1 ? 160 : 128);
         if (t128 < g_opt_small) shape = 3;
     }
-    // intra-block K-split (64-row wave tiles, 0.7-0.75 LDS fragment reads per MFMA): +13-18 % on long-K problems
-    // that run without split-K slices (convs at the 64x64 / 32x32 levels, K >= 2k GEMMs); its accumulator exchange in
-    // the epilogue costs 5-40 % on short K and its extra partial slices hurt split-K problems, so those stay on the
-    // 4 x (32 x BN) kernels (per-shape A/B in DESIGN.md)
+    // intra-block K-split (64-row wave tiles, 0.7-0.75 LDS fragment reads per MFMA): +7-18 % on every conv of the
+    // UNet (with or without split-K slices: the two K groups are combined in LDS before a partial slice is written)
+    // and on K >= 1-2k GEMMs; its accumulator exchange in the epilogue costs 5-40 % on short K (the K = 320 / 640
+    // projections), which stay on the 4 x (32 x BN) kernels (per-shape A/B in DESIGN.md)
     if constexpr (BKT == 64 && NST == 2) {
         if (g_opt_ksplit && g.out_mode == GL_OUT_F16_ROWMAJOR && (shape == 0 || shape == 1)) {
-            const int tiles = gl_cdiv(g.M, 128) * gl_cdiv(g.N, shape == 1 ? 160 : 128);
             const int nk = g.K / 64;
             bool use = (g_opt_ksplit == 2);
-            if (g_opt_ksplit == 1 && choose_splitk(g, tiles, CONV) == 1)
-                use = CONV ? (nk >= 40) : (shape == 0 ? nk >= 16 : nk >= 28);
+            if (g_opt_ksplit == 1) use = CONV ? (nk >= 20) : (nk >= 28 || (nk >= 16 && g.M <= 4096));
             if (use) {
                 if (shape == 1) return launch<128, 160, 2, 1, CONV, 64, 2, 2>(g, cg, st);
                 return launch<128, 128, 2, 1, CONV, 64, 2, 2>(g, cg, st);
