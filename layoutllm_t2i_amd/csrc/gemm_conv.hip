@@ -690,7 +690,8 @@ int dispatch_shape(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
         if (g_opt_ksplit && g.out_mode == GL_OUT_F16_ROWMAJOR && (shape == 0 || shape == 1)) {
             const int nk = g.K / 64;
             bool use = (g_opt_ksplit == 2);
-            if (g_opt_ksplit == 1) use = CONV ? (nk >= 20) : (nk >= 28 || (nk >= 16 && g.M <= 4096));
+            // (128-wide conv tiles only occur in the VAE decoder, M = 0.26-1 M pixels x 128/256 channels: measured 2 % slower)
+            if (g_opt_ksplit == 1) use = CONV ? (shape == 1 && nk >= 20) : (nk >= 28 || (nk >= 16 && g.M <= 4096));
             if (use) {
                 if (shape == 1) return launch<128, 160, 2, 1, CONV, 64, 2, 2>(g, cg, st);
                 return launch<128, 128, 2, 1, CONV, 64, 2, 2>(g, cg, st);
