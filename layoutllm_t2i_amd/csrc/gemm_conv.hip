@@ -362,6 +362,23 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
         __syncthreads();
     }
 
+    // K-split: group wk finalises m-tile wk of the shared 64 rows.  Swap the two m-tiles' accumulators in group 1
+    // (160 v_cndmask, once per tile) so that EVERY wave sends acc[1] and finalises acc[0]: one uniform code path,
+    // block barriers executed convergently.
+    if constexpr (WK == 2) {
+        const bool sw = (wk == 1);
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float a0 = acc[0][ni][r], a1 = acc[1][ni][r];
+                acc[0][ni][r] = sw ? a1 : a0;
+                acc[1][ni][r] = sw ? a0 : a1;
+            }
+    }
+    constexpr int TMF = (WK == 2) ? 1 : TM;       // m-tiles a wave finalises
+    const int mi_off = (WK == 2) ? wk : 0;        // ... starting at this one
+
     // K-split exchange of one 64-column pass (2 MFMA tiles): hand the partner group the half it finalises (my
     // acc[1 - mi]), take its acc[mi] and add -- both in the MFMA register layout, so every lane meets exactly its own
     // elements.  Called with compile-time (mi, np) from unrolled loops; two block barriers per call.
@@ -402,9 +419,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
         float* ws = reinterpret_cast<float*>(p.workspace) + (size_t)blockIdx.z * M * N;
         if constexpr (WK == 2) __syncthreads();          // every wave is done reading the operand buffers
 #pragma unroll
-        for (int mi = 0; mi < TM; ++mi) {
-            if (WK == 2 && mi != wk) continue;           // group wk finalises m-tile wk (wave-uniform, see the epilogue)
-            const int m = m0 + wm * (TM * 32) + mi * 32 + frow;
+        for (int mi = 0; mi < TMF; ++mi) {
+            const int m = m0 + wm * (TM * 32) + (mi + mi_off) * 32 + frow;
             if constexpr (WK == 2) {
 #pragma unroll
                 for (int np = 0; np < (TN + 1) / 2; ++np) kgroup_exchange(mi, np);
@@ -467,11 +483,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
     // staging slab, and LDS operations of one wave execute in order, so the passes need no further barriers
     __syncthreads();
 #pragma unroll
-    for (int mi = 0; mi < TM; ++mi) {
-        // K-split: group wk finalises m-tile mi == wk of the shared 64 rows (mi is a compile-time constant after
-        // unrolling; the skip is wave-uniform, and both groups execute the same number of block barriers)
-        if (WK == 2 && mi != wk) continue;
-        const int mbase = m0 + wm * (TM * 32) + mi * 32;
+    for (int mi = 0; mi < TMF; ++mi) {
+        const int mbase = m0 + wm * (TM * 32) + (mi + mi_off) * 32;
 #pragma unroll
         for (int np = 0; np < NPASS; ++np) {
             if constexpr (WK == 2) kgroup_exchange(mi, np);
@@ -684,14 +697,14 @@ int dispatch_shape(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     }
     // intra-block K-split (64-row wave tiles, 0.7-0.75 LDS fragment reads per MFMA): +7-18 % on every conv of the
     // UNet (with or without split-K slices: the two K groups are combined in LDS before a partial slice is written)
-    // and on K >= 1-2k GEMMs; its accumulator exchange in the epilogue costs 5-40 % on short K (the K = 320 / 640
+    // and on K >= 1024 GEMMs; its accumulator exchange in the epilogue costs 5-20 % on short K (the K = 320 / 640
     // projections), which stay on the 4 x (32 x BN) kernels (per-shape A/B in DESIGN.md)
     if constexpr (BKT == 64 && NST == 2) {
         if (g_opt_ksplit && g.out_mode == GL_OUT_F16_ROWMAJOR && (shape == 0 || shape == 1)) {
             const int nk = g.K / 64;
             bool use = (g_opt_ksplit == 2);
             // (128-wide conv tiles only occur in the VAE decoder, M = 0.26-1 M pixels x 128/256 channels: measured 2 % slower)
-            if (g_opt_ksplit == 1) use = CONV ? (shape == 1 && nk >= 20) : (nk >= 28 || (nk >= 16 && g.M <= 4096));
+            if (g_opt_ksplit == 1) use = CONV ? (shape == 1 && nk >= 20) : (nk >= 16);
             if (use) {
                 if (shape == 1) return launch<128, 160, 2, 1, CONV, 64, 2, 2>(g, cg, st);
                 return launch<128, 128, 2, 1, CONV, 64, 2, 2>(g, cg, st);
