@@ -54,15 +54,8 @@ struct ConvGeom {
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 __device__ __forceinline__ void glds16(const half_t* src, half_t* dst) {
@@ -329,17 +322,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
             __syncthreads();
         }
     } else {
-        // 3-stage ring.  Invariant at the top of iteration `it`: tiles it and it+1 have been requested.
-        // The counted wait leaves the newest tile's loads (my_loads of them, per wave) in flight; loads
-        // retire in issue order, so tile `it` has landed for this wave, and after the barrier for all waves.
-        // The buffer refilled right after the barrier, (it+2) % 3, was last read in iteration it-1, which
-        // every wave has finished before arriving at this barrier.
-        issue_tile(kt_begin, 0);
-        if (nkt > 1) issue_tile(kt_begin + 1, 1);
+        // NST-stage ring (NST = 3 or 4), prefetch distance D = NST - 1 tiles.  Invariant at the top of iteration `it`:
+        // tiles it .. it+D-1 have been requested.  The counted wait leaves the newest D-1 tiles' loads (my_loads each,
+        // per wave) in flight; loads retire in issue order, so tile `it` has landed for this wave, and after the
+        // barrier for all waves.  The buffer refilled right after the barrier, (it+D) % NST, was last read in
+        // iteration it-1, which every wave has finished before arriving at this barrier.
+        constexpr int D = NST - 1;
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+            if (j < nkt) issue_tile(kt_begin + j, j);
         int buf = 0;
         for (int it = 0; it < nkt; ++it) {
-            if (it + 1 < nkt) {
-                switch (my_loads) {
+            if (it + D - 1 < nkt) {
+                switch (my_loads * (D - 1)) {
                     case 2: wait_vmcnt<2>(); break;
                     case 3: wait_vmcnt<3>(); break;
                     case 4: wait_vmcnt<4>(); break;
@@ -347,17 +342,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
                     case 6: wait_vmcnt<6>(); break;
                     case 7: wait_vmcnt<7>(); break;
                     case 8: wait_vmcnt<8>(); break;
+                    case 10: wait_vmcnt<10>(); break;
+                    case 12: wait_vmcnt<12>(); break;
+                    case 14: wait_vmcnt<14>(); break;
+                    case 16: wait_vmcnt<16>(); break;
+                    case 18: wait_vmcnt<18>(); break;
                     default: wait_vmcnt<0>(); break;
                 }
             } else {
-                wait_vmcnt<0>();
+                wait_vmcnt<0>();          // tail: fewer than D-1 younger tiles exist; draining is exact enough
             }
             __builtin_amdgcn_s_barrier();
-            int nbuf = buf + 2;
-            if (nbuf >= 3) nbuf -= 3;
-            if (it + 2 < nkt) issue_tile(kt_begin + it + 2, nbuf);
+            int nbuf = buf + D;
+            if (nbuf >= NST) nbuf -= NST;
+            if (it + D < nkt) issue_tile(kt_begin + it + D, nbuf);
             compute_tile(buf);
-            buf = (buf == 2) ? 0 : buf + 1;
+            buf = (buf == NST - 1) ? 0 : buf + 1;
         }
         __syncthreads();
     }
@@ -746,6 +746,10 @@ int dispatch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     if (g.epi == GL_EPI_ROWBIAS && (g.rowbias == nullptr || g.rows_per_sample <= 0)) return GL_ERR_BAD_ARG;
     if (g_opt_pipe == 1) return dispatch_shape<CONV, 32, 3>(g, cg, st);
     if (g_opt_pipe == 3) return dispatch_shape<CONV, 32, 2>(g, cg, st);
+    if (g_opt_pipe == 4 && g.out_mode == GL_OUT_F16_ROWMAJOR && g.epi != GL_EPI_GEGLU && (g.N % 160) == 0 && g.K >= 1024) {
+        // experiment: K-split tile with BK 32 and a 4-stage ring (3 sub-tiles = 96 K-columns in flight per block)
+        return launch<128, 160, 2, 1, CONV, 32, 4, 2>(g, cg, st);
+    }
     // GEGLU with a short K (levels 0/1: K = 320/640, 5-10 k-tiles) spends a large share of each block in its
     // erf epilogue; BK 32 / 2-stage needs 35 KiB of LDS and 114 registers, so 4 blocks/CU are resident and
     // one block's epilogue overlaps the others' main loops (measured 150 -> 135 us and 109 -> 100 us; long-K
@@ -822,6 +826,7 @@ extern "C" int gl_init_gemm(void) {
     if ((e = set_lds_attr<256, 64, 4, 1, 64, 2>())) return e;
     if ((e = set_lds_attr<128, 160, 2, 1, 64, 2, 2>())) return e;
     if ((e = set_lds_attr<128, 128, 2, 1, 64, 2, 2>())) return e;
+    if ((e = set_lds_attr<128, 160, 2, 1, 32, 4, 2>())) return e;
     return 0;
 }
 
