@@ -206,7 +206,8 @@ int gl_sizeof_attn_args(void);
  * 3 = always 8-wave blocks; 4 = always 4-wave blocks); keys 4-7 = small-tile / split-K / 8-wave thresholds; key 8 = short-K
  * GEGLU GEMMs on the BK 32 / 4-blocks-per-CU variant (1 default, 0 off); key 9 = which 256-row GEMM variant key 7 selects;
  * key 10 = s_setprio around the attention MFMA clusters (-1 auto, 0 off, 1 on); key 11 = LayerNorm rows per wave;
- * key 12 = measurement-only main-loop ablation (results invalid while set); key 13 = intra-block K-split GEMM/conv
+ * key 12 = measurement-only main-loop ablation bits (1 = no MFMA half, 2 = no DMA half: results invalid;
+ * 4 = s_setprio around the MFMA cluster: valid results, measured -1 % GEMM / 0 % conv); key 13 = intra-block K-split GEMM/conv
  * variants (0 off, 1 auto = default, 2 always).
  * Results do not depend on these knobs beyond fp32 summation order in split-K. */
 int gl_set_option(int key, int value);

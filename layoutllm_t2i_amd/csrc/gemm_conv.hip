@@ -275,6 +275,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
     const int fhi = lane >> 5;
 
     auto compute_tile = [&](int buf) {
+        if (dbg & 4) __builtin_amdgcn_s_setprio(1);      // A/B: priority over the co-resident block's DMA issue
 #pragma unroll
         for (int kq = 0; kq < KSTEPS / WK; ++kq) {
             half8_t xf[TM], wf[TN];
@@ -306,6 +307,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
                     for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = mfma32(wf[ni], xf[mi], acc[mi][ni]);
             }
         }
+        if (dbg & 4) __builtin_amdgcn_s_setprio(0);
     };
 
     if constexpr (NST == 2) {
