@@ -208,7 +208,8 @@ int gl_sizeof_attn_args(void);
  * key 10 = s_setprio around the attention MFMA clusters (-1 auto, 0 off, 1 on); key 11 = LayerNorm rows per wave;
  * key 12 = measurement-only main-loop ablation bits (1 = no MFMA half, 2 = no DMA half: results invalid;
  * 4 = s_setprio around the MFMA cluster: valid results, measured -1 % GEMM / 0 % conv); key 13 = intra-block K-split GEMM/conv
- * variants (0 off, 1 auto = default, 2 always).
+ * variants (0 off, 1 auto = default, 2 always); key 14 = halo-resident 3x3 conv kernel (0 off = default, 1 when the
+ * grid has at least key-15 tiles, 2 whenever the geometry allows).
  * Results do not depend on these knobs beyond fp32 summation order in split-K. */
 int gl_set_option(int key, int value);
 /* one-time per-process setup (raises dynamic-LDS limits of the tiled kernels); idempotent */

@@ -36,6 +36,8 @@ __device__ uint4 g_zero16[4];
 namespace {
 
 int g_opt_big_kind = 1;     // which 256-row variant g_opt_big selects: 0 = 8 waves BK 64 / 3-stage, 1 = 4 waves BK 32 / 2-stage
+int g_opt_halo = 0;          // halo-resident conv kernel: 0 off, 1 auto (enough tiles), 2 whenever the geometry allows
+int g_opt_halo_tiles = 64;
 int g_opt_ksplit = 1;        // intra-block K-split variants (64-row wave tiles): 0 off, 1 auto (long K, no split-K), 2 always
 int g_opt_dbg = 0;           // measurement-only loop ablation, see the NST == 2 main loop
 int g_opt_geglu32 = 1;      // 1 = short-K GEGLU GEMMs use the 4-blocks/CU BK 32 variant
@@ -87,7 +89,15 @@ constexpr int min_waves() {
 // (TM + TN) / (TM * TN) LDS fragment reads per MFMA drop from 1.2 to 0.7 (128x160) -- the CU's LDS port, shared by
 // the LDS-DMA writes and the fragment reads, is what bounds the main loop (loop ablation).  The two
 // partial accumulators are exchanged through LDS in the epilogue: each wave ends up finalising 32 rows.
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, int BKT, int NST, int WK = 1>
+//
+// HALO = true (stride-1 3x3 convs whose 256-pixel row tile is a whole number of image rows): instead of one A tile per
+// (channel block, tap) -- nine shifted copies of the same pixels, each fetched from L2 into LDS -- the block keeps ONE
+// input patch per 64-channel block resident in LDS, (rows + 2) x (W + 2) pixels including the zero halo, and the nine
+// taps read their A fragments from it at a shifted pixel offset.  The patch of the next channel block streams in
+// during taps 1..7 (one 64-pixel pass per K-step).  L2 -> LDS traffic per channel block drops from
+// 9 x (256 + 160) to 448 + 9 x 160 rows of 128 B (-50 %), LDS-DMA writes likewise; 8 waves, K-split wave tiles.
+constexpr int PATCH_PX = 448;      // patch rows reserved in LDS: (256/W + 2) * (W + 2) <= 396 for W = 64, 32, 16
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, int BKT, int NST, int WK = 1, bool HALO = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT, NST, WK>())) void gemm_kernel(gl_gemm_args p, ConvGeom cg, int splitk, int kt_per_split, int dbg) {
     constexpr int NTHR = 64 * WAVES_M * WAVES_N * WK;  // 4 waves (256 threads) or 8 waves (512 threads, 256-row tiles)
     constexpr int TM = BM / WAVES_M / 32;
@@ -95,17 +105,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
     constexpr int CPR = BKT / 8;                 // 16-byte chunks per tile row (8 or 4)
     constexpr int RPP = NTHR / CPR;              // tile rows covered by one pass of the block's threads
     constexpr int RPW = 64 / CPR;                // tile rows covered by one wave instruction (1 KiB)
-    constexpr int APASS = (BM + RPP - 1) / RPP;
+    constexpr int APASS = HALO ? PATCH_PX / RPP : (BM + RPP - 1) / RPP;
     constexpr int BPASS = (BN + RPP - 1) / RPP;
     constexpr int KSTEPS = BKT / 16;
     static_assert(WAVES_M * WAVES_N * WK == 4 || WAVES_M * WAVES_N * WK == 8, "4 or 8 waves");
     static_assert(WK == 1 || (WK == 2 && TM == 2 && KSTEPS % 2 == 0), "K-split: two groups, two 32-row tiles per wave");
     static_assert(BM % RPW == 0 && BN % RPW == 0, "whole wave instructions");
     static_assert(BKT == 128 || BKT == 64 || BKT == 32, "BK");
+    static_assert(!HALO || (CONV && WK == 2 && BM == 256 && BKT == 64 && NST == 2 && NTHR == 512), "halo conv geometry");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     half_t* As = reinterpret_cast<half_t*>(smem);   // [NST][BM][BKT]
-    half_t* Bs = As + NST * BM * BKT;               // [NST][BN][BKT]
+    half_t* Bs = As + (HALO ? 2 * PATCH_PX : NST * BM) * BKT;   // [NST][BN][BKT]; HALO: As = [2][PATCH_PX][64]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -159,7 +170,20 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
         const int m = m0 + r;
         const bool rowok = (r < BM) && (m < M);
         aptr[i] = zsrc; cmask[i] = 0u; cbyx[i] = -1;
-        if constexpr (CONV) {
+        if constexpr (HALO) {
+            // pass i stages patch pixels 64 i .. 64 i + 63 (this thread: pixel r, 16-byte chunk skc of its 64 channels)
+            const int hw = cg.Hin * cg.Win;
+            const int b = m0 / hw;
+            const int oy0 = (m0 - b * hw) / cg.Win;
+            const int pw = cg.Win + 2;
+            const int py = r / pw;
+            const int px = r - py * pw;
+            const int iy = oy0 + py - 1, ix = px - 1;
+            if (r < (BM / cg.Win + 2) * pw && iy >= 0 && iy < cg.Hin && ix >= 0 && ix < cg.Win) {
+                aptr[i] = cg.in + ((size_t)(b * cg.Hin + iy) * cg.Win + ix) * cg.Cin + gc;
+                amask |= 1u << i;
+            }
+        } else if constexpr (CONV) {
             if (rowok) {
                 const int hw = cg.Hout * cg.Wout;
                 const int b = m / hw;
@@ -215,7 +239,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
             const int ci0 = (cblk << 6) + (k0 & 63);
             const int ky = tap / 3;
             const int kx = tap - ky * 3;
-            if (!cg.ups) {
+            if constexpr (HALO) {
+                // with the W tile of (cblk, tap) goes patch pass tap-1 of channel block cblk+1 (taps 1..7): its buffer,
+                // (cblk+1) & 1, was last read while (cblk-1, 8) was computed, one barrier before (cblk, 1) is issued
+                if (tap >= 1 && tap <= APASS && (cblk + 1) * 9 < kt_end) {
+                    half_t* dst = As + (size_t)(((cblk + 1) & 1) * PATCH_PX + wave * RPW) * BKT;
+                    const int coff = (cblk + 1) << 6;
+#pragma unroll
+                    for (int i = 0; i < APASS; ++i)
+                        if (i == tap - 1)
+                            glds16(((amask >> i) & 1u) ? aptr[i] + coff : zsrc, dst + (size_t)(RPP * i) * BKT);
+                }
+            } else if (!cg.ups) {
                 const int off = ((ky - 1) * cg.Win + (kx - 1)) * cg.Cin + ci0;    // wave-uniform
 #pragma unroll
                 for (int i = 0; i < APASS; ++i) {
@@ -274,7 +309,25 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
     const int frow = lane & 31;
     const int fhi = lane >> 5;
 
-    auto compute_tile = [&](int buf) {
+    // HALO: patch row of output pixel q = wm*64 + mi*32 + frow at tap (0,0): (q / W) * (W + 2) + q % W
+    int prow0[TM];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        prow0[mi] = 0;
+        if constexpr (HALO) {
+            const int q = wm * (TM * 32) + mi * 32 + frow;
+            const int dy = q / cg.Win;
+            prow0[mi] = dy * (cg.Win + 2) + (q - dy * cg.Win);
+        }
+    }
+    auto compute_tile = [&](int buf, int kt) {
+        int abase = 0;                                   // HALO: first LDS row of this tile's A operand
+        if constexpr (HALO) {
+            const int cblk = kt / 9;
+            const int tap = kt - cblk * 9;
+            const int ky = tap / 3;
+            abase = (cblk & 1) * PATCH_PX + ky * (cg.Win + 2) + (tap - ky * 3);
+        }
         if (dbg & 4) __builtin_amdgcn_s_setprio(1);      // A/B: priority over the co-resident block's DMA issue
 #pragma unroll
         for (int kq = 0; kq < KSTEPS / WK; ++kq) {
@@ -283,8 +336,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
             const int c = ks * 2 + fhi;
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi) {
-                const int r = wm * (TM * 32) + mi * 32 + frow;
-                xf[mi] = *reinterpret_cast<const half8_t*>(As + (size_t)(buf * BM + r) * BKT + ((c ^ swz(r)) << 3));
+                if constexpr (HALO) {
+                    const int r = abase + prow0[mi];     // swizzle follows the LDS row, i.e. the patch pixel
+                    xf[mi] = *reinterpret_cast<const half8_t*>(As + (size_t)r * BKT + ((c ^ swz(r)) << 3));
+                } else {
+                    const int r = wm * (TM * 32) + mi * 32 + frow;
+                    xf[mi] = *reinterpret_cast<const half8_t*>(As + (size_t)(buf * BM + r) * BKT + ((c ^ swz(r)) << 3));
+                }
             }
             if constexpr (WK == 2) {
                 // 160 accumulator registers: keep ONE weight fragment live at a time (each feeds both m-tiles)
@@ -313,13 +371,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
     if constexpr (NST == 2) {
         // dbg (gl_set_option 12, measurement only -- results are garbage): bit 0 skips the MFMA / fragment-read
         // half of the loop, bit 1 skips the global -> LDS half; isolates which side bounds a shape
+        if constexpr (HALO) {
+            // whole patch of the first channel block of this K range
+            const int cb0 = kt_begin / 9;
+#pragma unroll
+            for (int i = 0; i < APASS; ++i)
+                glds16(((amask >> i) & 1u) ? aptr[i] + (cb0 << 6) : zsrc,
+                       As + (size_t)((cb0 & 1) * PATCH_PX + RPP * i + wave * RPW) * BKT);
+        }
         issue_tile(kt_begin, 0);
         wait_vmcnt<0>();
         __syncthreads();
         for (int it = 0; it < nkt; ++it) {
             const int buf = it & 1;
             if (it + 1 < nkt && !(dbg & 2)) issue_tile(kt_begin + it + 1, buf ^ 1);
-            if (!(dbg & 1)) compute_tile(buf);
+            if (!(dbg & 1)) compute_tile(buf, kt_begin + it);
             wait_vmcnt<0>();
             __syncthreads();
         }
@@ -358,7 +424,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
             int nbuf = buf + D;
             if (nbuf >= NST) nbuf -= NST;
             if (it + D < nkt) issue_tile(kt_begin + it + D, nbuf);
-            compute_tile(buf);
+            compute_tile(buf, kt_begin + it);
             buf = (buf == NST - 1) ? 0 : buf + 1;
         }
         __syncthreads();
@@ -678,6 +744,38 @@ int launch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     return 0;
 }
 
+// halo-resident 3x3 conv (see gemm_kernel, HALO): 256-pixel row tiles, 8 waves, one block per CU
+constexpr int lds_bytes_halo(int bn) { return (2 * PATCH_PX + 2 * bn) * 64 * (int)sizeof(half_t); }
+
+inline bool halo_conv_ok(const gl_gemm_args& g, const ConvGeom& cg) {
+    const int hw = cg.Hin * cg.Win;
+    return cg.stride == 1 && !cg.ups && cg.Hin == cg.Hout && cg.Win == cg.Wout && cg.Win >= 16 && (256 % cg.Win) == 0 &&
+           (hw % 256) == 0 && (256 / cg.Win + 2) * (cg.Win + 2) <= PATCH_PX && (cg.Cin % 64) == 0 && (g.N % 160) == 0 &&
+           g.out_mode == GL_OUT_F16_ROWMAJOR && g.epi != GL_EPI_GEGLU;
+}
+
+int launch_halo(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
+    constexpr int BN = 160;
+    const int mt = g.M / 256, nt = gl_cdiv(g.N, BN);
+    const int ncb = cg.Cin / 64;                       // K-tiles come in groups of 9 taps per 64-channel block
+    gl_gemm_args gk = g;
+    int splitk = choose_splitk(gk, mt * nt, true);
+    if (splitk > ncb) splitk = ncb;
+    const int cb_per = gl_cdiv(ncb, splitk);
+    const int zs = gl_cdiv(ncb, cb_per);
+    dim3 grid(mt * nt, 1, zs);
+    gemm_kernel<256, BN, 4, 1, true, 64, 2, 2, true><<<grid, dim3(512), lds_bytes_halo(BN), st>>>(g, cg, zs, 9 * cb_per, g_opt_dbg);
+    GL_CHECK_LAUNCH();
+    if (zs > 1) {
+        const size_t total = (size_t)g.M * (g.N / 4);
+        int nblk = (int)((total + 255) / 256);
+        if (nblk > 2048) nblk = 2048;
+        splitk_reduce_kernel<<<dim3(nblk), dim3(256), 0, st>>>(g, zs);
+        GL_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
 template <bool CONV, int BKT, int NST>
 int dispatch_shape(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     // tile shape: 128x160 (4 waves x 32x160) when it divides N exactly -- N = 320/640/960/... are the
@@ -746,6 +844,10 @@ int dispatch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     if ((g.epi == GL_EPI_RES || g.epi == GL_EPI_GATE_RES) && g.res == nullptr) return GL_ERR_BAD_ARG;
     if (g.epi == GL_EPI_GATE_RES && g.gate == nullptr) return GL_ERR_BAD_ARG;
     if (g.epi == GL_EPI_ROWBIAS && (g.rowbias == nullptr || g.rows_per_sample <= 0)) return GL_ERR_BAD_ARG;
+    if constexpr (CONV) {
+        if (g_opt_halo && halo_conv_ok(g, cg) && (g_opt_halo == 2 || (g.M / 256) * gl_cdiv(g.N, 160) >= g_opt_halo_tiles))
+            return launch_halo(g, cg, st);
+    }
     if (g_opt_pipe == 1) return dispatch_shape<CONV, 32, 3>(g, cg, st);
     if (g_opt_pipe == 3) return dispatch_shape<CONV, 32, 2>(g, cg, st);
     if (g_opt_pipe == 4 && g.out_mode == GL_OUT_F16_ROWMAJOR && g.epi != GL_EPI_GEGLU && (g.N % 160) == 0 && g.K >= 1024) {
@@ -829,6 +931,11 @@ extern "C" int gl_init_gemm(void) {
     if ((e = set_lds_attr<128, 160, 2, 1, 64, 2, 2>())) return e;
     if ((e = set_lds_attr<128, 128, 2, 1, 64, 2, 2>())) return e;
     if ((e = set_lds_attr<128, 160, 2, 1, 32, 4, 2>())) return e;
+    {
+        hipError_t he = hipFuncSetAttribute((const void*)gemm_kernel<256, 160, 4, 1, true, 64, 2, 2, true>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes_halo(160));
+        if (he != hipSuccess) return (int)he;
+    }
     return 0;
 }
 
@@ -841,6 +948,8 @@ extern "C" int gl_set_option_gemm(int key, int value) {
     if (key == 9) { g_opt_big_kind = value; return 0; }
     if (key == 12) { g_opt_dbg = value; return 0; }
     if (key == 13) { g_opt_ksplit = value; return 0; }
+    if (key == 14) { g_opt_halo = value; return 0; }
+    if (key == 15) { g_opt_halo_tiles = value; return 0; }
     if (key == 5) { g_opt_splitk_tiles = value; g_opt_splitk_tiles_conv = value; return 0; }
     if (key == 6) { g_opt_splitk_nk = value; return 0; }
     return GL_ERR_BAD_ARG;

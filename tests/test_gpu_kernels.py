@@ -239,6 +239,29 @@ def test_conv3x3(mode, Cin, Cout, hw):
     check(out, _nhwc(ref), f"conv_{mode}_{Cin}_{Cout}_{hw}")
 
 
+@pytest.mark.parametrize("Cin,Cout,hw,B", [(320, 320, 16, 2), (64, 320, 32, 1), (640, 320, 64, 1), (1280, 1280, 16, 2), (1920, 640, 32, 2)])
+def test_conv3x3_halo_variant(Cin, Cout, hw, B):
+    """halo-resident conv kernel (gl_set_option(14, 2)): one LDS patch per 64-channel block feeds the nine taps.
+    Rows of 16 / 32 / 64 pixels (16, 8, 4 image rows per 256-pixel tile), image borders, several channel blocks,
+    and the split-K path over channel-block ranges (1280 -> 1280 at 16x16 launches few tiles)."""
+    ops.set_option(14, 2)
+    try:
+        x, _ = h16(rnd(f"hx{Cin}{hw}", (B, Cin, hw, hw)))
+        w, _ = h16(rnd(f"hw{Cin}{Cout}", (Cout, Cin, 3, 3), 1 / math.sqrt(9 * Cin)))
+        b = rnd(f"hb{Cout}", (Cout,), 0.1)
+        r, rd = h16(rnd(f"hr{Cout}{hw}", (B * hw * hw, Cout)))
+        xd = _nhwc(x).to(torch.float16).to(DEV)
+        wd = pack_conv3x3(w).to(DEV)
+        ref = _nhwc(F.conv2d(x, w, b, padding=1))
+        out = torch.empty(B * hw * hw, Cout, dtype=torch.float16, device=DEV)
+        ops.conv3x3(xd, wd, out, B, hw, hw, b.to(DEV))
+        check(out, ref, f"conv_halo_{Cin}_{Cout}_{hw}")
+        ops.conv3x3(xd, wd, out, B, hw, hw, b.to(DEV), epi=EPI_RES, res=rd)
+        check(out, ref + r, f"conv_halo_res_{Cin}_{Cout}_{hw}")
+    finally:
+        ops.set_option(14, 0)
+
+
 def test_conv3x3_first_and_last():
     """first conv (4 channels zero-padded to 64) and the out conv (Cout = 4, fp32 NCHW store)."""
     B, hw, mc = 2, 16, 64
