@@ -107,7 +107,8 @@ typedef struct gl_attn_args {
 } gl_attn_args;
 
 /* gl_transpose_v: V [B, Nk, *] (row stride ldv, head h at column h*d) -> vt [B, H, d, ldvt], zero-fills keys
- * [Nk, ldvt).  Layout glue for gl_attention's P.V MFMA operand. */
+ * [Nk, ldvt).  Layout glue for gl_attention's P.V MFMA operand.  d, ldv, ldvt, v_bstride multiples of 8 (16-byte
+ * accesses), v and vt 16-byte aligned. */
 int gl_transpose_v(const void* v, int64_t v_bstride, int32_t ldv, void* vt, int32_t ldvt,
                    int32_t B, int32_t H, int32_t d, int32_t Nk, void* stream);
 

@@ -530,28 +530,38 @@ __global__ __launch_bounds__(256) void attn_pipe_kernel(gl_attn_args p) {
     }
 }
 
-// V [B, Nk, *] -> V^T [B, H, d, ldvt] with zero fill of keys >= Nk.
+// V [B, Nk, *] -> V^T [B, H, d, ldvt] with zero fill of keys >= Nk.  One block per (64 keys, head, sample): 16-byte
+// global loads (8 channels of one key), a [64][d + 2] LDS tile (row stride chosen so that the 8 key groups of one
+// channel column fall on 8 different banks), 16-byte global stores (8 consecutive keys of one channel; 8 lanes
+// cover a 128-byte line of a V^T row).
 __global__ __launch_bounds__(256) void transpose_v_kernel(const half_t* __restrict__ v, int64_t v_bstride, int ldv,
                                                           half_t* __restrict__ vt, int ldvt, int H, int d, int Nk) {
-    __shared__ half_t tile[64 * 162];
+    __shared__ __attribute__((aligned(16))) half_t tile[64 * 162];
     const int key0 = blockIdx.x * 64;
     const int h = blockIdx.y;
     const int b = blockIdx.z;
     const int tstr = d + 2;
+    const int dch = d >> 3;                       // 16-byte chunks per key
     const half_t* src = v + (size_t)b * v_bstride + (size_t)h * d;
-    for (int idx = threadIdx.x; idx < 64 * d; idx += 256) {
-        const int key = idx / d;
-        const int c = idx - key * d;
-        half_t val = (half_t)0.0f;
-        if (key0 + key < Nk) val = src[(size_t)(key0 + key) * ldv + c];
-        tile[key * tstr + c] = val;
+    for (int idx = threadIdx.x; idx < 64 * dch; idx += 256) {
+        const int key = idx / dch;
+        const int ch = idx - key * dch;
+        uint4 raw = make_uint4(0u, 0u, 0u, 0u);
+        if (key0 + key < Nk) raw = ld16(src + (size_t)(key0 + key) * ldv + ch * 8);
+        unsigned* t32 = reinterpret_cast<unsigned*>(tile + key * tstr + ch * 8);      // 4-byte aligned (tstr even)
+        t32[0] = raw.x; t32[1] = raw.y; t32[2] = raw.z; t32[3] = raw.w;
     }
     __syncthreads();
     half_t* dst = vt + (size_t)(b * H + h) * d * ldvt;
-    for (int idx = threadIdx.x; idx < 64 * d; idx += 256) {
-        const int c = idx >> 6;
-        const int key = idx & 63;
-        if (key0 + key < ldvt) dst[(size_t)c * ldvt + key0 + key] = tile[key * tstr + c];
+    for (int idx = threadIdx.x; idx < d * 8; idx += 256) {
+        const int c = idx >> 3;
+        const int kg = idx & 7;
+        if (key0 + kg * 8 < ldvt) {               // ldvt is a multiple of 8: whole 8-key groups
+            half8_t o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = tile[(kg * 8 + j) * tstr + c];
+            st16(dst + (size_t)c * ldvt + key0 + kg * 8, *reinterpret_cast<uint4*>(&o));
+        }
     }
 }
 
@@ -610,7 +620,8 @@ extern "C" int gl_set_option_attn(int key, int value) {
 
 extern "C" int gl_transpose_v(const void* v, int64_t v_bstride, int32_t ldv, void* vt, int32_t ldvt, int32_t B,
                               int32_t H, int32_t d, int32_t Nk, void* stream) {
-    if (!v || !vt || d <= 0 || d > 160 || Nk <= 0 || ldvt < Nk) return GL_ERR_BAD_ARG;
+    if (!v || !vt || d <= 0 || d > 160 || (d % 8) || Nk <= 0 || ldvt < Nk) return GL_ERR_BAD_ARG;
+    if ((ldv % 8) || (ldvt % 8) || (v_bstride % 8)) return GL_ERR_BAD_ARG;        // 16-byte loads / stores
     dim3 grid(gl_cdiv(ldvt, 64), H, B);
     transpose_v_kernel<<<grid, dim3(256), 0, (hipStream_t)stream>>>(
         reinterpret_cast<const half_t*>(v), v_bstride, ldv, reinterpret_cast<half_t*>(vt), ldvt, H, d, Nk);
