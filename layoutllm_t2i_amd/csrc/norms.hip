@@ -290,11 +290,13 @@ void launch_ln(const half_t* x, int ldx, half_t* y, int ldy, const float* gamma,
 }
 
 int g_ln_rpw = 0;   // rows per wave override for A/B (0 = auto)
+int g_gn_ppb = 16;  // GroupNorm apply: pixels per pixel-lane per block (A/B knob 16)
 
 }  // namespace
 
 extern "C" int gl_set_option_norm(int key, int value) {
     if (key == 11) { g_ln_rpw = value; return 0; }
+    if (key == 16) { g_gn_ppb = value > 0 ? value : 16; return 0; }
     return GL_ERR_BAD_ARG;
 }
 
@@ -318,7 +320,7 @@ extern "C" int gl_groupnorm_apply(const void* x1, int32_t C1, const void* x2, in
     // pixels per block: >= 2 pixels per pixel-lane, ~1-2k blocks at the 64x64 level
     const int nvec = C / 8;
     const int nplanes = 256 / (nvec < 256 ? nvec : 256);
-    int ppb = 16 * nplanes;
+    int ppb = g_gn_ppb * nplanes;
     if (ppb < 16) ppb = 16;
     if (ppb > HW) ppb = HW;
     const int nblk = gl_cdiv(HW, ppb);

@@ -104,7 +104,7 @@ def main():
     init_device()
     if "KB_PIPE" in os.environ:
         ops.set_option(1, int(os.environ["KB_PIPE"]))
-    for k, env in ((4, "KB_SMALL"), (5, "KB_SKT"), (6, "KB_SKNK"), (7, "KB_BIG"), (8, "KB_GEGLU32"), (9, "KB_BIGKIND"), (10, "KB_ATTNPRIO"), (11, "KB_LNRPW"), (12, "KB_DBG"), (13, "KB_KSPLIT"), (14, "KB_HALO"), (15, "KB_HALOTILES")):
+    for k, env in ((4, "KB_SMALL"), (5, "KB_SKT"), (6, "KB_SKNK"), (7, "KB_BIG"), (8, "KB_GEGLU32"), (9, "KB_BIGKIND"), (10, "KB_ATTNPRIO"), (11, "KB_LNRPW"), (12, "KB_DBG"), (13, "KB_KSPLIT"), (14, "KB_HALO"), (15, "KB_HALOTILES"), (16, "KB_GNPPB")):
         if env in os.environ:
             ops.set_option(k, int(os.environ[env]))
     if "KB_QT2" in os.environ:
