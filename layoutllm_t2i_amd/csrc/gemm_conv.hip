@@ -800,6 +800,15 @@ int dispatch_shape(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     // and on K >= 1024 GEMMs; its accumulator exchange in the epilogue costs 5-20 % on short K (the K = 320 / 640
     // projections), which stay on the 4 x (32 x BN) kernels (per-shape A/B in DESIGN.md)
     if constexpr (BKT == 64 && NST == 2) {
+        // experiment (key 7 = tile threshold, key 9 = 2): 256-row K-split tile, 8 waves, 3-stage ring -- one block per
+        // CU with TWO K-tiles of loads in flight (106 KB) instead of two blocks with one each (74 KB)
+        if (g_opt_big && g_opt_big_kind == 2 && g.out_mode == GL_OUT_F16_ROWMAJOR && (shape == 0 || shape == 1) && g.M >= 256) {
+            const long t256 = (long)gl_cdiv(g.M, 256) * gl_cdiv(g.N, shape == 1 ? 160 : 128);
+            if (t256 >= g_opt_big) {
+                if (shape == 1) return launch<256, 160, 4, 1, CONV, 64, 3, 2>(g, cg, st);
+                return launch<256, 128, 4, 1, CONV, 64, 3, 2>(g, cg, st);
+            }
+        }
         if (g_opt_ksplit && g.out_mode == GL_OUT_F16_ROWMAJOR && (shape == 0 || shape == 1)) {
             const int nk = g.K / 64;
             bool use = (g_opt_ksplit == 2);
@@ -930,6 +939,8 @@ extern "C" int gl_init_gemm(void) {
     if ((e = set_lds_attr<256, 64, 4, 1, 64, 2>())) return e;
     if ((e = set_lds_attr<128, 160, 2, 1, 64, 2, 2>())) return e;
     if ((e = set_lds_attr<128, 128, 2, 1, 64, 2, 2>())) return e;
+    if ((e = set_lds_attr<256, 160, 4, 1, 64, 3, 2>())) return e;
+    if ((e = set_lds_attr<256, 128, 4, 1, 64, 3, 2>())) return e;
     if ((e = set_lds_attr<128, 160, 2, 1, 32, 4, 2>())) return e;
     {
         hipError_t he = hipFuncSetAttribute((const void*)gemm_kernel<256, 160, 4, 1, true, 64, 2, 2, true>,

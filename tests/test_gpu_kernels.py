@@ -127,10 +127,10 @@ def test_gemm_split_k(M, N, K, epi):
     check(out, ref, f"gemm_splitk_{M}x{N}x{K}_{epi}")
 
 
-@pytest.mark.parametrize("kind", [0, 1])
+@pytest.mark.parametrize("kind", [0, 1, 2])
 def test_gemm_conv_256row_variants(kind):
     """the opt-in 256-row kernels (gl_set_option(7, n); option 9: 0 = 8 waves BK64/3-stage, 1 = 4 waves with
-    64-row wave tiles BK32/2-stage) against the same references"""
+    64-row wave tiles BK32/2-stage, 2 = 8 waves K-split with a 3-stage ring) against the same references"""
     ops.set_option(9, kind)
     ops.set_option(7, 1)
     try:
