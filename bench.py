@@ -226,7 +226,7 @@ def main():
         for _ in range(nrep):
             _o.conv3x3(xa, wa, oa, Bn, side, side, ba)
         k1.record()
-        sync()
+        torch.cuda.synchronize()          # rank-local: no collective here, the other ranks do not run this block
         k_us = k0.elapsed_time(k1) / nrep * 1e3
         k_flops = 2.0 * Bn * side * side * 320 * 9 * 320
         k_tf = k_flops / (k_us * 1e-6) / 1e12
@@ -247,7 +247,7 @@ def main():
                    "parallelism": f"replicas x{world}, one weight broadcast, no per-step collectives"},
         "unet_step_ms": round(gpu_ms / max(n_fwd, 1), 3),
         "vae_decode_ms_per_batch": (round(sum(a.elapsed_time(b) for a, b in vae_events) / max(len(vae_events), 1), 2) if vae_events else None),
-        "step_includes": "PLMS denoise (51 x 2B UNet forward)" + (" + VAE decode to fp32 images" if vae is not None else ""),
+        "step_includes": f"PLMS denoise ({args.plms_steps + 1} x 2B UNet forward)" + (" + VAE decode to fp32 images" if vae is not None else ""),
         "images_per_sec_per_gpu": round(value / world, 4),
         "roofline": roofline,
         "setup_s": round(setup_s, 1),
