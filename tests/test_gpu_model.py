@@ -342,3 +342,21 @@ def test_tiny_unet_max_boxes_max_relations_vs_oracle():
     r = report("tiny_30boxes_10relations", out, ref)
     assert float(inp["masks"].sum()) == 90.0
     assert r < 6e-3, r
+
+
+def test_bench_two_ranks_on_one_gpu_gloo():
+    """bench.py's N > 1 path end to end (rendezvous, weight broadcast, per-rank shards, max-over-ranks timing, the JSON
+    line) with two ranks sharing this GPU over gloo -- every rank must execute the same collectives."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+           "--backend", "gloo", "--plms-steps", "5", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["weight_bytes"] > 2.4e9 and "roofline" in d and "hot_kernel" in d["roofline"]
