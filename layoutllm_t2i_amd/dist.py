@@ -77,7 +77,9 @@ def broadcast_packed(P: Optional[PackedWeights], cfg: UNetConfig, device, src: i
     manifest = box[0]
     if rank != src:
         flat = torch.empty(manifest["total"], dtype=torch.uint8, device=device)
-    dist.broadcast(flat, src=src)           # the one data-path collective of the whole job
+    # the one data-path collective of the whole job; sent as int64 words (the buffer is 256-byte padded) so the element
+    # count of the 2.5 GB buffer stays far below 2^31 whatever the backend's count type
+    dist.broadcast(flat.view(torch.int64) if flat.numel() % 8 == 0 else flat, src=src)
     return unflatten_packed(flat, manifest, cfg, device)
 
 
