@@ -78,6 +78,7 @@ constexpr int lds_bytes() {
 template <int BM, int BN, int BKT, int NST, int WK = 1>
 constexpr int min_waves() {
     if (WK > 1) return 2;
+    if (BM == 128 && BN == 160 && BKT == 32 && NST == 2 && WK == 1) return 2;   // (2-wave 64x160 variant shares this key: needs 2)
     if (BKT != 32) return 1;
     if (BM * BN >= 256 * 128) return NST == 2 ? 2 : 1;
     if (BM * BN <= 128 * 128) return NST == 2 ? 4 : 3;
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
     constexpr int APASS = HALO ? PATCH_PX / RPP : (BM + RPP - 1) / RPP;
     constexpr int BPASS = (BN + RPP - 1) / RPP;
     constexpr int KSTEPS = BKT / 16;
-    static_assert(WAVES_M * WAVES_N * WK == 4 || WAVES_M * WAVES_N * WK == 8, "4 or 8 waves");
+    static_assert(WAVES_M * WAVES_N * WK == 2 || WAVES_M * WAVES_N * WK == 4 || WAVES_M * WAVES_N * WK == 8, "2, 4 or 8 waves");
     static_assert(WK == 1 || (WK == 2 && TM == 2 && KSTEPS % 2 == 0), "K-split: two groups, two 32-row tiles per wave");
     static_assert(BM % RPW == 0 && BN % RPW == 0, "whole wave instructions");
     static_assert(BKT == 128 || BKT == 64 || BKT == 32, "BK");
@@ -865,6 +866,11 @@ int dispatch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     }
     if (g_opt_pipe == 1) return dispatch_shape<CONV, 32, 3>(g, cg, st);
     if (g_opt_pipe == 3) return dispatch_shape<CONV, 32, 2>(g, cg, st);
+    if (g_opt_pipe == 5 && g.out_mode == GL_OUT_F16_ROWMAJOR && g.epi != GL_EPI_GEGLU && (g.N % 160) == 0) {
+        // experiment: 2-wave blocks with 64 x 160 wave tiles (0.7 fragment reads per MFMA WITHOUT a K-split exchange),
+        // BK 32 so that four blocks (8 waves) fit a CU
+        return launch<128, 160, 2, 1, CONV, 32, 2>(g, cg, st);
+    }
     if (g_opt_pipe == 4 && g.out_mode == GL_OUT_F16_ROWMAJOR && g.epi != GL_EPI_GEGLU && (g.N % 160) == 0 && g.K >= 1024) {
         // experiment: K-split tile with BK 32 and a 4-stage ring (3 sub-tiles = 96 K-columns in flight per block)
         return launch<128, 160, 2, 1, CONV, 32, 4, 2>(g, cg, st);
@@ -945,6 +951,7 @@ extern "C" int gl_init_gemm(void) {
     if ((e = set_lds_attr<256, 64, 4, 1, 64, 2>())) return e;
     if ((e = set_lds_attr<128, 160, 2, 1, 64, 2, 2>())) return e;
     if ((e = set_lds_attr<128, 128, 2, 1, 64, 2, 2>())) return e;
+    if ((e = set_lds_attr<128, 160, 2, 1, 32, 2>())) return e;
     if ((e = set_lds_attr_plain<64, 128, 1, 2, 64, 2, 2>())) return e;
     if ((e = set_lds_attr<256, 160, 4, 1, 64, 3, 2>())) return e;
     if ((e = set_lds_attr<256, 128, 4, 1, 64, 3, 2>())) return e;

@@ -172,9 +172,10 @@ def test_gemm_conv_ksplit_variant():
         ops.set_option(13, 1)
 
 
-@pytest.mark.parametrize("pipe", [1, 3])
+@pytest.mark.parametrize("pipe", [1, 3, 4, 5])
 def test_gemm_conv_bk32_variants(pipe):
-    """BK 32 pipelines (gl_set_option(1, 1|3)): 3-stage counted-vmcnt and 2-stage / 4 blocks per CU"""
+    """BK 32 pipelines (gl_set_option(1, 1|3|4|5)): 3-stage counted-vmcnt, 2-stage / 4 blocks per CU, K-split 4-stage
+    ring, 2-wave blocks with 64x160 wave tiles"""
     ops.set_option(1, pipe)
     try:
         test_gemm_bias(512, 1280, 640)
