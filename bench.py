@@ -6,10 +6,14 @@
 
 One "step" = one pass of the hot path over one batch of synthetic input = a complete 50-step PLMS
 denoise (CFG 7.5, alpha_type [0.3,0,0.7] -> 102 UNet evaluations per image, run as 51 evaluations of
-the 2B [cond;uncond] batch) of B=4 latents of 4x64x64 with 8 grounding boxes per image: BASELINE.json
-configs[1] "1xMI355X, 512x512, 50 PLMS steps, batch=4, 8 grounding boxes per image, fp16".
-Weights are random (recipe scaling; no checkpoint exists offline), inputs synthetic and resident in
-HBM before the timed region.  value = images/s over all ranks (weak scaling: 4 images per GPU per step).
+the 2B [cond;uncond] batch) + VAE decode.  ``--config`` picks the workload by SURVEY 8d's numbering:
+   2 (default at N=1)  BASELINE.json configs[1]: 512x512, batch=4/GPU, 8 grounding boxes per image
+   3                   configs[2]: 768x768, batch=2, 16 boxes (long-sequence stress)
+   4 (default at N>1)  configs[3]: 8 images per GPU (global batch 64 on 8 GPUs), config-2 shapes
+   5                   configs[4]: train_rl rollout, batch=16 denoise (+ reward scoring stage)
+--batch/--latent/--boxes/--plms-steps override individual fields; the metric / workload strings always state what
+actually ran.  Weights are random (recipe scaling; no checkpoint exists offline), inputs synthetic and resident in
+HBM before the timed region.  value = images/s over all ranks (weak scaling: fixed images per GPU per step).
 
 Extra objects in the JSON line:
   roofline      whole-UNet-forward MFMA roofline: algorithmic FLOPs of the forwards executed in the
@@ -33,9 +37,9 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
-F_FULL = 1.1477e12      # algorithmic FLOPs / sample-forward, 64x64 latent, fuser on   
-F_OFF = 0.8141e12       # ... with the gated-SA fuser exactly skipped (scale == 0)
 MFMA_PEAK_TFLOPS = 2500.0
+# SURVEY 8d numbering -> (BASELINE.json configs index, images per GPU, latent side, boxes per image)
+CONFIGS = {2: (1, 4, 64, 8), 3: (2, 2, 96, 16), 4: (3, 8, 64, 8), 5: (4, 16, 64, 8)}
 
 
 def parse():
@@ -43,10 +47,14 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=4, help="images per GPU per step (config 2: 4)")
-    ap.add_argument("--latent", type=int, default=64, help="latent side (64 = 512x512)")
+    ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5],
+                    help="workload by SURVEY 8d numbering (0 = auto: 2 at N=1, 4 at N>1)")
+    ap.add_argument("--batch", type=int, default=0, help="override: images per GPU per step")
+    ap.add_argument("--latent", type=int, default=0, help="override: latent side (64 = 512x512, 96 = 768x768)")
     ap.add_argument("--plms-steps", type=int, default=50)
-    ap.add_argument("--boxes", type=int, default=8)
+    ap.add_argument("--boxes", type=int, default=0, help="override: grounding boxes per image")
+    ap.add_argument("--cpu-config1", action="store_true",
+                    help="also run BASELINE configs[0] end to end on the CPU oracle (S=10, 22 forwards, ~2 min)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tiny", action="store_true", help="debug: tiny UNet (not a valid benchmark)")
     ap.add_argument("--no-vae", action="store_true", help="stop at the final latent (exclude the VAE decode stage from the step)")
@@ -88,7 +96,14 @@ def main():
     from layoutllm_t2i_amd.weights import pack_state_dict, random_state_dict, random_vae_state_dict
 
     cfg = TINY if args.tiny else UNetConfig()
-    B, side = args.batch, args.latent
+    cnum = args.config or (2 if world == 1 else 4)
+    cidx, B, side, nbox = CONFIGS[cnum]
+    B, side, nbox = args.batch or B, args.latent or side, args.boxes or nbox
+    args.boxes = nbox
+    overridden = (B, side, nbox) != CONFIGS[cnum][1:] or args.plms_steps != 50 or args.tiny
+    from layoutllm_t2i_amd.flops import unet_forward_flops
+    F_FULL = unet_forward_flops(cfg, side, True)       # algorithmic FLOPs / sample-forward, fuser on   
+    F_OFF = unet_forward_flops(cfg, side, False)       # ... with the gated-SA fuser exactly skipped (scale == 0)
     if args.opt:
         from layoutllm_t2i_amd import ops as _ops
         for kv in args.opt:
@@ -194,19 +209,18 @@ def main():
         gpu_ms += e0.elapsed_time(e1)
         flops += nsamp * (F_FULL if fuser_on else F_OFF)
     n_fwd = len(fwd_events)
-    scale_flops = 1.0 if (side == 64 and not args.tiny) else float("nan")   # F_* are for the 64x64 full model only
-    achieved = flops * scale_flops / (gpu_ms * 1e-3) / 1e12 if gpu_ms > 0 else float("nan")
+    achieved = flops / (gpu_ms * 1e-3) / 1e12 if gpu_ms > 0 else float("nan")
     # HBM traffic per forward launch: measured in separate rocprofv3 --pmc passes (profiles/r1_traffic.json)
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
-    if os.path.exists(tpath) and side == 64 and not args.tiny and B == 4:
+    tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_traffic.json") for r in (2, 1)) if os.path.exists(q)), None)
+    if tpath and side == 64 and not args.tiny and B == 4:
         traffic = round(json.load(open(tpath))["traffic_bytes_per_forward"])
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                "traffic_note": "bytes per forward launch from separate --pmc FETCH_SIZE/WRITE_SIZE passes (2*FETCH + WRITE, profiles/r1_traffic.json)",
-                "launch": "UNet forward of the 2B=8 [cond;uncond] batch (one hipGraph replay)",
+                "traffic_note": "bytes per forward launch from separate --pmc FETCH_SIZE/WRITE_SIZE passes (2*FETCH + WRITE, %s)" % (os.path.relpath(tpath, ROOT) if tpath else None),
+                "launch": "UNet forward of the 2B=%d [cond;uncond] batch (one hipGraph replay)" % (2 * B),
                 "launches": n_fwd, "avg_launch_ms": round(gpu_ms / max(n_fwd, 1), 3),
-                "flops_per_launch": round(flops / max(n_fwd, 1)), "flop_model": "SURVEY 8d minimal (32 F_full + 70 F_off per image)"}
+                "flops_per_launch": round(flops / max(n_fwd, 1)), "flop_model": "SURVEY 8d minimal (32 F_full + 70 F_off per image at S=50; F_full=%.4f, F_off=%.4f TFLOP/sample-forward at this latent)" % (F_FULL / 1e12, F_OFF / 1e12)}
 
     # ---- the single hottest kernel shape, timed standalone with HIP events on the launch stream: the implicit-GEMM
     # 3x3 conv 320 -> 320 at the 64x64 level of the 2B batch (gemm_kernel<128,160,2,1,true,64,2,2>, 7 launches per forward;
@@ -238,11 +252,13 @@ def main():
     images = args.steps * B * world
     value = images / elapsed
     result = {
-        "metric": "512x512 50-step images/sec (PLMS, CFG 7.5, layout-conditioned GLIGEN UNet)",
+        "metric": f"{side * 8}x{side * 8} {args.plms_steps}-step images/sec (PLMS, CFG 7.5, layout-conditioned GLIGEN UNet)",
         "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "fp16 (fp32 accumulate)", "data": "synthetic inputs, random-init weights of the reference architecture",
-        "config": {"workload": f"configs[1]: {side * 8}x{side * 8}, {args.plms_steps} PLMS steps, batch={B}/GPU, {args.boxes} grounding boxes/image, fp16",
+        "config": {"workload": ("custom (flags override the named config): " if overridden else f"configs[{cidx}]: ")
+                   + f"{'TINY debug UNet, ' if args.tiny else ''}{side * 8}x{side * 8}, {args.plms_steps} PLMS steps, batch={B}/GPU, {args.boxes} grounding boxes/image, fp16",
+                   "survey_config": cnum,
                    "images_per_gpu_per_step": B, "unet_forwards_per_image": 2 * (args.plms_steps + 1), "latent": [B, 4, side, side],
                    "parallelism": f"replicas x{world}, one weight broadcast, no per-step collectives"},
         "unet_step_ms": round(gpu_ms / max(n_fwd, 1), 3),
@@ -258,22 +274,74 @@ def main():
 
     # ---- CPU baseline: the oracle on the host cores, bounded sample (rank 0, N=1 only)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and sd_cpu_sample is not None:
-        from oracle import unet_ref
+        from oracle import plms_ref, unet_ref
         cores = min(os.cpu_count() or 1, 32)   # eager torch scales poorly past ~32 threads on this op mix
         torch.set_num_threads(cores)
+        cpu_model = "unknown"
+        try:
+            with open("/proc/cpuinfo") as fcpu:
+                cpu_model = next(l.split(":", 1)[1].strip() for l in fcpu if l.startswith("model name"))
+        except (OSError, StopIteration):
+            pass
         ci = {k: torch.from_numpy(v) for k, v in recipe.synth_inputs(cfg, 1, side, n_boxes=args.boxes, n_rel=3, seed=1234).items()}
+        zz = torch.zeros_like
+
+        def cpu_fwd(x, tt, cond, fuser_scale=1.0):
+            if cond:
+                return unet_ref.unet_forward(sd_cpu_sample, cfg, x, tt, ci["context"], ci["relations"], ci["boxes"], ci["masks"],
+                                             ci["positive_embeddings"], fuser_scale=fuser_scale)
+            return unet_ref.unet_forward(sd_cpu_sample, cfg, x, tt, ci["uc"], ci["relations"], zz(ci["boxes"]), zz(ci["masks"]),
+                                         zz(ci["positive_embeddings"]), fuser_scale=fuser_scale)
         with torch.no_grad():
-            times = []
-            for rep in range(3):                      # bounded sample: 3 conditional forwards (~15 s of CPU work)
+            # bounded sample (~20 s of CPU work): one warm-up + the four forward kinds a sampling step is made of
+            cpu_fwd(ci["x"], torch.tensor([481]), True)
+            kinds, refs = {}, {}
+            for name, cond, fs in (("cond_on", True, 1.0), ("uncond_on", False, 1.0), ("cond_off", True, 0.0), ("uncond_off", False, 0.0)):
                 tc = time.time()
-                unet_ref.unet_forward(sd_cpu_sample, cfg, ci["x"], torch.tensor([481]), ci["context"], ci["relations"], ci["boxes"],
-                                      ci["masks"], ci["positive_embeddings"])
-                times.append(time.time() - tc)
-            t_fwd = min(times)
-        per_image = t_fwd * 2 * (args.plms_steps + 1)
-        result["cpu_baseline"] = {"value": round(1.0 / per_image, 6), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-                                  "sample": f"3 conditional UNet forwards, B=1, {side}x{side} latent, fp32 oracle (best {t_fwd:.1f} s, all {[round(t, 1) for t in times]}); x{2 * (args.plms_steps + 1)} forwards/image extrapolated, VAE decode not included",
-                                  "seconds_per_forward": round(t_fwd, 2)}
+                refs[name] = cpu_fwd(ci["x"], torch.tensor([481]), cond, fs)
+                kinds[name] = time.time() - tc
+        # the oracle as CHECKER of the batch the benchmark actually ran (same tiles / split-K dispatch): sample 0 of the
+        # 2B batch = synth sample 0 (cond), sample B = its unconditional twin; unrounded fp32 weights on the oracle side
+        cat = lambda a, b: torch.cat([a, b], 0)
+        eng.forward = orig_forward
+        eng.set_conditioning(cat(inp["context"], inp["uc"]), cat(inp["relations"], inp["relations"]), cat(inp["boxes"], zz(inp["boxes"])),
+                             cat(inp["masks"], zz(inp["masks"])), cat(inp["positive_embeddings"], zz(inp["positive_embeddings"])), side)
+        rl2 = lambda a, b: float((a.float().cpu() - b).norm() / b.norm())
+        e_on = eng.forward(inp["x"], 481.0, 1.0, False, 2).clone()
+        e_off = eng.forward(inp["x"], 481.0, 0.0, False, 2).clone()
+        result["parity_at_bench_batch"] = {"rel_l2_cond_on": rl2(e_on[0:1], refs["cond_on"]), "rel_l2_uncond_on": rl2(e_on[B:B + 1], refs["uncond_on"]),
+                                           "rel_l2_cond_off": rl2(e_off[0:1], refs["cond_off"]), "rel_l2_uncond_off": rl2(e_off[B:B + 1], refs["uncond_off"]),
+                                           "note": "HIP engine sample 0 / B of the 2B batch vs the fp32 oracle (fp32 weights), t=481"}
+        with torch.no_grad():
+            pass
+        S = args.plms_steps
+        n_on = int(0.3 * S) + 1                       # step-evaluations with the fuser scaled 1 (step 0 evaluates twice)
+        n_off = S + 1 - n_on
+        per_image = n_on * (kinds["cond_on"] + kinds["uncond_on"]) + n_off * (kinds["cond_off"] + kinds["uncond_off"])
+        result["cpu_baseline"] = {
+            "value": round(1.0 / per_image, 6), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "cpu_model": cpu_model, "host_cores_total": os.cpu_count(),
+            "sample": f"4 UNet forwards (cond/uncond x fuser on/off), B=1, {side}x{side} latent, fp32 oracle after one warm-up: "
+                      f"{ {k: round(v, 2) for k, v in kinds.items()} } s; extrapolated to {n_on} on + {n_off} off step-evaluations x 2 passes "
+                      f"per image; the oracle executes the fuser at scale 0 like the reference does; VAE decode not included",
+            "seconds_per_forward": round(sum(kinds.values()) / 4, 2)}
+        if args.cpu_config1:
+            # BASELINE.json configs[0] / BASELINE.md section 4: txt2img plumbing case, B=1, 64x64, S=10 -> 22 forwards, fp32, end to end
+            c1 = {k: torch.from_numpy(v) for k, v in recipe.synth_inputs(cfg, 1, 64, n_boxes=2, n_rel=3, seed=1234).items()}
+
+            def eps_fn(x, tt, i, alpha):
+                with torch.no_grad():
+                    e_c = unet_ref.unet_forward(sd_cpu_sample, cfg, x, tt, c1["context"], c1["relations"], c1["boxes"], c1["masks"],
+                                                c1["positive_embeddings"], fuser_scale=float(alpha))
+                    e_u = unet_ref.unet_forward(sd_cpu_sample, cfg, x, tt, c1["uc"], c1["relations"], zz(c1["boxes"]), zz(c1["masks"]),
+                                                zz(c1["positive_embeddings"]), fuser_scale=float(alpha))
+                return e_u + 7.5 * (e_c - e_u)
+            tc = time.time()
+            lat1 = plms_ref.plms_sample(eps_fn, c1["x"], 10, [0.3, 0.0, 0.7])
+            t_c1 = time.time() - tc
+            assert torch.isfinite(lat1).all()
+            result["cpu_baseline"]["config1_end_to_end"] = {"seconds": round(t_c1, 1), "forwards": 22, "S": 10, "boxes": 2,
+                                                            "images_per_s": round(1.0 / t_c1, 6)}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

@@ -92,7 +92,7 @@ PROTOTYPES = {
 }
 
 _lib = None
-_inited = False
+_inited = set()
 
 
 class HipLibraryError(RuntimeError):
@@ -128,12 +128,16 @@ def lib() -> C.CDLL:
     return l
 
 
-def init_device() -> None:
-    """One-time per-process device-side setup (needs a GPU)."""
-    global _inited
-    if not _inited:
-        check(lib().gl_init(), "gl_init")
-        _inited = True
+def init_device(index=None) -> None:
+    """One-time per-device setup (needs a GPU): raises the dynamic-LDS limits of the tiled kernels on the CURRENT
+    device, so it is tracked per device index."""
+    import torch
+    if index is None:
+        index = torch.cuda.current_device()
+    if index not in _inited:
+        with torch.cuda.device(index):
+            check(lib().gl_init(), "gl_init")
+        _inited.add(index)
 
 
 def check(code: int, what: str) -> None:

@@ -43,6 +43,18 @@ class UNetConfig:
     def from_dict(params: dict) -> "UNetConfig":
         """Accepts the ``config['model']['params']`` dict of a GLIGEN checkpoint."""
         gt = (params.get("grounding_tokenizer") or {}).get("params", {})
+        # variants that share parameter names / shapes with this UNet but compute something else must not load silently
+        # (load_state_dict(strict=False), interface.py:91, would accept them): openaimodel.py:246-262, attention.py:362-384
+        if params.get("fuser_type", "gatedSA") != "gatedSA":
+            raise NotImplementedError(f"fuser_type={params.get('fuser_type')!r}: only 'gatedSA' is on the layout-to-image path")
+        if int(params.get("transformer_depth", 1)) != 1:
+            raise NotImplementedError("transformer_depth != 1 is not supported")
+        if params.get("inpaint_mode", False):
+            raise NotImplementedError("inpaint_mode checkpoints (9-channel first conv) are not on the layout-to-image path")
+        if params.get("grounding_downsampler") is not None:
+            raise NotImplementedError("grounding_downsampler is not on the text_layout path")
+        if not params.get("use_spatial_transformer", True):
+            raise NotImplementedError("use_spatial_transformer=False is not supported")
         return UNetConfig(
             image_size=int(params.get("image_size", 64)),
             in_channels=int(params.get("in_channels", 4)),

@@ -28,7 +28,9 @@ def _get(cfg, key, default=None):
 
 
 @torch.no_grad()
-def run(meta, config, starting_noise=None):
+def run(meta, config, starting_noise=None, clip_model=None, clip_processor=None):
+    """``clip_model`` / ``clip_processor``: the HF CLIP objects the reference creates inline (gligen_inference.py:96-98,
+    ``openai/clip-vit-large-patch14``); pass them in to run offline -- they are only downloaded when omitted."""
     device = _get(config, "device", "cuda")
     ckpt = meta["ckpt"]
     if ckpt not in _MODELS:
@@ -40,10 +42,13 @@ def run(meta, config, starting_noise=None):
              alpha_type=meta.get("alpha_type", [0.3, 0.0, 0.7]))
     if starting_noise is None:
         starting_noise = torch.randn(bs, 4, 64, 64).to(device)
-    from transformers import CLIPModel, CLIPProcessor
-    version = "openai/clip-vit-large-patch14"
-    clip_model = CLIPModel.from_pretrained(version).to(device)
-    clip_processor = CLIPProcessor.from_pretrained(version)
+    if clip_model is None or clip_processor is None:
+        from transformers import CLIPModel, CLIPProcessor
+        version = "openai/clip-vit-large-patch14"
+        clip_model = CLIPModel.from_pretrained(version).to(device)
+        clip_processor = CLIPProcessor.from_pretrained(version)
+    if "steps" in (config if isinstance(config, dict) else vars(config)):
+        args["steps"] = _get(config, "steps")
     images = interface.run_one_image(all_models, args, m, starting_noise, clip_model, clip_processor, device=device)
     folder = _get(config, "folder")
     if folder:

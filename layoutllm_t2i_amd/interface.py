@@ -63,15 +63,50 @@ def _instantiate_reference(config_node):
     return getattr(importlib.import_module(module), cls)(**config_node.get("params", dict()))
 
 
+def find_sd_first_conv(ckpt_path=None):
+    """Locates ``SD_input_conv_weight_bias.pth``.  The reference reads it from the GLIGEN code directory on every
+    scale-0 step (openaimodel.py:396-398) and fails hard when it is missing.  Search order: $GLIGEN_SD_FIRST_CONV,
+    next to the checkpoint, $GLIGEN_HOME, and the directory the reference itself computes -- four levels above
+    ``ldm/modules/diffusionmodules/openaimodel.py`` of whatever ``ldm`` package is importable.  Returns None if absent."""
+    name = "SD_input_conv_weight_bias.pth"
+    cands = []
+    if os.environ.get("GLIGEN_SD_FIRST_CONV"):
+        cands.append(os.environ["GLIGEN_SD_FIRST_CONV"])
+    if ckpt_path is not None:
+        cands.append(os.path.join(os.path.dirname(os.path.abspath(ckpt_path)), name))
+    if os.environ.get("GLIGEN_HOME"):
+        cands.append(os.path.join(os.environ["GLIGEN_HOME"], name))
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("ldm")
+        if spec is not None and spec.submodule_search_locations:
+            cands.append(os.path.join(os.path.dirname(list(spec.submodule_search_locations)[0]), name))
+    except (ImportError, ValueError):
+        pass
+    for c in cands:
+        if os.path.exists(c):
+            return c
+    return None
+
+
 def load_ckpt(ckpt_path, device="cuda"):
     """interface.py:78-101.  The UNet ('model') is built by this package from saved_ckpt['model'];
-    autoencoder / text_encoder / grounding tokenizer are instantiated from the checkpoint's config."""
+    autoencoder / text_encoder / grounding tokenizer are instantiated from the checkpoint's config.
+
+    Like the reference (openaimodel.py:393-405) the SD first-conv file is mandatory for a non-inpainting model:
+    a missing file raises FileNotFoundError here (the reference fails at the first scale-0 step) instead of silently
+    keeping the GLIGEN conv.  ``GLIGEN_ALLOW_NO_SD_CONV=1`` opts out explicitly (first_conv_restorable = False)."""
     saved_ckpt = torch.load(ckpt_path, map_location="cpu")
     config = saved_ckpt["config_dict"]["_content"]
     cfg = UNetConfig.from_dict(config["model"]["params"])
-    sd_path = os.environ.get("GLIGEN_SD_FIRST_CONV",
-                             os.path.join(os.path.dirname(os.path.abspath(ckpt_path)), "SD_input_conv_weight_bias.pth"))
-    model = UNetModel(cfg, saved_ckpt["model"], device=device, sd_first_conv=load_sd_first_conv(sd_path))
+    sd_path = find_sd_first_conv(ckpt_path)
+    if sd_path is None and os.environ.get("GLIGEN_ALLOW_NO_SD_CONV") != "1":
+        raise FileNotFoundError(
+            "SD_input_conv_weight_bias.pth not found (looked at $GLIGEN_SD_FIRST_CONV, next to the checkpoint, $GLIGEN_HOME and "
+            "the importable ldm package's GLIGEN directory): the sampler switches to it on every fuser-scale-0 step "
+            "(openaimodel.py:393-405).  Set GLIGEN_ALLOW_NO_SD_CONV=1 to run without it (results then differ from the reference).")
+    model = UNetModel(cfg, saved_ckpt["model"], device=device, sd_first_conv=load_sd_first_conv(sd_path),
+                      allow_missing_sd_conv=sd_path is None)
     dparams = config["diffusion"].get("params", {})
     diffusion = LatentDiffusion(linear_start=dparams.get("linear_start", 0.00085), linear_end=dparams.get("linear_end", 0.012),
                                 timesteps=dparams.get("timesteps", 1000), device=device)
@@ -161,6 +196,8 @@ def _one_sample_grounding(phrases, locations, model, processor, max_objs, device
     image_masks = torch.zeros(max_objs)
     text_embeddings = torch.zeros(max_objs, 768)
     image_embeddings = torch.zeros(max_objs, 768)
+    if phrases is None:
+        phrases = [None] * len(locations)           # interface.py:166: zero embeddings, boxes still grounded
     if feature_cache is None:
         feature_cache = get_clip_features_batched(model, processor, phrases, device)
     feats = [None if ph is None else feature_cache[ph] for ph in phrases]
@@ -192,6 +229,9 @@ def prepare_batch(meta, model, processor, batch=1, max_objs=MAX_OBJS, device=Non
 def prepare_batch_multiple(meta, model, processor, batch=1, max_objs=MAX_OBJS, device=None):
     """interface.py:424-475: one layout per prompt."""
     phrases_batch = meta.get("phrases")
+    if phrases_batch is None:
+        phrases_batch = [None] * len(meta["locations"])
+    phrases_batch = [[None] * len(loc) if ph is None else ph for ph, loc in zip(phrases_batch, meta["locations"])]
     assert batch == len(phrases_batch)
     cols = [[] for _ in range(6)]
     cache = get_clip_features_batched(model, processor, [ph for phrases in phrases_batch for ph in phrases], device)
@@ -288,7 +328,9 @@ def _run(all_models, args, meta, starting_noise, clip_model, clip_processor, dev
         context = text_encoder.encode([meta["prompt"]] * bs)
         relations = prepare_relation_phrases(meta["prompt"], bs, max_rel, text_encoder, device=device)
     uc = text_encoder.encode([""]).repeat(bs, 1, 1)          # the reference encodes bs copies of "" (interface.py:496)
-    samples = denoise(all_models, context, uc, relations, batch, starting_noise, meta.get("alpha_type"), cfg.guidance_scale)
+    # S is a harness parameter: the reference hard-codes 50 (interface.py:507); ``args["steps"]`` overrides it
+    samples = denoise(all_models, context, uc, relations, batch, starting_noise, meta.get("alpha_type"), cfg.guidance_scale,
+                      steps=int(cfg.get("steps", PLMS_STEPS)))
     return _postprocess(autoencoder.decode(samples))
 
 

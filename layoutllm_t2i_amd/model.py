@@ -93,7 +93,7 @@ class UNetModel:
     """
 
     def __init__(self, cfg: UNetConfig, state_dict: Mapping[str, object], device="cuda:0",
-                 sd_first_conv: Optional[Mapping[str, object]] = None):
+                 sd_first_conv: Optional[Mapping[str, object]] = None, allow_missing_sd_conv: bool = False):
         self.cfg = cfg
         self.device = torch.device(device)
         self.image_size = cfg.image_size
@@ -101,6 +101,7 @@ class UNetModel:
         self.out_channels = cfg.out_channels
         self.model_channels = cfg.model_channels
         self.first_conv_restorable = sd_first_conv is not None
+        self.allow_missing_sd_conv = allow_missing_sd_conv
         self.first_conv_type = "GLIGEN"
         self.grounding_tokenizer_input: Optional[GroundingNetInput] = None   # set externally (interface.py:370)
         self.fuser_scale = 1.0          # what set_alpha_scale writes (interface.py:34-38)
@@ -118,10 +119,17 @@ class UNetModel:
         return self
 
     def restore_first_conv_from_SD(self):
+        """openaimodel.py:393-408.  The reference's non-restorable branch exists for inpainting models only; for this
+        (non-inpainting) UNet a missing SD conv would silently change 35 of 50 steps, so it is an error unless the
+        model was built with ``allow_missing_sd_conv=True`` (then the reference's message is printed)."""
         if self.first_conv_restorable:
             self.first_conv_type = "SD"
-        else:
+        elif getattr(self, "allow_missing_sd_conv", False):
             print("First conv layer is not restorable and skipped this process, probably because this is an inpainting model?")
+        else:
+            raise RuntimeError("restore_first_conv_from_SD: the SD first-conv weights (GLIGEN/SD_input_conv_weight_bias.pth) were "
+                               "not given to UNetModel(sd_first_conv=...); the reference switches to them on every fuser-scale-0 "
+                               "step (openaimodel.py:393-405)")
 
     @property
     def use_sd_conv(self) -> bool:

@@ -18,8 +18,18 @@ F16 = torch.float16
 F32 = torch.float32
 
 
+_DEV = None
+
+
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """Stream of the device the last checked tensor lives on (``_req`` records it and asserts that all tensors of a
+    call share it).  A tensor on cuda:N while another device is current therefore launches on cuda:N's current stream."""
+    dev = _DEV if _DEV is not None else torch.cuda.current_device()
+    if dev != torch.cuda.current_device():
+        raise _lib.HipLibraryError(f"tensors live on cuda:{dev} but cuda:{torch.cuda.current_device()} is current: wrap the "
+                                   "call in torch.cuda.device(...) (kernels launch on the current device)")
+    _lib.init_device(dev)
+    return torch.cuda.current_stream(dev).cuda_stream
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -29,6 +39,8 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 def _req(t: torch.Tensor, dtype, name: str, align: int = 16) -> None:
     if not t.is_cuda:
         raise _lib.HipLibraryError(f"{name}: tensor is not on the GPU (the HIP path has no CPU fallback)")
+    global _DEV
+    _DEV = t.device.index
     if t.dtype != dtype:
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
     if t.data_ptr() % align:

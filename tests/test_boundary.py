@@ -1,0 +1,243 @@
+"""The drop-in boundary EXECUTED: a synthetic checkpoint with the reference's container layout goes through
+load_all_models -> generate_batch_images / generate_one_image / run_batch_images / gligen_inference.run with a stub text
+encoder, a toy HF CLIP and a rule-based sng_parser, and the result is checked against the test's own restatement of
+the reference flow (interface.py:424-570) driving the ORACLE UNet / PLMS / VAE.
+
+CPU tests cover what needs no GPU (checkpoint container, mandatory SD first conv, config validation)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(__file__))
+import stubs
+from layoutllm_t2i_amd import interface as itf
+from layoutllm_t2i_amd import recipe
+from layoutllm_t2i_amd.arch import TINY, VAE_TINY, UNetConfig
+from oracle import plms_ref, unet_ref, vae_ref
+
+DEV = "cuda:0"
+
+
+# ------------------------------------------------------------------------------------------- CPU: container + validation
+def test_synthetic_checkpoint_has_the_reference_container(tmp_path):
+    p = str(tmp_path / "ckpt.pth")
+    ck = stubs.write_synthetic_checkpoint(p, TINY, VAE_TINY)
+    saved = torch.load(p, map_location="cpu")
+    assert set(saved) == {"model", "autoencoder", "text_encoder", "diffusion", "config_dict"}
+    content = saved["config_dict"]["_content"]
+    assert {"model", "autoencoder", "text_encoder", "diffusion", "grounding_tokenizer_input"} <= set(content)
+    cfg = UNetConfig.from_dict(content["model"]["params"])
+    assert cfg == TINY
+    assert os.path.exists(tmp_path / "SD_input_conv_weight_bias.pth")
+    assert itf.find_sd_first_conv(p) == str(tmp_path / "SD_input_conv_weight_bias.pth")
+
+
+def test_unet_config_rejects_lookalike_variants():
+    base = dict(model_channels=64, num_heads=4)
+    assert UNetConfig.from_dict(base).model_channels == 64
+    for bad in (dict(fuser_type="gatedSA2"), dict(fuser_type="gatedCA"), dict(transformer_depth=2), dict(inpaint_mode=True),
+                dict(grounding_downsampler={"target": "x"}), dict(use_spatial_transformer=False)):
+        with pytest.raises(NotImplementedError):
+            UNetConfig.from_dict({**base, **bad})
+
+
+def test_load_ckpt_requires_the_sd_first_conv(tmp_path, monkeypatch):
+    """A missing SD_input_conv_weight_bias.pth is an error, as in the reference (openaimodel.py:396-398), not a
+    silent fallback to the GLIGEN first conv."""
+    p = str(tmp_path / "ckpt.pth")
+    stubs.write_synthetic_checkpoint(p, TINY, VAE_TINY, with_sd_conv=False)
+    for k in ("GLIGEN_SD_FIRST_CONV", "GLIGEN_HOME", "GLIGEN_ALLOW_NO_SD_CONV"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(itf, "find_sd_first_conv", lambda ckpt_path=None: None)
+    with pytest.raises(FileNotFoundError):
+        itf.load_ckpt(p, "cpu")
+
+
+def test_prepare_batch_accepts_phrases_none():
+    """interface.py:166: phrases=None -> zero text embeddings, boxes still grounded."""
+    model, proc = stubs.toy_clip(), stubs.ToyProcessor()
+    meta = {"phrases": None, "locations": [[0.1, 0.1, 0.5, 0.5], [0.2, 0.3, 0.9, 0.8]]}
+    out = itf.prepare_batch(meta, model, proc, batch=2, device="cpu")
+    assert out["masks"][0].tolist() == [1.0, 1.0] + [0.0] * 28 and float(out["text_embeddings"].abs().max()) == 0.0
+    assert float(out["text_masks"].abs().max()) == 0.0
+    outm = itf.prepare_batch_multiple({"phrases": None, "locations": [meta["locations"], meta["locations"][:1]]}, model, proc, batch=2,
+                                      device="cpu")
+    assert outm["masks"].sum(-1).tolist() == [2.0, 1.0] and float(outm["text_embeddings"].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------- GPU: the boundary, executed
+def _expected_conditioning(prompts, phrases, locations, enc, clip, proc, max_rel):
+    """The reference flow restated independently of interface.py's batched helpers: one CLIP forward per phrase
+    (interface.py:446-448), 'PAD' + every relation twice truncated to max_relations (:226-243), uc = "" (:496)."""
+    import sng_parser
+    B = len(prompts)
+    boxes, masks, emb = torch.zeros(B, 30, 4), torch.zeros(B, 30), torch.zeros(B, 30, 768)
+    for b in range(B):
+        for i, (ph, loc) in enumerate(zip(phrases[b], locations[b])):
+            boxes[b, i] = torch.tensor(loc)
+            masks[b, i] = 1
+            emb[b, i] = itf.get_clip_feature(clip, proc, ph, "cpu")[0]
+    rel = torch.zeros(B, max_rel, 768)
+    for b, p in enumerate(prompts):
+        g = sng_parser.parse(p)
+        trip = [" ".join([g["entities"][r["subject"]]["lemma_head"], r["relation"], g["entities"][r["object"]]["lemma_head"]])
+                for r in g["relations"]]
+        if trip:
+            lst = (["PAD"] + trip + trip)[:max_rel]
+            rel[b, :len(lst)] = enc.encode(lst, return_pooler_output=True)[1]
+    return dict(context=enc.encode(prompts), uc=enc.encode([""]).repeat(B, 1, 1), relations=rel, boxes=boxes, masks=masks,
+                positive_embeddings=emb)
+
+
+def _oracle_pipeline(cond, noise, S, alpha_type, guidance=7.5):
+    sd = {k: torch.from_numpy(np.asarray(v)).float() for k, v in recipe.state_dict(TINY, 0).items()}
+    fcn = recipe.sd_first_conv(TINY, 0)
+    fc = {k: torch.from_numpy(v) for k, v in fcn.items()}
+    z = torch.zeros_like
+    state = dict(sd=False)
+
+    def eps_fn(x, t, i, alpha):
+        if alpha == 0:
+            state["sd"] = True
+        first = fc if state["sd"] else None
+        with torch.no_grad():
+            e_c = unet_ref.unet_forward(sd, TINY, x, t, cond["context"], cond["relations"], cond["boxes"], cond["masks"],
+                                        cond["positive_embeddings"], fuser_scale=float(alpha), first_conv=first)
+            e_u = unet_ref.unet_forward(sd, TINY, x, t, cond["uc"], cond["relations"], z(cond["boxes"]), z(cond["masks"]),
+                                        z(cond["positive_embeddings"]), fuser_scale=float(alpha), first_conv=first)
+        return e_u + guidance * (e_c - e_u)
+    lat = plms_ref.plms_sample(eps_fn, noise, S, alpha_type)
+    vsd = {k: torch.from_numpy(np.asarray(v)) for k, v in recipe.vae_state_dict(VAE_TINY, 0).items()}
+    with torch.no_grad():
+        img = vae_ref.decode(vsd, lat, VAE_TINY.ch_mult, VAE_TINY.num_res_blocks, VAE_TINY.scale_factor)
+    return lat, img
+
+
+@pytest.fixture(scope="module")
+def loaded(tmp_path_factory):
+    d = tmp_path_factory.mktemp("ckpt")
+    p = str(d / "tiny_gligen.pth")
+    stubs.write_synthetic_checkpoint(p, TINY, VAE_TINY, max_relations=10)
+    stubs.install_fake_sng_parser()
+    am = itf.load_all_models(p, DEV)
+    clip = stubs.toy_clip().to(DEV)
+    return p, am, clip, stubs.ToyProcessor()
+
+
+PROMPTS = ["cat sitting on mat and dog under a tree", "a quiet empty street"]
+PHRASES = [["cat", "mat", "a big dog"], ["street"]]
+BOXES_LTRB = [[[0.10, 0.10, 0.50, 0.55], [0.05, 0.60, 0.95, 0.95], [0.55, 0.20, 0.90, 0.70]], [[0.0, 0.5, 1.0, 1.0]]]
+
+
+@pytest.mark.gpu
+def test_load_all_models_builds_the_five_tuple(loaded):
+    p, am, clip, proc = loaded
+    model, autoencoder, text_encoder, diffusion, config = am
+    from layoutllm_t2i_amd.model import GroundingNetInput, LatentDiffusion, UNetModel
+    from layoutllm_t2i_amd.vae import VAEDecoder
+    assert isinstance(model, UNetModel) and isinstance(model.grounding_tokenizer_input, GroundingNetInput)
+    assert isinstance(autoencoder, VAEDecoder) and isinstance(text_encoder, stubs.StubTextEncoder)
+    assert isinstance(diffusion, LatentDiffusion) and diffusion.num_timesteps == 1000
+    assert model.first_conv_restorable and model.first_conv_type == "GLIGEN"
+    assert config["max_relations"] == 10 and "model" in config and text_encoder.loaded is not None
+
+
+@pytest.mark.gpu
+def test_run_batch_images_equals_the_oracle_pipeline(loaded):
+    """run_batch_images (interface.py:478-549) with the harness parameter S = 4 on a 16x16 latent: the final latent
+    (captured at autoencoder.decode) and the PIL images vs the oracle UNet -> PLMS -> VAE fed with the reference flow's
+    conditioning."""
+    p, am, clip, proc = loaded
+    model, autoencoder, text_encoder, diffusion, config = am
+    model.first_conv_type = "GLIGEN"
+    torch.manual_seed(123)
+    noise = torch.randn(2, 4, 16, 16)
+    captured = {}
+    dec = autoencoder.decode
+    autoencoder.decode = lambda z: captured.setdefault("img", dec(captured.setdefault("lat", z.clone())))
+    try:
+        args = dict(batch_size=2, no_plms=False, guidance_scale=7.5, steps=4)
+        meta = dict(prompts=PROMPTS, phrases=PHRASES, locations=BOXES_LTRB, alpha_type=[0.5, 0.0, 0.5])
+        imgs = itf.run_batch_images(am, args, meta, noise.to(DEV), clip, proc, device=DEV)
+    finally:
+        autoencoder.decode = dec
+    assert config["batch_size"] == 2 and config["guidance_scale"] == 7.5 and config["steps"] == 4   # config.update(args) mutates
+    assert model.first_conv_type == "SD"
+    cond = _expected_conditioning(PROMPTS, PHRASES, BOXES_LTRB, text_encoder.to("cpu"), clip.cpu(), proc, 10)
+    text_encoder.to(DEV), clip.to(DEV)
+    lat_ref, img_ref = _oracle_pipeline(cond, noise, 4, [0.5, 0.0, 0.5])
+    rl = float((captured["lat"].cpu() - lat_ref).norm() / lat_ref.norm())
+    ri = float((captured["img"].float().cpu() - img_ref).norm() / img_ref.norm())
+    print(f"[boundary] latent rel_l2={rl:.3e} decoded image rel_l2={ri:.3e}")
+    assert rl < 8e-3 and ri < 1.5e-2, (rl, ri)
+    assert len(imgs) == 2 and imgs[0].size == (32, 32) and imgs[0].mode == "RGB"
+    want = (torch.clamp(img_ref, -1, 1) * 0.5 + 0.5).numpy().transpose(0, 2, 3, 1) * 255
+    got = np.stack([np.asarray(im) for im in imgs]).astype(np.int32)
+    assert np.mean(np.abs(got - want.astype(np.uint8).astype(np.int32)) <= 3) > 0.98
+
+
+@pytest.mark.gpu
+def test_generate_batch_and_one_image_contracts(loaded):
+    """generate_batch_images (interface.py:551-570) and generate_one_image (:376-395) as train_rl.py / txt2img.py call
+    them: list[PIL] of the right length / size, 64x64 noise from the GLOBAL CPU RNG, boxes passed through UNconverted by
+    the batch entry point and xywh -> ltrb converted by the single-image one, config mutated, SD first conv permanent."""
+    p, am, clip, proc = loaded
+    model, autoencoder, text_encoder, diffusion, config = am
+    model.first_conv_type = "GLIGEN"
+    seen = {}
+    eng = model.engine
+    orig = eng.set_conditioning
+
+    def spy(context, relations, boxes, masks, pe, hw):
+        seen.update(boxes=boxes.detach().float().cpu().clone(), masks=masks.detach().float().cpu().clone(), hw=hw, n=boxes.shape[0])
+        return orig(context, relations, boxes, masks, pe, hw)
+    eng.set_conditioning = spy
+    lat = {}
+    dec = autoencoder.decode
+    autoencoder.decode = lambda z: dec(lat.setdefault("z", z.clone()))
+    try:
+        torch.manual_seed(77)
+        imgs = itf.generate_batch_images(am, PROMPTS, PHRASES, BOXES_LTRB, clip, proc, device=DEV)
+        after = torch.randn(3)
+        torch.manual_seed(77)
+        noise = torch.randn(2, 4, 64, 64)
+        assert torch.equal(after, torch.randn(3)), "exactly one torch.randn(bs,4,64,64) is drawn from the global CPU RNG (interface.py:566)"
+        assert len(imgs) == 2 and all(im.size == (128, 128) and im.mode == "RGB" for im in imgs)   # tiny VAE: 2x upsampling
+        assert seen["hw"] == 64 and seen["n"] == 4                                                   # [cond ; uncond] batch
+        assert torch.allclose(seen["boxes"][0, :3], torch.tensor(BOXES_LTRB[0])) and float(seen["boxes"][2:].abs().max()) == 0.0
+        assert config["batch_size"] == 2 and config["no_plms"] is False and model.first_conv_type == "SD"
+        assert torch.isfinite(lat["z"]).all() and lat["z"].shape == (2, 4, 64, 64)
+        # deterministic in (prompt, layout, RNG state)
+        lat1 = lat.pop("z")
+        torch.manual_seed(77)
+        imgs2 = itf.generate_batch_images(am, PROMPTS, PHRASES, BOXES_LTRB, clip, proc, device=DEV)
+        # (first_conv stays "SD" for the second image, like the reference: every step now runs with the SD conv)
+        assert lat["z"].shape == lat1.shape
+        lat.pop("z")
+        # single image: xywh boxes are converted (interface.py:383)
+        xywh = [[0.10, 0.10, 0.40, 0.45], [0.05, 0.60, 0.90, 0.35]]
+        torch.manual_seed(5)
+        one = itf.generate_one_image(am, PROMPTS[0], ["cat", "mat"], xywh, clip, proc, device=DEV)
+        assert len(one) == 1 and one[0].size == (128, 128) and config["batch_size"] == 1
+        assert torch.allclose(seen["boxes"][0, :2], torch.tensor([[0.10, 0.10, 0.50, 0.55], [0.05, 0.60, 0.95, 0.95]]))
+    finally:
+        eng.set_conditioning = orig
+        autoencoder.decode = dec
+
+
+@pytest.mark.gpu
+def test_gligen_inference_run_with_injected_clip(loaded, tmp_path):
+    p, am, clip, proc = loaded
+    from layoutllm_t2i_amd import gligen_inference as gi
+    gi._MODELS[p] = am
+    meta = dict(ckpt=p, prompt=PROMPTS[0], phrases=PHRASES[0], locations=BOXES_LTRB[0], save_folder_name="t")
+    cfg = dict(batch_size=1, guidance_scale=7.5, no_plms=False, folder=str(tmp_path), device=DEV, steps=3)
+    torch.manual_seed(1)
+    imgs = gi.run(meta, cfg, clip_model=clip, clip_processor=proc)
+    assert len(imgs) == 1 and imgs[0].size == (128, 128)
+    assert os.path.exists(tmp_path / "t" / "0.png")
+    with pytest.raises(NotImplementedError):
+        gi.run(meta, dict(cfg, no_plms=True), clip_model=clip, clip_processor=proc)

@@ -1,0 +1,173 @@
+"""Parity at the sizes BASELINE.json's configs actually run (the tile / split-K / 256-row dispatch depends on the
+batch): the 2B = 8 batch of configs[1], the 2B = 32 batch of configs[4], configs[2] at 96x96 latents with B = 2 and
+16 boxes.  Samples of a batch are independent (GroupNorm is per sample, LayerNorm per token), so the oracle is
+evaluated for ONE sample of each batch on the host CPU and compared with the engine's row for that sample.
+
+Bounds are <= 1.5x the values measured on MI355X (printed by ``report``); the arithmetic floor of ANY implementation
+that feeds fp16 operands to the matrix cores is rel-L2 ~1.1e-3 on this network (tools/precision_sim.py).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.dirname(__file__))
+from layoutllm_t2i_amd import recipe
+from layoutllm_t2i_amd.arch import UNetConfig
+from layoutllm_t2i_amd.interface import denoise
+from layoutllm_t2i_amd.model import GroundingNetInput, LatentDiffusion, UNetModel
+from layoutllm_t2i_amd.weights import random_state_dict
+from oracle import unet_ref
+
+DEV = "cuda:0"
+T = torch.from_numpy
+
+
+def rel_l2(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def report(name, out, ref):
+    out, ref = out.float().cpu(), ref.float().cpu()
+    r = rel_l2(out, ref)
+    d = (out - ref).abs()
+    frac = float((d > 1e-4 + 1e-3 * ref.abs()).float().mean())
+    print(f"[{name}] rel_l2={r:.3e} max|err|={float(d.max()):.3e} |ref|max={float(ref.abs().max()):.3f} "
+          f"outside rtol1e-3/atol1e-4: {100 * frac:.1f}%")
+    assert torch.isfinite(out).all(), name
+    return r
+
+
+_full = {}
+
+
+def full_model():
+    """The 1.26 B-parameter config-2 UNet with random weights (recipe scaling) + an SD first conv; one per session."""
+    if "m" not in _full:
+        cfg = UNetConfig()
+        dev = torch.device(DEV)
+        sd = random_state_dict(cfg, dev, seed=3)
+        g = torch.Generator(device=dev)
+        g.manual_seed(11)
+        fc = {"weight": torch.randn(cfg.model_channels, cfg.in_channels, 3, 3, device=dev, generator=g) * 0.16,
+              "bias": torch.zeros(cfg.model_channels, device=dev)}
+        m = UNetModel(cfg, sd, device=DEV, sd_first_conv={k: v.cpu().numpy() for k, v in fc.items()})
+        m.grounding_tokenizer_input = GroundingNetInput()
+        # oracle weights: matrices rounded to fp16 like the engine stores them (isolates arithmetic error)
+        sd_cpu = {k: (v.detach().float().cpu().half().float() if v.dim() >= 2 else v.detach().float().cpu()) for k, v in sd.items()}
+        fc_cpu = {k: (v.float().cpu().half().float() if v.dim() >= 2 else v.float().cpu()) for k, v in fc.items()}
+        del sd
+        torch.cuda.empty_cache()
+        _full.update(m=m, sd=sd_cpu, fc=fc_cpu, cfg=cfg)
+    return _full["m"], _full["sd"], _full["fc"], _full["cfg"]
+
+
+def cfg_batch(cfg, B, hw, n_boxes, seed):
+    """[cond ; uncond] conditioning exactly as the sampler builds it (sampler.py / plms.py:115-124)."""
+    inp = {k: T(v) for k, v in recipe.synth_inputs(cfg, B, hw, n_boxes=n_boxes, n_rel=3, seed=seed).items()}
+    z = torch.zeros_like
+    cat = lambda a, b: torch.cat([a, b], 0)
+    two = dict(context=cat(inp["context"], inp["uc"]), relations=cat(inp["relations"], inp["relations"]),
+               boxes=cat(inp["boxes"], z(inp["boxes"])), masks=cat(inp["masks"], z(inp["masks"])),
+               positive_embeddings=cat(inp["positive_embeddings"], z(inp["positive_embeddings"])))
+    return inp, two
+
+
+def oracle_one(sd, cfg, inp, k, cond, tval, fuser_scale=1.0, first_conv=None):
+    """fp32 oracle for sample k of the batch: conditional, or its null-grounding / empty-prompt twin."""
+    s = lambda a: a[k:k + 1]
+    z = torch.zeros_like
+    torch.set_num_threads(min(32, max(1, os.cpu_count() or 1)))
+    t = torch.full((1,), int(tval), dtype=torch.long)
+    with torch.no_grad():
+        if cond:
+            return unet_ref.unet_forward(sd, cfg, s(inp["x"]).half().float(), t, s(inp["context"]).half().float(),
+                                         s(inp["relations"]).half().float(), s(inp["boxes"]), s(inp["masks"]), s(inp["positive_embeddings"]),
+                                         fuser_scale=fuser_scale, first_conv=first_conv)
+        return unet_ref.unet_forward(sd, cfg, s(inp["x"]).half().float(), t, s(inp["uc"]).half().float(),
+                                     s(inp["relations"]).half().float(), z(s(inp["boxes"])), z(s(inp["masks"])),
+                                     z(s(inp["positive_embeddings"])), fuser_scale=fuser_scale, first_conv=first_conv)
+
+
+# measured on MI355X (round 2): see DESIGN.md section 4; asserts are <= 1.5x these
+BOUND_FULL = 2.6e-3
+
+
+@pytest.mark.parametrize("B", [4, 16], ids=["configs1_2B8", "configs4_2B32"])
+def test_config2_shapes_at_bench_batch_vs_oracle(B):
+    """configs[1] (B = 4 -> 2B = 8) and configs[4] (B = 16 -> 2B = 32): the 2B batch the sampler launches, checked
+    against the oracle on one conditional sample (k = 1) and its unconditional twin (row B + 1); fuser on, then the
+    scale-0 / SD-first-conv form the last 35 sampling steps use."""
+    model, sd, fc, cfg = full_model()
+    hw, k = 64, 1
+    inp, two = cfg_batch(cfg, B, hw, 8, seed=2024)
+    eng = model.engine
+    eng.set_conditioning(two["context"], two["relations"], two["boxes"], two["masks"], two["positive_embeddings"], hw)
+    x = inp["x"].to(DEV)
+    e_on = eng.forward(x, 481.0, 1.0, False, 2).clone()
+    e_off = eng.forward(x, 201.0, 0.0, True, 2).clone()
+    assert e_on.shape == (2 * B, 4, hw, hw)
+    r = [report(f"2B={2 * B} cond  fuser on ", e_on[k:k + 1], oracle_one(sd, cfg, inp, k, True, 481)),
+         report(f"2B={2 * B} uncond fuser on ", e_on[B + k:B + k + 1], oracle_one(sd, cfg, inp, k, False, 481)),
+         report(f"2B={2 * B} cond  fuser off", e_off[k:k + 1], oracle_one(sd, cfg, inp, k, True, 201, 0.0, fc))]
+    assert max(r) < BOUND_FULL, r
+    # samples are independent: every row of the batch is a different image, and a replay is deterministic
+    assert rel_l2(e_on[0:1], e_on[1:2]) > 1e-2 and rel_l2(e_on[0:1], e_on[B:B + 1]) > 1e-3
+    assert torch.equal(e_on, eng.forward(x, 481.0, 1.0, False, 2))
+
+
+def test_config4_rollout_batch16_plms_runs():
+    """configs[4]'s denoise stage: 16 prompts through ``denoise`` (5 PLMS steps, CFG 7.5, alpha_type [0.3, 0, 0.7])."""
+    model, sd, fc, cfg = full_model()
+    model.first_conv_type = "GLIGEN"
+    B, hw = 16, 64
+    inp, _ = cfg_batch(cfg, B, hw, 8, seed=7)
+    batch = dict(boxes=inp["boxes"], masks=inp["masks"], text_embeddings=inp["positive_embeddings"])
+    am = (model, None, None, LatentDiffusion(device=DEV), {})
+    lat = denoise(am, inp["context"], inp["uc"], inp["relations"], batch, inp["x"].to(DEV), [0.3, 0.0, 0.7], 7.5, steps=5)
+    assert lat.shape == (B, 4, hw, hw) and torch.isfinite(lat).all()
+    assert model.first_conv_type == "SD"
+    # a sample's latent does not depend on what else is in the batch (up to the fp16 pipeline's dispatch-dependent rounding)
+    model.first_conv_type = "GLIGEN"
+    sub = {k: v[:4] for k, v in inp.items()}
+    lat4 = denoise(am, sub["context"], sub["uc"], sub["relations"], {k: v[:4] for k, v in batch.items()}, sub["x"].to(DEV),
+                   [0.3, 0.0, 0.7], 7.5, steps=5)
+    r = report("B=16 vs B=4 rows", lat[:4], lat4)
+    assert r < 1e-2, r
+
+
+def test_config3_768px_whole_unet_vs_oracle_and_50_steps():
+    """configs[2]: 768x768 -> 96x96 latents (9216 / 2304 / 576 / 144 tokens per level, 12x12 convs with M = 2B*144
+    ragged against the 128-row tiles), B = 2, 16 grounding boxes: whole UNet vs the oracle on sample 1, null-grounding
+    and determinism properties, then the full 50-step sampling run."""
+    model, sd, fc, cfg = full_model()
+    model.first_conv_type = "GLIGEN"
+    B, hw, k = 2, 96, 1
+    inp, two = cfg_batch(cfg, B, hw, 16, seed=31)
+    assert float(inp["masks"].sum()) == 32.0
+    eng = model.engine
+    eng.set_conditioning(two["context"], two["relations"], two["boxes"], two["masks"], two["positive_embeddings"], hw)
+    x = inp["x"].to(DEV)
+    e = eng.forward(x, 481.0, 1.0, False, 2).clone()
+    r = [report("768px cond", e[k:k + 1], oracle_one(sd, cfg, inp, k, True, 481)),
+         report("768px uncond", e[B + k:B + k + 1], oracle_one(sd, cfg, inp, k, False, 481))]
+    assert max(r) < BOUND_FULL, r
+    assert torch.equal(e, eng.forward(x, 481.0, 1.0, False, 2))
+    # the unconditional half ignores boxes / phrase embeddings entirely (null tokens; rela_fuse == LN3)
+    two2 = dict(two)
+    two2["boxes"] = torch.cat([inp["boxes"], torch.rand_like(inp["boxes"])], 0)
+    two2["positive_embeddings"] = torch.cat([inp["positive_embeddings"], torch.randn_like(inp["positive_embeddings"])], 0)
+    eng.set_conditioning(two2["context"], two2["relations"], two2["boxes"], two2["masks"], two2["positive_embeddings"], hw)
+    assert torch.equal(e, eng.forward(x, 481.0, 1.0, False, 2))
+    batch = dict(boxes=inp["boxes"], masks=inp["masks"], text_embeddings=inp["positive_embeddings"])
+    am = (model, None, None, LatentDiffusion(device=DEV), {})
+    lat = denoise(am, inp["context"], inp["uc"], inp["relations"], batch, x, [0.3, 0.0, 0.7], 7.5, steps=50)
+    assert lat.shape == (B, 4, hw, hw) and torch.isfinite(lat).all() and float(lat.abs().max()) < 1e3
+    model.first_conv_type = "GLIGEN"
+    lat2 = denoise(am, inp["context"], inp["uc"], inp["relations"], batch, x, [0.3, 0.0, 0.7], 7.5, steps=50)
+    assert torch.equal(lat, lat2), "the sampling run is deterministic (fixed reduction orders, graph replay)"
