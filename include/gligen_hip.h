@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GL_ABI_VERSION 2
+#define GL_ABI_VERSION 3
 
 /* error codes (negative; positive values are hipError_t) */
 #define GL_ERR_BAD_ARG (-1)
@@ -41,7 +41,11 @@ enum gl_epilogue {
 
 enum gl_out_mode {
     GL_OUT_F16_ROWMAJOR = 0, /* out[m * ldc + n] fp16                                   */
-    GL_OUT_F32_NCHW = 1      /* out[(b * N + n) * HW + p] fp32, m = b * HW + p           */
+    GL_OUT_F32_NCHW = 1,     /* out[(b * N + n) * HW + p] fp32, m = b * HW + p           */
+    GL_OUT_F32_ROWMAJOR = 2  /* out[m * ldc + n] fp32: the RESIDUAL STREAM (ResBlock / transformer-block sums,
+                                openaimodel.py:231, attention.py:395-402,446) is kept in fp32 so that ~100 chained
+                                residual adds are not rounded to fp16 each; out2 (optional) gets an fp16 copy for
+                                consumers that feed it to the matrix cores (GroupNorm -> conv, 1x1 skip conv)      */
 };
 
 /*
@@ -70,6 +74,8 @@ typedef struct gl_gemm_args {
      * levels: 40-160 tiles) and K is long, K is cut into slices that write fp32 partial tiles here and a
      * second kernel reduces them and applies the epilogue.  NULL disables splitting. */
     void* workspace;    int64_t workspace_bytes;
+    int32_t res_f32;                    /* != 0: res is fp32 [M, ldres] (residual stream), else fp16 */
+    void* out2;         int32_t ldc2;   /* optional fp16 copy [M, N] of a GL_OUT_F32_ROWMAJOR output; NULL = none */
 } gl_gemm_args;
 
 /*
@@ -116,7 +122,8 @@ int gl_transpose_v(const void* v, int64_t v_bstride, int32_t ldv, void* vt, int3
  * GroupNorm(32 groups) over NHWC fp16, fp32 statistics (GroupNorm32, util.py:226-228; Normalize,
  * attention.py:78-79), fused SiLU (openaimodel.py:155-157,180-181) and fused channel concat of two
  * sources (openaimodel.py:456): channels [0, C1) come from x1 [B, HW, C1], [C1, C1+C2) from x2.
- *   gl_groupnorm_stats : partial[b][chunk][32][2] (sum, sumsq) fp32, nchunk chunks of pixels
+ *   gl_groupnorm_stats : partial[b][chunk][32][2] = (mean, M2) per group and pixel chunk, fp32, gathered about a
+ *                        per-channel shift and merged with the exact pairwise (Welford / Chan) formula
  *   gl_groupnorm_apply : y = (x - mean) * rstd * gamma + beta (, SiLU) -> fp16 [B, HW, C1+C2]
  */
 int gl_groupnorm_stats(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t B, int32_t HW,
@@ -126,13 +133,13 @@ int gl_groupnorm_apply(const void* x1, int32_t C1, const void* x2, int32_t C2, i
                        float eps, int32_t silu, void* out, void* stream);
 
 /*
- * gl_layernorm: row LayerNorm eps 1e-5 over C (attention.py:216-217,292-294,369-371), fp32 statistics.
- * Input row r = (b, i) with i < rows_in; output row index = b * rows_out + row_off + i -- this writes
- * straight into the [x ; objs] concatenation of GatedSelfAttentionDense (attention.py:230).  C % 8 == 0,
- * C <= 2048.
+ * gl_layernorm: row LayerNorm eps 1e-5 over C (attention.py:216-217,292-294,369-371), fp32 statistics (two-pass).
+ * Input row r = (b, i) with i < rows_in, fp32 when x_f32 != 0 (the residual stream) else fp16; output fp16, row index
+ * = b * rows_out + row_off + i -- this writes straight into the [x ; objs] concatenation of GatedSelfAttentionDense
+ * (attention.py:230).  stats (optional): (mean, rstd) per input row, fp32 [B * rows_in, 2].  C % 8 == 0, C <= 2048.
  */
-int gl_layernorm(const void* x, int32_t ldx, void* y, int32_t ldy, const float* gamma, const float* beta,
-                 int32_t B, int32_t rows_in, int32_t rows_out, int32_t row_off, int32_t C, float eps,
+int gl_layernorm(const void* x, int32_t ldx, int32_t x_f32, void* y, int32_t ldy, const float* gamma, const float* beta,
+                 int32_t B, int32_t rows_in, int32_t rows_out, int32_t row_off, int32_t C, float eps, float* stats,
                  void* stream);
 
 /*
@@ -143,10 +150,14 @@ int gl_layernorm(const void* x, int32_t ldx, void* y, int32_t ldy, const float* 
  * reproduces the reference's NaN for an empty (right < left) slice.
  *   gl_rela_pool  : feat[b, i, :] = mean_{p in rect_i} hid[b, p, :]   (0 rows for i >= nvalid[b])
  *   gl_rela_merge : y = 0.5 * (x + hid + (1/max_objs) * sum_i 1[p in rect_i] f[b, i, :])
+ *                   x / y fp32 when x_f32 != 0 (residual stream) else fp16.  hid = LayerNorm3(x) is either read (fp16,
+ *                   ln_stats == NULL) or re-evaluated in fp32 from ln_stats = gl_layernorm's (mean, rstd) rows and
+ *                   gamma / beta, so that it enters the stream unrounded.
  */
 int gl_rela_pool(const void* hid, int32_t B, int32_t H, int32_t W, int32_t C, const int32_t* rects,
                  const int32_t* nvalid, const int32_t* poison, int32_t max_objs, void* feat, void* stream);
-int gl_rela_merge(const void* x, const void* hid, const void* f, int32_t B, int32_t H, int32_t W, int32_t C,
+int gl_rela_merge(const void* x, int32_t x_f32, const void* hid, const float* ln_stats, const float* gamma,
+                  const float* beta, const void* f, int32_t B, int32_t H, int32_t W, int32_t C,
                   const int32_t* rects, const int32_t* nvalid, const int32_t* poison, int32_t max_objs,
                   void* y, void* stream);
 
@@ -201,17 +212,12 @@ int gl_abi_version(void);
 int gl_sizeof_gemm_args(void);
 int gl_sizeof_conv_args(void);
 int gl_sizeof_attn_args(void);
-/* tuning knobs for A/B measurements: key 1 = GEMM/conv pipeline (0 = BK 64, 2 LDS stages, default;
- * 1 = BK 32, 3 stages with counted vmcnt; 3 = BK 32, 2 stages at 4 blocks/CU); key 2 = tile shape policy (0 auto, 1 force 128x128, 2 prefer 128x160); key 3 = attention
- * variant (0 = auto: 32 queries/wave, 8-wave blocks for long sequences; 1 = 64 queries/wave; 2 = software-pipelined;
- * 3 = always 8-wave blocks; 4 = always 4-wave blocks); keys 4-7 = small-tile / split-K / 8-wave thresholds; key 8 = short-K
- * GEGLU GEMMs on the BK 32 / 4-blocks-per-CU variant (1 default, 0 off); key 9 = which 256-row GEMM variant key 7 selects;
- * key 10 = s_setprio around the attention MFMA clusters (-1 auto, 0 off, 1 on); key 11 = LayerNorm rows per wave;
- * key 12 = measurement-only main-loop ablation bits (1 = no MFMA half, 2 = no DMA half: results invalid;
- * 4 = s_setprio around the MFMA cluster: valid results, measured -1 % GEMM / 0 % conv); key 13 = intra-block K-split GEMM/conv
- * variants (0 off, 1 auto = default, 2 always); key 14 = halo-resident 3x3 conv kernel (0 off = default, 1 when the
- * grid has at least key-15 tiles, 2 whenever the geometry allows).
- * Results do not depend on these knobs beyond fp32 summation order in split-K. */
+/* tuning knobs for A/B measurements (results do not depend on them beyond fp32 summation order in split-K):
+ * key 2 = GEMM tile shape policy (0 auto, 1 force 128x128, 2 prefer 128x160); key 3 = attention block shape (0 auto,
+ * 3 always 8 waves, 4 always 4 waves); keys 4-7 = small-tile / split-K / 256-row-tile thresholds; key 8 = short-K GEGLU
+ * GEMMs on the BK 32 / 4-blocks-per-CU variant (1 default, 0 off); key 10 = s_setprio around the attention MFMA
+ * clusters (-1 auto, 0 off, 1 on); key 13 = intra-block K-split GEMM/conv variants (0 off, 1 auto = default, 2 always);
+ * key 16 = GroupNorm apply pixels per block. */
 int gl_set_option(int key, int value);
 /* one-time per-process setup (raises dynamic-LDS limits of the tiled kernels); idempotent */
 int gl_init(void);

@@ -11,11 +11,11 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgligen_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # enum gl_epilogue / gl_out_mode
 EPI_BIAS, EPI_SILU, EPI_GEGLU, EPI_RES, EPI_GATE_RES, EPI_ROWBIAS = range(6)
-OUT_F16_ROWMAJOR, OUT_F32_NCHW = 0, 1
+OUT_F16_ROWMAJOR, OUT_F32_NCHW, OUT_F32_ROWMAJOR = 0, 1, 2
 
 vp = C.c_void_p
 i32 = C.c_int32
@@ -39,6 +39,8 @@ class GemmArgs(C.Structure):
         ("rowbias", vp), ("ld_rowbias", i32), ("rows_per_sample", i32),
         ("hw", i32),
         ("workspace", vp), ("workspace_bytes", i64),
+        ("res_f32", i32),
+        ("out2", vp), ("ldc2", i32),
     ]
 
 
@@ -72,9 +74,9 @@ PROTOTYPES = {
     "gl_transpose_v": (i32, [vp, i64, i32, vp, i32, i32, i32, i32, i32, vp]),
     "gl_groupnorm_stats": (i32, [vp, i32, vp, i32, i32, i32, fp, i32, vp]),
     "gl_groupnorm_apply": (i32, [vp, i32, vp, i32, i32, i32, fp, i32, fp, fp, f32, i32, vp, vp]),
-    "gl_layernorm": (i32, [vp, i32, vp, i32, fp, fp, i32, i32, i32, i32, i32, f32, vp]),
+    "gl_layernorm": (i32, [vp, i32, i32, vp, i32, fp, fp, i32, i32, i32, i32, i32, f32, fp, vp]),
     "gl_rela_pool": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp]),
-    "gl_rela_merge": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp]),
+    "gl_rela_merge": (i32, [vp, i32, vp, fp, fp, fp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp]),
     "gl_posnet_input": (i32, [fp, fp, fp, fp, fp, i32, i32, i32, vp, vp]),
     "gl_timestep_embedding": (i32, [fp, i32, i32, vp, vp]),
     "gl_silu_f16": (i32, [vp, vp, i64, vp]),

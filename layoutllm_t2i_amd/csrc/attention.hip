@@ -23,10 +23,9 @@
 
 namespace {
 
-int g_attn_qt2 = 0;
+int g_attn_qt2 = 0;          // block shape: 0 auto, 3 always 8 waves, 4 always 4 waves
 int g_attn_setprio = -1;     // s_setprio(1) around the MFMA clusters: -1 auto (head dim <= 48: +6 %; d = 80: -4 %), 0 off, 1 on
 constexpr int KT = 64;          // keys per tile
-constexpr int VSTR = KT + 4;    // V^T LDS row stride in halfs (136 B: odd number of 8-byte slots), pipelined variant
 constexpr int VSTR2 = KT + 8;   // main kernel: 144 B rows = 9 x 16 B, conflict-free 16-byte fragment reads
 
 template <int DQK, int QT, int NW>
@@ -295,241 +294,6 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(gl_attn_args p, int flags
     }
 }
 
-// Software-pipelined variant (QT = 1): the K.Q^T MFMAs of tile t+1 are issued before the softmax of tile t,
-// so the matrix pipe works while the VALU does exp / max / convert of the previous tile (the base kernel
-// serialises QK^T -> softmax -> P.V inside each wave: PMC showed VALU 45 % + MFMA 27 % busy with the rest
-// waiting).  K/V tiles live in a 3-deep LDS ring so the refill of tile t+2 never races the readers of tile
-// t (one barrier per tile); the loop body is unrolled x2 so the two score arrays swap roles without copies.
-template <int DQK>
-__global__ __launch_bounds__(256) void attn_pipe_kernel(gl_attn_args p) {
-    constexpr int NKS = DQK / 16;
-    constexpr int NDT = (DQK + 31) / 32;
-    constexpr int KSTR = DQK + 8;
-    constexpr int KCH = DQK / 8;
-    constexpr int K_ITEMS = KT * KCH;
-    constexpr int K_PER_T = (K_ITEMS + 255) / 256;
-    constexpr int V_ITEMS = NDT * 32 * (KT / 8);
-    constexpr int V_PER_T = (V_ITEMS + 255) / 256;
-    constexpr bool ONES = (NDT * 32 > DQK);
-    constexpr int OC = NDT * 32 - 1;
-    constexpr int KBUF = KT * KSTR;
-    constexpr int VBUF = NDT * 32 * VSTR;
-    __shared__ __attribute__((aligned(16))) half_t Ksm[3 * KBUF];
-    __shared__ __attribute__((aligned(16))) half_t Vsm[3 * VBUF];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int ql = lane & 31;
-    const int hi = lane >> 5;
-    const int b = blockIdx.z;
-    const int h = blockIdx.y;
-    const int q0 = blockIdx.x * 128 + wave * 32;
-    const int d = p.d, Nq = p.Nq, Nk = p.Nk;
-
-    const half_t* __restrict__ Qg = reinterpret_cast<const half_t*>(p.q) + (size_t)b * p.q_bstride + (size_t)h * d;
-    const half_t* __restrict__ Kg = reinterpret_cast<const half_t*>(p.k) + (size_t)b * p.k_bstride + (size_t)h * d;
-    const half_t* __restrict__ Vg = reinterpret_cast<const half_t*>(p.vt) + (size_t)(b * p.H + h) * d * p.ldvt;
-
-    half8_t qf[NKS];
-    {
-        int q = q0 + ql;
-        if (q >= Nq) q = Nq - 1;
-        const half_t* qrow = Qg + (size_t)q * p.ldq;
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            const int c0 = (2 * ks + hi) * 8;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (c0 < d) v = ld16(qrow + c0);
-            qf[ks] = *reinterpret_cast<half8_t*>(&v);
-        }
-    }
-    f32x16 o[NDT];
-#pragma unroll
-    for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[dt][r] = 0.0f;
-    float m_run = -INFINITY, l_run = 0.0f;
-    const float c_scale = p.scale * 1.4426950408889634f;
-
-    uint4 rk[K_PER_T], rv[V_PER_T];
-    const half_t* kptr[K_PER_T];
-    const half_t* vptr[V_PER_T];
-    int krow[K_PER_T], klds[K_PER_T], vlds[V_PER_T];
-    bool kok[K_PER_T], vok[V_PER_T], vone[V_PER_T];
-#pragma unroll
-    for (int i = 0; i < K_PER_T; ++i) {
-        const int idx = tid + 256 * i;
-        const int row = idx / KCH;
-        const int c = idx - row * KCH;
-        krow[i] = row;
-        kok[i] = (idx < K_ITEMS) && (c * 8 < d);
-        klds[i] = row * KSTR + c * 8;
-        kptr[i] = Kg + (size_t)row * p.ldk + c * 8;
-    }
-#pragma unroll
-    for (int i = 0; i < V_PER_T; ++i) {
-        const int idx = tid + 256 * i;
-        const int row = idx >> 3;
-        const int c = idx & 7;
-        vok[i] = (idx < V_ITEMS) && (row < d);
-        vone[i] = ONES && (idx < V_ITEMS) && (row == OC);
-        vlds[i] = row * VSTR + c * 8;
-        vptr[i] = Vg + (size_t)row * p.ldvt + c * 8;
-    }
-    const size_t kstep = (size_t)KT * p.ldk;
-    auto load_tile = [&](int key0) {
-#pragma unroll
-        for (int i = 0; i < K_PER_T; ++i) {
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (kok[i] && key0 + krow[i] < Nk) v = ld16(kptr[i]);
-            kptr[i] += kstep;
-            rk[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < V_PER_T; ++i) {
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (vone[i]) v = make_uint4(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u);
-            if (vok[i]) v = ld16(vptr[i]);
-            vptr[i] += KT;
-            rv[i] = v;
-        }
-    };
-    auto store_tile = [&](int buf) {
-        half_t* Ksw = Ksm + buf * KBUF;
-        half_t* Vsw = Vsm + buf * VBUF;
-#pragma unroll
-        for (int i = 0; i < K_PER_T; ++i)
-            if (tid + 256 * i < K_ITEMS) st16(Ksw + klds[i], rk[i]);
-#pragma unroll
-        for (int i = 0; i < V_PER_T; ++i)
-            if (tid + 256 * i < V_ITEMS) {
-                uint2* dst = reinterpret_cast<uint2*>(Vsw + vlds[i]);
-                dst[0] = make_uint2(rv[i].x, rv[i].y);
-                dst[1] = make_uint2(rv[i].z, rv[i].w);
-            }
-    };
-    const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    auto qk = [&](f32x16 (&sd)[2], int buf) {
-        const half_t* Ks = Ksm + buf * KBUF;
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                const half8_t kf = *reinterpret_cast<const half8_t*>(Ks + (kh * 32 + ql) * KSTR + (2 * ks + hi) * 8);
-                sd[kh] = mfma32(kf, qf[ks], ks == 0 ? zero16 : sd[kh]);
-            }
-    };
-    constexpr float DEFER = 8.0f;
-    // softmax of tile `t` (scores in sc) followed by its P.V against V ring slot `vbuf`
-    auto softmax_pv = [&](f32x16 (&sc)[2], int t, int vbuf) {
-        const int key0 = t * KT;
-        if (key0 + KT > Nk) {
-#pragma unroll
-            for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = key0 + kh * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (key >= Nk) sc[kh][r] = -INFINITY;
-                }
-        }
-        auto sv = [&](int i) -> float { return sc[i >> 4][i & 15]; };
-        float tmax = max3f(sv(0), sv(1), sv(2));
-#pragma unroll
-        for (int i = 3; i < 31; i += 2) tmax = max3f(tmax, sv(i), sv(i + 1));
-        tmax = fmaxf(tmax, sv(31));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * c_scale;
-        if (__any(tmax > m_run + DEFER)) {
-            const float m_new = fmaxf(m_run, tmax);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            m_run = m_new;
-            if constexpr (!ONES) l_run *= alpha;
-#pragma unroll
-            for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-        }
-        const float nm = -m_run;
-        float psum = 0.0f;
-        uint4 pf[4];
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const float p0 = __builtin_amdgcn_exp2f(fmaf(sc[kh][r], c_scale, nm));
-                const float p1 = __builtin_amdgcn_exp2f(fmaf(sc[kh][r + 1], c_scale, nm));
-                if constexpr (!ONES) psum += p0 + p1;
-                f32x2 pv = {p0, p1};
-                const half2_t ph = __builtin_convertvector(pv, half2_t);
-                const unsigned pw = *reinterpret_cast<const unsigned*>(&ph);
-                const int j = kh * 2 + (r >> 3);
-                const int e = (r & 7) >> 1;
-                if (e == 0) pf[j].x = pw; else if (e == 1) pf[j].y = pw; else if (e == 2) pf[j].z = pw; else pf[j].w = pw;
-            }
-        if constexpr (!ONES) l_run += psum;
-        const half_t* Vs = Vsm + vbuf * VBUF;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) {
-                const half_t* vrow = Vs + (dt * 32 + ql) * VSTR + 16 * j + 4 * hi;
-                const uint2 lo = *reinterpret_cast<const uint2*>(vrow);
-                const uint2 hi8 = *reinterpret_cast<const uint2*>(vrow + 8);
-                uint4 v4 = make_uint4(lo.x, lo.y, hi8.x, hi8.y);
-                o[dt] = mfma32(*reinterpret_cast<half8_t*>(&v4), *reinterpret_cast<const half8_t*>(&pf[j]), o[dt]);
-            }
-    };
-
-    const int ntiles = (Nk + KT - 1) / KT;
-    // prologue: tiles 0 and 1 into ring slots 0 and 1, tile 2 into registers
-    load_tile(0);
-    store_tile(0);
-    if (ntiles > 1) { load_tile(KT); store_tile(1); }
-    __syncthreads();
-    if (ntiles > 2) load_tile(2 * KT);
-    f32x16 sA[2], sB[2];
-    qk(sA, 0);
-    int bt = 0;            // ring slot of tile t
-    // one step: S(t+1) MFMAs -> softmax/PV of tile t -> refill slot of tile t+2 -> barrier -> prefetch tile t+3
-    auto step = [&](f32x16 (&s_cur)[2], f32x16 (&s_next)[2], int t) {
-        const int b1 = (bt == 2) ? 0 : bt + 1;
-        const int b2 = (b1 == 2) ? 0 : b1 + 1;
-        if (t + 1 < ntiles) qk(s_next, b1);
-        softmax_pv(s_cur, t, bt);
-        if (t + 2 < ntiles) store_tile(b2);     // slot b2 held tile t-1: its readers finished before the previous barrier
-        __syncthreads();
-        if (t + 3 < ntiles) load_tile((t + 3) * KT);
-        bt = b1;
-    };
-    int t = 0;
-    for (; t + 1 < ntiles; t += 2) {
-        step(sA, sB, t);
-        step(sB, sA, t + 1);
-    }
-    if (t < ntiles) step(sA, sB, t);
-
-    float lpart = l_run;
-    if constexpr (ONES) lpart = (hi == 1) ? o[NDT - 1][15] : 0.0f;
-    const float l_tot = lpart + __shfl_xor(lpart, 32, 64);
-    const float inv = 1.0f / l_tot;
-    const int q = q0 + ql;
-    if (q < Nq) {
-        half_t* orow = reinterpret_cast<half_t*>(p.out) + (size_t)b * p.o_bstride + (size_t)q * p.ldo + (size_t)h * d;
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int c = dt * 32 + 8 * rg + 4 * hi;
-                if (c < d) {
-                    half4_t ov;
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) ov[jj] = (half_t)(o[dt][rg * 4 + jj] * inv);
-                    *reinterpret_cast<half4_t*>(orow + c) = ov;
-                }
-            }
-    }
-}
-
 // V [B, Nk, *] -> V^T [B, H, d, ldvt] with zero fill of keys >= Nk.  One block per (64 keys, head, sample): 16-byte
 // global loads (8 channels of one key), a [64][d + 2] LDS tile (row stride chosen so that the 8 key groups of one
 // channel column fall on 8 different banks), 16-byte global stores (8 consecutive keys of one channel; 8 lanes
@@ -573,23 +337,16 @@ int launch_attn(const gl_attn_args& a, hipStream_t st) {
     return 0;
 }
 
-// 64 queries per wave once there are enough query blocks to fill the chip with 256-query tiles
+// 4-wave (128-query) or 8-wave (256-query) blocks.  Round-1 variants that lost (64 queries per wave: 280 registers ->
+// 1 wave/SIMD, 651 vs 479 us; a software-pipelined S(t+1) || softmax(t) kernel with a 3-slot LDS ring: -10 % at d = 40)
+// are recorded in DESIGN.md and no longer compiled.
 template <int DQK>
 int launch_attn_auto(const gl_attn_args& a, hipStream_t st) {
-    // measured on MI355X (d = 40, N = 4096): QT = 2 needs 280 registers -> 1 wave/SIMD and runs 651 us vs
-    // 479 us for QT = 1 at 3 waves/SIMD; occupancy beats staging reuse here, so QT = 2 stays opt-in.
     if constexpr (DQK <= 80) {
-        if (g_attn_qt2 == 1 && a.Nq >= 256) return launch_attn<DQK, 2>(a, st);
         // 8 waves (256 queries) per block halve the K / V^T tile traffic per query: 355 -> 326 us at d = 40,
         // N = 4096 (with the XCD-aware block order); no effect on the 77-key text cross-attention
         if ((g_attn_qt2 == 3 && a.Nq >= 256) || (g_attn_qt2 == 0 && a.Nq >= 512 && a.Nk >= 512))
             return launch_attn<DQK, 1, 8>(a, st);
-        if (g_attn_qt2 == 2 && a.Nk > 128) {
-            dim3 grid(gl_cdiv(a.Nq, 128), a.H, a.B);
-            attn_pipe_kernel<DQK><<<grid, dim3(256), 0, st>>>(a);
-            GL_CHECK_LAUNCH();
-            return 0;
-        }
     }
     return launch_attn<DQK, 1>(a, st);
 }

@@ -6,27 +6,25 @@
 // of an NHWC feature map for a 3x3 / pad 1 convolution (stride 1, stride 2, or nearest-2x-upsampled
 // input).  A K-tile never straddles a filter tap because Cin % 64 == 0.
 //
-// Tiling: 256 threads = 4 waves; block tile BM x BN (128x128, 128x160 or 256x64), MFMA 32x32 tiles,
-// fp32 accumulators.  Operand tiles go global -> LDS directly (global_load_lds_dwordx4: a wave's 64
+// Tiling: 256 threads = 4 waves; block tile BM x BN (128x128, 128x160, 256x64, 64x128, 256x128/160), MFMA 32x32
+// tiles, fp32 accumulators.  Operand tiles go global -> LDS directly (global_load_lds_dwordx4: a wave's 64
 // lanes fill 1 KiB of consecutive LDS = 8 or 16 tile rows), so the LDS image is lane-linear and the
 // bank-conflict swizzle is applied to the per-lane GLOBAL source chunk and, identically, to the
 // fragment reads (chunk' = chunk ^ f(row); f = (row>>1)&7 for 128-byte rows, (row>>2)&3 for 64-byte
 // rows: conflict-free for the 16-lane groups of ds_read_b128).  Masked lanes (rows past M/N, the conv
 // halo) read a 16-byte zero page, since LDS-DMA cannot be predicated per lane.
 //
-// Two pipelines (gl_set_option key 1):
-//   BK=64, 2 LDS stages : (default) tile t+1 is requested before the MFMAs of tile t; s_waitcnt vmcnt(0) +
-//                         barrier per K-tile.  PMC on the level-0 convs: waves wait 39 % of their lifetime,
-//                         MFMA pipe 31 % busy.
-//   BK=32, 3 LDS stages : tiles t+1 and t+2 are in flight during the MFMAs of tile t; the wait before each
-//                         barrier is a COUNTED vmcnt (only tile t must have landed) and the barrier is a raw
-//                         s_barrier (a __syncthreads would drain the LDS-DMA queue).  Measured 15-25 % SLOWER
-//                         than BK=64 on every shape of this UNet (twice the barriers and fragment-read
-//                         restarts per K outweigh the deeper prefetch), so it is kept only as an A/B knob.
+// Pipeline: BK = 64 (BK = 32 for the short-K GEGLU projections and the 256-row tiles), 2 LDS stages: tile t+1 is
+// requested before the MFMAs of tile t; s_waitcnt vmcnt(0) + barrier per K-tile.  The round-1 experiments that lost
+// to it (BK 32 / 3-4 stage rings with counted vmcnt, BK 128, 8-wave 256-row tiles, a halo-resident conv) are recorded
+// in DESIGN.md section 3 and no longer compiled.
 //
 // The MFMA is issued "swapped" (weights as the row operand, activations as the column operand) and the
 // epilogue restages the fp32 tile through LDS so that outputs, residuals and row-biases move as
 // 16-byte row-contiguous accesses; GEGLU pairs x|gate columns that the weight packing interleaved.
+//
+// Residual stream: with res_f32 / GL_OUT_F32_ROWMAJOR the residual is read and the sum written in fp32 (plus an
+// optional fp16 copy for matrix-core consumers), so chained residual adds are never rounded to fp16.
 #include "common.h"
 #include "gligen_hip.h"
 
@@ -35,14 +33,9 @@ __device__ uint4 g_zero16[4];
 
 namespace {
 
-int g_opt_big_kind = 1;     // which 256-row variant g_opt_big selects: 0 = 8 waves BK 64 / 3-stage, 1 = 4 waves BK 32 / 2-stage
-int g_opt_halo = 0;          // halo-resident conv kernel: 0 off, 1 auto (enough tiles), 2 whenever the geometry allows
-int g_opt_halo_tiles = 64;
-int g_opt_ksplit = 1;        // intra-block K-split variants (64-row wave tiles): 0 off, 1 auto (long K, no split-K), 2 always
-int g_opt_dbg = 0;           // measurement-only loop ablation, see the NST == 2 main loop
-int g_opt_geglu32 = 1;      // 1 = short-K GEGLU GEMMs use the 4-blocks/CU BK 32 variant
-int g_opt_pipe = 0;          // 0 = BK 64 / 2-stage (default, faster), 1 = BK 32 / 3-stage counted-vmcnt pipeline
-int g_opt_big = 300;          // problems with >= this many 256-row tiles use the 256-row variant (B=4: neutral; B=16: +5-7 %); 0 = off
+int g_opt_ksplit = 1;        // intra-block K-split variants (64-row wave tiles): 0 off, 1 auto (long K), 2 always
+int g_opt_geglu32 = 1;       // 1 = short-K GEGLU GEMMs use the 4-blocks/CU BK 32 variant
+int g_opt_big = 300;         // problems with >= this many 256-row tiles use the 256-row variant (B=4: neutral; B=16: +5-7 %); 0 = off
 int g_opt_small = 400;       // use 64x128 tiles when the 128-row grid has fewer tiles than this (0 = never)
 int g_opt_splitk_tiles = 300; // split K only below this many tiles (plain GEMM) ...
 int g_opt_splitk_tiles_conv = 450; // ... (conv)
@@ -54,11 +47,7 @@ struct ConvGeom {
     int B, Hin, Win, Cin, Hout, Wout, stride, ups;
 };
 
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
+__device__ __forceinline__ void wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 __device__ __forceinline__ void glds16(const half_t* src, half_t* dst) {
     __builtin_amdgcn_global_load_lds(
@@ -66,23 +55,77 @@ __device__ __forceinline__ void glds16(const half_t* src, half_t* dst) {
         reinterpret_cast<__attribute__((address_space(3))) void*>(reinterpret_cast<uintptr_t>(dst)), 16, 0, 0);
 }
 
-template <int BM, int BN, int BKT, int NST, int NW = 4>
+template <int BM, int BN, int BKT, int NW = 4>
 constexpr int lds_bytes() {
-    constexpr int pipe = NST * (BM + BN) * BKT * (int)sizeof(half_t);
+    constexpr int pipe = 2 * (BM + BN) * BKT * (int)sizeof(half_t);
     constexpr int epi = NW * 32 * 68 * (int)sizeof(float);    // epilogue staging: NW waves x 32 rows x (64+4) fp32
     return pipe > epi ? pipe : epi;
 }
 
-// occupancy hint: the 3-stage BK=32 128x128 kernel needs 48 KiB of LDS (3 blocks/CU) but ~178 registers;
-// asking for 3 waves/SIMD makes the compiler fit 170 so that the third block is actually resident.
-template <int BM, int BN, int BKT, int NST, int WK = 1>
+// occupancy hints (waves per SIMD the register allocator must leave room for)
+template <int BM, int BN, int BKT, int WK = 1>
 constexpr int min_waves() {
     if (WK > 1) return 2;
-    if (BM == 128 && BN == 160 && BKT == 32 && NST == 2 && WK == 1) return 2;   // (2-wave 64x160 variant shares this key: needs 2)
     if (BKT != 32) return 1;
-    if (BM * BN >= 256 * 128) return NST == 2 ? 2 : 1;
-    if (BM * BN <= 128 * 128) return NST == 2 ? 4 : 3;
-    return NST == 2 ? 3 : 1;
+    if (BM * BN >= 256 * 128) return 2;
+    if (BM * BN <= 128 * 128) return 4;
+    return 3;
+}
+
+// One 8-column piece of one output row: bias / activation / residual, then the stores.  Shared by the GEMM epilogue
+// and the split-K reduction so that both produce bit-identical results from the same fp32 sums.
+__device__ __forceinline__ void finish8(const gl_gemm_args& p, float gate, int m, int n, float (&v)[8]) {
+    const int epi = p.epi;
+    if (p.bias) {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n);
+        const float4 b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+        v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+    }
+    if (epi == GL_EPI_SILU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = silu_f(v[j]);
+    } else if (epi == GL_EPI_RES || epi == GL_EPI_GATE_RES) {
+        float r[8];
+        if (p.res_f32) {
+            const float* rp = reinterpret_cast<const float*>(p.res) + (size_t)m * p.ldres + n;
+            const float4 r0 = *reinterpret_cast<const float4*>(rp);
+            const float4 r1 = *reinterpret_cast<const float4*>(rp + 4);
+            r[0] = r0.x; r[1] = r0.y; r[2] = r0.z; r[3] = r0.w; r[4] = r1.x; r[5] = r1.y; r[6] = r1.z; r[7] = r1.w;
+        } else {
+            uint4 raw = ld16(reinterpret_cast<const half_t*>(p.res) + (size_t)m * p.ldres + n);
+            const half8_t rv = *reinterpret_cast<half8_t*>(&raw);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = (float)rv[j];
+        }
+        if (epi == GL_EPI_RES) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += r[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = r[j] + gate * v[j];
+        }
+    } else if (epi == GL_EPI_ROWBIAS) {
+        const int sidx = m / p.rows_per_sample;
+        uint4 raw = ld16(reinterpret_cast<const half_t*>(p.rowbias) + (size_t)sidx * p.ld_rowbias + n);
+        const half8_t rv = *reinterpret_cast<half8_t*>(&raw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += (float)rv[j];
+    }
+    half_t* o16 = reinterpret_cast<half_t*>(p.out);
+    int ld16o = p.ldc;
+    if (p.out_mode == GL_OUT_F32_ROWMAJOR) {
+        float* o = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n;
+        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        o16 = reinterpret_cast<half_t*>(p.out2);
+        ld16o = p.ldc2;
+        if (o16 == nullptr) return;
+    }
+    half8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (half_t)v[j];
+    st16(o16 + (size_t)m * ld16o + n, *reinterpret_cast<uint4*>(&o));
 }
 
 // WK = 2: intra-block K split.  The waves form two groups that own the SAME output rows/columns but alternate
@@ -90,34 +133,25 @@ constexpr int min_waves() {
 // (TM + TN) / (TM * TN) LDS fragment reads per MFMA drop from 1.2 to 0.7 (128x160) -- the CU's LDS port, shared by
 // the LDS-DMA writes and the fragment reads, is what bounds the main loop (loop ablation).  The two
 // partial accumulators are exchanged through LDS in the epilogue: each wave ends up finalising 32 rows.
-//
-// HALO = true (stride-1 3x3 convs whose 256-pixel row tile is a whole number of image rows): instead of one A tile per
-// (channel block, tap) -- nine shifted copies of the same pixels, each fetched from L2 into LDS -- the block keeps ONE
-// input patch per 64-channel block resident in LDS, (rows + 2) x (W + 2) pixels including the zero halo, and the nine
-// taps read their A fragments from it at a shifted pixel offset.  The patch of the next channel block streams in
-// during taps 1..7 (one 64-pixel pass per K-step).  L2 -> LDS traffic per channel block drops from
-// 9 x (256 + 160) to 448 + 9 x 160 rows of 128 B (-50 %), LDS-DMA writes likewise; 8 waves, K-split wave tiles.
-constexpr int PATCH_PX = 448;      // patch rows reserved in LDS: (256/W + 2) * (W + 2) <= 396 for W = 64, 32, 16
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, int BKT, int NST, int WK = 1, bool HALO = false>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT, NST, WK>())) void gemm_kernel(gl_gemm_args p, ConvGeom cg, int splitk, int kt_per_split, int dbg) {
-    constexpr int NTHR = 64 * WAVES_M * WAVES_N * WK;  // 4 waves (256 threads) or 8 waves (512 threads, 256-row tiles)
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, int BKT, int WK = 1>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT, WK>())) void gemm_kernel(gl_gemm_args p, ConvGeom cg, int splitk, int kt_per_split) {
+    constexpr int NTHR = 64 * WAVES_M * WAVES_N * WK;
     constexpr int TM = BM / WAVES_M / 32;
     constexpr int TN = BN / WAVES_N / 32;
     constexpr int CPR = BKT / 8;                 // 16-byte chunks per tile row (8 or 4)
     constexpr int RPP = NTHR / CPR;              // tile rows covered by one pass of the block's threads
     constexpr int RPW = 64 / CPR;                // tile rows covered by one wave instruction (1 KiB)
-    constexpr int APASS = HALO ? PATCH_PX / RPP : (BM + RPP - 1) / RPP;
+    constexpr int APASS = (BM + RPP - 1) / RPP;
     constexpr int BPASS = (BN + RPP - 1) / RPP;
     constexpr int KSTEPS = BKT / 16;
-    static_assert(WAVES_M * WAVES_N * WK == 2 || WAVES_M * WAVES_N * WK == 4 || WAVES_M * WAVES_N * WK == 8, "2, 4 or 8 waves");
+    static_assert(WAVES_M * WAVES_N * WK == 4, "4 waves");
     static_assert(WK == 1 || (WK == 2 && TM == 2 && KSTEPS % 2 == 0), "K-split: two groups, two 32-row tiles per wave");
     static_assert(BM % RPW == 0 && BN % RPW == 0, "whole wave instructions");
-    static_assert(BKT == 128 || BKT == 64 || BKT == 32, "BK");
-    static_assert(!HALO || (CONV && WK == 2 && BM == 256 && BKT == 64 && NST == 2 && NTHR == 512), "halo conv geometry");
+    static_assert(BKT == 64 || BKT == 32, "BK");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    half_t* As = reinterpret_cast<half_t*>(smem);   // [NST][BM][BKT]
-    half_t* Bs = As + (HALO ? 2 * PATCH_PX : NST * BM) * BKT;   // [NST][BN][BKT]; HALO: As = [2][PATCH_PX][64]
+    half_t* As = reinterpret_cast<half_t*>(smem);   // [2][BM][BKT]
+    half_t* Bs = As + 2 * BM * BKT;                 // [2][BN][BKT]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -149,7 +183,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
 
     const int srow = tid / CPR;      // staging row within a pass
     const int skc = tid % CPR;       // LDS chunk slot within the row
-    auto swz = [](int r) -> int { return BKT == 128 ? (r & 15) : (BKT == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3)); };
+    auto swz = [](int r) -> int { return BKT == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3); };
 
     const half_t* __restrict__ Ag = reinterpret_cast<const half_t*>(p.a);
     const half_t* __restrict__ A2g = reinterpret_cast<const half_t*>(p.a2);
@@ -171,20 +205,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
         const int m = m0 + r;
         const bool rowok = (r < BM) && (m < M);
         aptr[i] = zsrc; cmask[i] = 0u; cbyx[i] = -1;
-        if constexpr (HALO) {
-            // pass i stages patch pixels 64 i .. 64 i + 63 (this thread: pixel r, 16-byte chunk skc of its 64 channels)
-            const int hw = cg.Hin * cg.Win;
-            const int b = m0 / hw;
-            const int oy0 = (m0 - b * hw) / cg.Win;
-            const int pw = cg.Win + 2;
-            const int py = r / pw;
-            const int px = r - py * pw;
-            const int iy = oy0 + py - 1, ix = px - 1;
-            if (r < (BM / cg.Win + 2) * pw && iy >= 0 && iy < cg.Hin && ix >= 0 && ix < cg.Win) {
-                aptr[i] = cg.in + ((size_t)(b * cg.Hin + iy) * cg.Win + ix) * cg.Cin + gc;
-                amask |= 1u << i;
-            }
-        } else if constexpr (CONV) {
+        if constexpr (CONV) {
             if (rowok) {
                 const int hw = cg.Hout * cg.Wout;
                 const int b = m / hw;
@@ -222,13 +243,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
         if (ok) bmask |= 1u << i;
     }
 
-    // number of LDS-DMA instructions THIS wave issues per tile (passes whose rows exist for this wave)
-    int my_loads = 0;
-#pragma unroll
-    for (int i = 0; i < APASS; ++i) my_loads += (RPP * i + wave * RPW < BM) ? 1 : 0;
-#pragma unroll
-    for (int i = 0; i < BPASS; ++i) my_loads += (RPP * i + wave * RPW < BN) ? 1 : 0;
-
     auto issue_tile = [&](int kt, int buf) {
         const int k0 = kt * BKT;
         if constexpr (CONV) {
@@ -240,18 +254,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
             const int ci0 = (cblk << 6) + (k0 & 63);
             const int ky = tap / 3;
             const int kx = tap - ky * 3;
-            if constexpr (HALO) {
-                // with the W tile of (cblk, tap) goes patch pass tap-1 of channel block cblk+1 (taps 1..7): its buffer,
-                // (cblk+1) & 1, was last read while (cblk-1, 8) was computed, one barrier before (cblk, 1) is issued
-                if (tap >= 1 && tap <= APASS && (cblk + 1) * 9 < kt_end) {
-                    half_t* dst = As + (size_t)(((cblk + 1) & 1) * PATCH_PX + wave * RPW) * BKT;
-                    const int coff = (cblk + 1) << 6;
-#pragma unroll
-                    for (int i = 0; i < APASS; ++i)
-                        if (i == tap - 1)
-                            glds16(((amask >> i) & 1u) ? aptr[i] + coff : zsrc, dst + (size_t)(RPP * i) * BKT);
-                }
-            } else if (!cg.ups) {
+            if (!cg.ups) {
                 const int off = ((ky - 1) * cg.Win + (kx - 1)) * cg.Cin + ci0;    // wave-uniform
 #pragma unroll
                 for (int i = 0; i < APASS; ++i) {
@@ -277,6 +280,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
         } else {
             if (A2g != nullptr && k0 == p.ksplit && k0 != k_first) {
                 // two-source A: crossing into the second matrix (th.cat folded into the GEMM), once per block
+                // (ksplit % BKT == 0 is validated by the launcher)
 #pragma unroll
                 for (int i = 0; i < APASS; ++i) {
                     const int r = srow + RPP * i;
@@ -310,26 +314,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
     const int frow = lane & 31;
     const int fhi = lane >> 5;
 
-    // HALO: patch row of output pixel q = wm*64 + mi*32 + frow at tap (0,0): (q / W) * (W + 2) + q % W
-    int prow0[TM];
-#pragma unroll
-    for (int mi = 0; mi < TM; ++mi) {
-        prow0[mi] = 0;
-        if constexpr (HALO) {
-            const int q = wm * (TM * 32) + mi * 32 + frow;
-            const int dy = q / cg.Win;
-            prow0[mi] = dy * (cg.Win + 2) + (q - dy * cg.Win);
-        }
-    }
-    auto compute_tile = [&](int buf, int kt) {
-        int abase = 0;                                   // HALO: first LDS row of this tile's A operand
-        if constexpr (HALO) {
-            const int cblk = kt / 9;
-            const int tap = kt - cblk * 9;
-            const int ky = tap / 3;
-            abase = (cblk & 1) * PATCH_PX + ky * (cg.Win + 2) + (tap - ky * 3);
-        }
-        if (dbg & 4) __builtin_amdgcn_s_setprio(1);      // A/B: priority over the co-resident block's DMA issue
+    auto compute_tile = [&](int buf) {
 #pragma unroll
         for (int kq = 0; kq < KSTEPS / WK; ++kq) {
             half8_t xf[TM], wf[TN];
@@ -337,13 +322,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
             const int c = ks * 2 + fhi;
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi) {
-                if constexpr (HALO) {
-                    const int r = abase + prow0[mi];     // swizzle follows the LDS row, i.e. the patch pixel
-                    xf[mi] = *reinterpret_cast<const half8_t*>(As + (size_t)r * BKT + ((c ^ swz(r)) << 3));
-                } else {
-                    const int r = wm * (TM * 32) + mi * 32 + frow;
-                    xf[mi] = *reinterpret_cast<const half8_t*>(As + (size_t)(buf * BM + r) * BKT + ((c ^ swz(r)) << 3));
-                }
+                const int r = wm * (TM * 32) + mi * 32 + frow;
+                xf[mi] = *reinterpret_cast<const half8_t*>(As + (size_t)(buf * BM + r) * BKT + ((c ^ swz(r)) << 3));
             }
             if constexpr (WK == 2) {
                 // 160 accumulator registers: keep ONE weight fragment live at a time (each feeds both m-tiles)
@@ -366,68 +346,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
                     for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = mfma32(wf[ni], xf[mi], acc[mi][ni]);
             }
         }
-        if (dbg & 4) __builtin_amdgcn_s_setprio(0);
     };
 
-    if constexpr (NST == 2) {
-        // dbg (gl_set_option 12, measurement only -- results are garbage): bit 0 skips the MFMA / fragment-read
-        // half of the loop, bit 1 skips the global -> LDS half; isolates which side bounds a shape
-        if constexpr (HALO) {
-            // whole patch of the first channel block of this K range
-            const int cb0 = kt_begin / 9;
-#pragma unroll
-            for (int i = 0; i < APASS; ++i)
-                glds16(((amask >> i) & 1u) ? aptr[i] + (cb0 << 6) : zsrc,
-                       As + (size_t)((cb0 & 1) * PATCH_PX + RPP * i + wave * RPW) * BKT);
-        }
-        issue_tile(kt_begin, 0);
-        wait_vmcnt<0>();
-        __syncthreads();
-        for (int it = 0; it < nkt; ++it) {
-            const int buf = it & 1;
-            if (it + 1 < nkt && !(dbg & 2)) issue_tile(kt_begin + it + 1, buf ^ 1);
-            if (!(dbg & 1)) compute_tile(buf, kt_begin + it);
-            wait_vmcnt<0>();
-            __syncthreads();
-        }
-    } else {
-        // NST-stage ring (NST = 3 or 4), prefetch distance D = NST - 1 tiles.  Invariant at the top of iteration `it`:
-        // tiles it .. it+D-1 have been requested.  The counted wait leaves the newest D-1 tiles' loads (my_loads each,
-        // per wave) in flight; loads retire in issue order, so tile `it` has landed for this wave, and after the
-        // barrier for all waves.  The buffer refilled right after the barrier, (it+D) % NST, was last read in
-        // iteration it-1, which every wave has finished before arriving at this barrier.
-        constexpr int D = NST - 1;
-#pragma unroll
-        for (int j = 0; j < D; ++j)
-            if (j < nkt) issue_tile(kt_begin + j, j);
-        int buf = 0;
-        for (int it = 0; it < nkt; ++it) {
-            if (it + D - 1 < nkt) {
-                switch (my_loads * (D - 1)) {
-                    case 2: wait_vmcnt<2>(); break;
-                    case 3: wait_vmcnt<3>(); break;
-                    case 4: wait_vmcnt<4>(); break;
-                    case 5: wait_vmcnt<5>(); break;
-                    case 6: wait_vmcnt<6>(); break;
-                    case 7: wait_vmcnt<7>(); break;
-                    case 8: wait_vmcnt<8>(); break;
-                    case 10: wait_vmcnt<10>(); break;
-                    case 12: wait_vmcnt<12>(); break;
-                    case 14: wait_vmcnt<14>(); break;
-                    case 16: wait_vmcnt<16>(); break;
-                    case 18: wait_vmcnt<18>(); break;
-                    default: wait_vmcnt<0>(); break;
-                }
-            } else {
-                wait_vmcnt<0>();          // tail: fewer than D-1 younger tiles exist; draining is exact enough
-            }
-            __builtin_amdgcn_s_barrier();
-            int nbuf = buf + D;
-            if (nbuf >= NST) nbuf -= NST;
-            if (it + D < nkt) issue_tile(kt_begin + it + D, nbuf);
-            compute_tile(buf, kt_begin + it);
-            buf = (buf == NST - 1) ? 0 : buf + 1;
-        }
+    issue_tile(kt_begin, 0);
+    wait_vmcnt0();
+    __syncthreads();
+    for (int it = 0; it < nkt; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < nkt) issue_tile(kt_begin + it + 1, buf ^ 1);
+        compute_tile(buf);
+        wait_vmcnt0();
         __syncthreads();
     }
 
@@ -510,8 +438,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
 
     // ------------------------------------------------------------------ epilogue
     const float* __restrict__ bias = p.bias;
-    const half_t* __restrict__ res = reinterpret_cast<const half_t*>(p.res);
-    const half_t* __restrict__ rowbias = reinterpret_cast<const half_t*>(p.rowbias);
     const int epi = p.epi;
     float gate = 1.0f;
     if (epi == GL_EPI_GATE_RES) gate = p.gate[0];
@@ -538,7 +464,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
         return;
     }
 
-    // Row-major fp16 output: the fp32 accumulator tile of each wave is staged through LDS (the operand
+    // Row-major output: the fp32 accumulator tile of each wave is staged through LDS (the operand
     // buffers are dead by now), 32 rows x 64 columns (two MFMA tiles) at a time, so that every lane then
     // owns 8 CONSECUTIVE channels of one row: residual / row-bias reads and the output stores are 16-byte
     // accesses, 128 contiguous bytes per row per 8 lanes, instead of 8-byte pieces scattered over 32 rows
@@ -609,36 +535,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
                         const float4 a0 = *reinterpret_cast<const float4*>(stage + r * EPS + c);
                         const float4 a1 = *reinterpret_cast<const float4*>(stage + r * EPS + c + 4);
                         float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-                        if (bias) {
-                            const float4 b0 = *reinterpret_cast<const float4*>(bias + n);
-                            const float4 b1 = *reinterpret_cast<const float4*>(bias + n + 4);
-                            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-                            v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-                        }
-                        if (epi == GL_EPI_SILU) {
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) v[j] = silu_f(v[j]);
-                        } else if (epi == GL_EPI_RES || epi == GL_EPI_GATE_RES) {
-                            uint4 raw = ld16(res + (size_t)m * p.ldres + n);
-                            const half8_t rv = *reinterpret_cast<half8_t*>(&raw);
-                            if (epi == GL_EPI_RES) {
-#pragma unroll
-                                for (int j = 0; j < 8; ++j) v[j] += (float)rv[j];
-                            } else {
-#pragma unroll
-                                for (int j = 0; j < 8; ++j) v[j] = (float)rv[j] + gate * v[j];
-                            }
-                        } else if (epi == GL_EPI_ROWBIAS) {
-                            const int sidx = m / p.rows_per_sample;
-                            uint4 raw = ld16(rowbias + (size_t)sidx * p.ld_rowbias + n);
-                            const half8_t rv = *reinterpret_cast<half8_t*>(&raw);
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) v[j] += (float)rv[j];
-                        }
-                        half8_t o;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) o[j] = (half_t)v[j];
-                        st16(outp + (size_t)m * p.ldc + n, *reinterpret_cast<uint4*>(&o));
+                        finish8(p, gate, m, n, v);
                     }
                 }
             }
@@ -646,66 +543,41 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
     }
 }
 
-// Sums the split-K partial tiles and applies the epilogue (fp16 row-major outputs only).
+// Sums the split-K partial tiles and applies the epilogue (row-major outputs only).
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(gl_gemm_args p, int splitk) {
     const int M = p.M, N = p.N;
-    const int nq = N / 4;
+    const int nq = N / 8;
     const size_t total = (size_t)M * nq;
     const float* ws = reinterpret_cast<const float*>(p.workspace);
-    const half_t* res = reinterpret_cast<const half_t*>(p.res);
-    const half_t* rowbias = reinterpret_cast<const half_t*>(p.rowbias);
-    half_t* out = reinterpret_cast<half_t*>(p.out);
     float gate = 1.0f;
     if (p.epi == GL_EPI_GATE_RES) gate = p.gate[0];
     const size_t zstride = (size_t)M * N;
     for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < (unsigned)total; idx += gridDim.x * 256u) {
         const int m = (int)(idx / (unsigned)nq);
-        const int n = (int)(idx - (unsigned)m * (unsigned)nq) * 4;
+        const int n = (int)(idx - (unsigned)m * (unsigned)nq) * 8;
         const float* src = ws + (size_t)m * N + n;
         float4 a = *reinterpret_cast<const float4*>(src);
-        // slices are added in index order (deterministic); 4 independent loads in flight per step instead of a
-        // load -> wait -> add chain per slice
+        float4 c = *reinterpret_cast<const float4*>(src + 4);
+        // slices are added in index order (deterministic); independent loads in flight instead of a load -> wait -> add chain
         int z = 1;
-        for (; z + 3 < splitk; z += 4) {
+        for (; z + 1 < splitk; z += 2) {
             const float4 b0 = *reinterpret_cast<const float4*>(src + (size_t)z * zstride);
+            const float4 d0 = *reinterpret_cast<const float4*>(src + (size_t)z * zstride + 4);
             const float4 b1 = *reinterpret_cast<const float4*>(src + (size_t)(z + 1) * zstride);
-            const float4 b2 = *reinterpret_cast<const float4*>(src + (size_t)(z + 2) * zstride);
-            const float4 b3 = *reinterpret_cast<const float4*>(src + (size_t)(z + 3) * zstride);
+            const float4 d1 = *reinterpret_cast<const float4*>(src + (size_t)(z + 1) * zstride + 4);
             a.x += b0.x; a.y += b0.y; a.z += b0.z; a.w += b0.w;
+            c.x += d0.x; c.y += d0.y; c.z += d0.z; c.w += d0.w;
             a.x += b1.x; a.y += b1.y; a.z += b1.z; a.w += b1.w;
-            a.x += b2.x; a.y += b2.y; a.z += b2.z; a.w += b2.w;
-            a.x += b3.x; a.y += b3.y; a.z += b3.z; a.w += b3.w;
+            c.x += d1.x; c.y += d1.y; c.z += d1.z; c.w += d1.w;
         }
         for (; z < splitk; ++z) {
             const float4 b = *reinterpret_cast<const float4*>(src + (size_t)z * zstride);
+            const float4 d = *reinterpret_cast<const float4*>(src + (size_t)z * zstride + 4);
             a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            c.x += d.x; c.y += d.y; c.z += d.z; c.w += d.w;
         }
-        float v[4] = {a.x, a.y, a.z, a.w};
-        if (p.bias) {
-            const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
-            v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-        }
-        if (p.epi == GL_EPI_SILU) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
-        } else if (p.epi == GL_EPI_RES) {
-            const half4_t rv = *reinterpret_cast<const half4_t*>(res + (size_t)m * p.ldres + n);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] += (float)rv[j];
-        } else if (p.epi == GL_EPI_GATE_RES) {
-            const half4_t rv = *reinterpret_cast<const half4_t*>(res + (size_t)m * p.ldres + n);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = (float)rv[j] + gate * v[j];
-        } else if (p.epi == GL_EPI_ROWBIAS) {
-            const int sidx = m / p.rows_per_sample;
-            const half4_t rv = *reinterpret_cast<const half4_t*>(rowbias + (size_t)sidx * p.ld_rowbias + n);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] += (float)rv[j];
-        }
-        half4_t o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (half_t)v[j];
-        *reinterpret_cast<half4_t*>(out + (size_t)m * p.ldc + n) = o;
+        float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+        finish8(p, gate, m, n, v);
     }
 }
 
@@ -713,7 +585,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(gl_gemm_args p, int 
 // the fp32 partial round trip.
 inline int choose_splitk(const gl_gemm_args& g, int tiles, bool conv) {
     const int nk = g.K / 64;
-    if (!g.workspace || g.epi == GL_EPI_GEGLU || g.out_mode != GL_OUT_F16_ROWMAJOR) return 1;
+    if (!g.workspace || g.epi == GL_EPI_GEGLU || g.out_mode == GL_OUT_F32_NCHW) return 1;
     // convs (long K, weights streamed once per row tile) profit up to ~1.7 tiles per CU: the 32x32-level
     // convs launch exactly 256 tiles and went 604 -> 694 TF/s with 2 K-slices; plain GEMMs only below ~300
     if (tiles >= (conv ? g_opt_splitk_tiles_conv : g_opt_splitk_tiles) || nk < g_opt_splitk_nk) return 1;
@@ -724,19 +596,20 @@ inline int choose_splitk(const gl_gemm_args& g, int tiles, bool conv) {
     return s < 2 ? 1 : s;
 }
 
-template <int BM, int BN, int WM, int WN, bool CONV, int BKT, int NST, int WK = 1>
+template <int BM, int BN, int WM, int WN, bool CONV, int BKT, int WK = 1>
 int launch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
+    if (g.a2 != nullptr && (g.ksplit % BKT) != 0) return GL_ERR_BAD_ARG;    // the two-source crossover happens on a K-tile edge
     const int mt = gl_cdiv(g.M, BM), nt = gl_cdiv(g.N, BN);
     const int nk = g.K / BKT;
     int splitk = choose_splitk(g, mt * nt, CONV);
     int kper = gl_cdiv(nk, splitk);
     const int zs = gl_cdiv(nk, kper);          // slices that actually have work
     dim3 grid(mt * nt, 1, zs);
-    constexpr int lds = lds_bytes<BM, BN, BKT, NST, WM * WN * WK>();
-    gemm_kernel<BM, BN, WM, WN, CONV, BKT, NST, WK><<<grid, dim3(64 * WM * WN * WK), lds, st>>>(g, cg, zs, kper, g_opt_dbg);
+    constexpr int lds = lds_bytes<BM, BN, BKT, WM * WN * WK>();
+    gemm_kernel<BM, BN, WM, WN, CONV, BKT, WK><<<grid, dim3(64 * WM * WN * WK), lds, st>>>(g, cg, zs, kper);
     GL_CHECK_LAUNCH();
     if (zs > 1) {
-        const size_t total = (size_t)g.M * (g.N / 4);
+        const size_t total = (size_t)g.M * (g.N / 8);
         int nblk = (int)((total + 255) / 256);
         if (nblk > 2048) nblk = 2048;
         splitk_reduce_kernel<<<dim3(nblk), dim3(256), 0, st>>>(g, zs);
@@ -745,45 +618,14 @@ int launch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     return 0;
 }
 
-// halo-resident 3x3 conv (see gemm_kernel, HALO): 256-pixel row tiles, 8 waves, one block per CU
-constexpr int lds_bytes_halo(int bn) { return (2 * PATCH_PX + 2 * bn) * 64 * (int)sizeof(half_t); }
-
-inline bool halo_conv_ok(const gl_gemm_args& g, const ConvGeom& cg) {
-    const int hw = cg.Hin * cg.Win;
-    return cg.stride == 1 && !cg.ups && cg.Hin == cg.Hout && cg.Win == cg.Wout && cg.Win >= 16 && (256 % cg.Win) == 0 &&
-           (hw % 256) == 0 && (256 / cg.Win + 2) * (cg.Win + 2) <= PATCH_PX && (cg.Cin % 64) == 0 && (g.N % 160) == 0 &&
-           g.out_mode == GL_OUT_F16_ROWMAJOR && g.epi != GL_EPI_GEGLU;
-}
-
-int launch_halo(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
-    constexpr int BN = 160;
-    const int mt = g.M / 256, nt = gl_cdiv(g.N, BN);
-    const int ncb = cg.Cin / 64;                       // K-tiles come in groups of 9 taps per 64-channel block
-    gl_gemm_args gk = g;
-    int splitk = choose_splitk(gk, mt * nt, true);
-    if (splitk > ncb) splitk = ncb;
-    const int cb_per = gl_cdiv(ncb, splitk);
-    const int zs = gl_cdiv(ncb, cb_per);
-    dim3 grid(mt * nt, 1, zs);
-    gemm_kernel<256, BN, 4, 1, true, 64, 2, 2, true><<<grid, dim3(512), lds_bytes_halo(BN), st>>>(g, cg, zs, 9 * cb_per, g_opt_dbg);
-    GL_CHECK_LAUNCH();
-    if (zs > 1) {
-        const size_t total = (size_t)g.M * (g.N / 4);
-        int nblk = (int)((total + 255) / 256);
-        if (nblk > 2048) nblk = 2048;
-        splitk_reduce_kernel<<<dim3(nblk), dim3(256), 0, st>>>(g, zs);
-        GL_CHECK_LAUNCH();
-    }
-    return 0;
-}
-
-template <bool CONV, int BKT, int NST>
+template <bool CONV, int BKT>
 int dispatch_shape(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     // tile shape: 128x160 (4 waves x 32x160) when it divides N exactly -- N = 320/640/960/... are the
     // channel widths of this UNet and 128-wide tiles would waste up to 17 % of the MFMA work there
     // (convs, whose K is long, prefer it even when 128 also divides N: measured 442 vs 408 and 607 vs 536 TF/s
     // at the 32x32 and 16x16 levels); otherwise 128x128; 256x64 only for narrow outputs.
     const bool geglu = (g.epi == GL_EPI_GEGLU);
+    const bool rowmajor = (g.out_mode != GL_OUT_F32_NCHW);
     int shape = 0;                                   // 0: 128x128, 1: 128x160, 2: 256x64, 3: 64x128
     if (g.N < 256 && (g.N % 128) != 0) shape = 2;
     else if (!geglu && (g.N % 160) == 0 && ((g.N % 128) != 0 || CONV || g_opt_tile == 2)) shape = 1;
@@ -796,63 +638,59 @@ int dispatch_shape(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
         const long t128 = (long)gl_cdiv(g.M, 128) * gl_cdiv(g.N, shape == 1 ? 160 : 128);
         if (t128 < g_opt_small) shape = 3;
     }
-    // intra-block K-split (64-row wave tiles, 0.7-0.75 LDS fragment reads per MFMA): +7-18 % on every conv of the
-    // UNet (with or without split-K slices: the two K groups are combined in LDS before a partial slice is written)
-    // and on K >= 1024 GEMMs; its accumulator exchange in the epilogue costs 5-20 % on short K (the K = 320 / 640
-    // projections), which stay on the 4 x (32 x BN) kernels (per-shape A/B in DESIGN.md)
-    if constexpr (BKT == 64 && NST == 2) {
-        // experiment (key 7 = tile threshold, key 9 = 2): 256-row K-split tile, 8 waves, 3-stage ring -- one block per
-        // CU with TWO K-tiles of loads in flight (106 KB) instead of two blocks with one each (74 KB)
-        if (g_opt_big && g_opt_big_kind == 2 && g.out_mode == GL_OUT_F16_ROWMAJOR && (shape == 0 || shape == 1) && g.M >= 256) {
-            const long t256 = (long)gl_cdiv(g.M, 256) * gl_cdiv(g.N, shape == 1 ? 160 : 128);
-            if (t256 >= g_opt_big) {
-                if (shape == 1) return launch<256, 160, 4, 1, CONV, 64, 3, 2>(g, cg, st);
-                return launch<256, 128, 4, 1, CONV, 64, 3, 2>(g, cg, st);
-            }
-        }
-        if (g_opt_ksplit && g.out_mode == GL_OUT_F16_ROWMAJOR && (shape == 0 || shape == 1)) {
+    if constexpr (BKT == 64) {
+        // intra-block K-split (64-row wave tiles, 0.7-0.75 LDS fragment reads per MFMA): +7-18 % on every conv of the
+        // UNet (with or without split-K slices: the two K groups are combined in LDS before a partial slice is written)
+        // and on K >= 1024 GEMMs; its accumulator exchange in the epilogue costs 5-20 % on short K (the K = 320 / 640
+        // projections), which stay on the 4 x (32 x BN) kernels (per-shape A/B in DESIGN.md)
+        if (g_opt_ksplit && rowmajor && (shape == 0 || shape == 1)) {
             const int nk = g.K / 64;
             bool use = (g_opt_ksplit == 2);
             // (128-wide conv tiles only occur in the VAE decoder, M = 0.26-1 M pixels x 128/256 channels: measured 2 % slower)
             if (g_opt_ksplit == 1) use = CONV ? (shape == 1 && nk >= 20) : (nk >= 16);
             if (use) {
-                if (shape == 1) return launch<128, 160, 2, 1, CONV, 64, 2, 2>(g, cg, st);
-                return launch<128, 128, 2, 1, CONV, 64, 2, 2>(g, cg, st);
+                if (shape == 1) return launch<128, 160, 2, 1, CONV, 64, 2>(g, cg, st);
+                return launch<128, 128, 2, 1, CONV, 64, 2>(g, cg, st);
             }
         }
-    }
-    // deep-prefetch variant for the big level-0 / wide-N problems: 8 waves share a 256-row tile, BK 64 with a
-    // 3-stage ring (loads get TWO tile-times to land instead of one) at the same 2 waves/SIMD occupancy
-    if constexpr (BKT == 64 && NST == 2) {
-        if (g_opt_big && shape != 2 && g.M >= 256) {
+        // 256-row tiles (4 waves x 64-row wave tiles, BK 32) once the problem has >= g_opt_big of them
+        if (g_opt_big && shape != 2 && shape != 3 && g.M >= 256) {
             const int bn = (shape == 1) ? 160 : 128;
             const long t256 = (long)gl_cdiv(g.M, 256) * gl_cdiv(g.N, bn);
             if (t256 >= g_opt_big) {
-                if (g_opt_big_kind == 1) {   // 4 waves with 64-row wave tiles: 0.7-0.75 LDS fragment reads per MFMA
-                    if (shape == 1) return launch<256, 160, 4, 1, CONV, 32, 2>(g, cg, st);
-                    if (shape == 0) return launch<256, 128, 4, 1, CONV, 32, 2>(g, cg, st);
-                }
-                if (shape == 1) return launch<256, 160, 8, 1, CONV, 64, 3>(g, cg, st);
-                if (shape == 0) return launch<256, 128, 4, 2, CONV, 64, 3>(g, cg, st);
+                if (shape == 1) return launch<256, 160, 4, 1, CONV, 32>(g, cg, st);
+                return launch<256, 128, 4, 1, CONV, 32>(g, cg, st);
             }
         }
+        if constexpr (!CONV) {
+            // K-split for the small-tile shape too (64x64 instead of 32x64 wave tiles): 22.4 -> 20.4 us at
+            // M = 2048, N = K = 1280; neutral at K = 640, which stays on the plain kernel
+            if (shape == 3 && (g_opt_ksplit == 2 || (g_opt_ksplit == 1 && g.K >= 1024)))
+                return launch<64, 128, 1, 2, false, 64, 2>(g, cg, st);
+        }
+        if (shape == 3) return launch<64, 128, 2, 2, CONV, 64>(g, cg, st);
+        if (shape == 1) return launch<128, 160, 4, 1, CONV, 64>(g, cg, st);
+        if (shape == 0) return launch<128, 128, 2, 2, CONV, 64>(g, cg, st);
+        return launch<256, 64, 4, 1, CONV, 64>(g, cg, st);
+    } else {
+        // BK 32 (plain GEMMs only): 128x128 / 64x128 at 4 blocks per CU, 256x128 once there are enough tiles
+        static_assert(!CONV, "BK 32 dispatch is for plain GEMMs");
+        if (g_opt_big && shape == 0 && g.M >= 256) {
+            const long t256 = (long)gl_cdiv(g.M, 256) * gl_cdiv(g.N, 128);
+            if (t256 >= g_opt_big) return launch<256, 128, 4, 1, false, 32>(g, cg, st);
+        }
+        if (shape == 3) return launch<64, 128, 2, 2, false, 32>(g, cg, st);
+        return launch<128, 128, 2, 2, false, 32>(g, cg, st);
     }
-    if constexpr (BKT == 64 && NST == 2 && !CONV) {
-        // K-split for the small-tile shape too (64x64 instead of 32x64 wave tiles): 22.4 -> 20.4 us at
-        // M = 2048, N = K = 1280; neutral at K = 640, which stays on the plain kernel
-        if (shape == 3 && (g_opt_ksplit == 2 || (g_opt_ksplit == 1 && g.K >= 1024)))
-            return launch<64, 128, 1, 2, false, 64, 2, 2>(g, cg, st);
-    }
-    if (shape == 3) return launch<64, 128, 2, 2, CONV, BKT, NST>(g, cg, st);
-    if (shape == 1) return launch<128, 160, 4, 1, CONV, BKT, NST>(g, cg, st);
-    if (shape == 0) return launch<128, 128, 2, 2, CONV, BKT, NST>(g, cg, st);
-    if constexpr (BKT == 128) return GL_ERR_UNSUPPORTED; else return launch<256, 64, 4, 1, CONV, BKT, NST>(g, cg, st);
 }
 
 template <bool CONV>
 int dispatch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K % 64) != 0) return GL_ERR_BAD_ARG;
-    if (g.out_mode == GL_OUT_F16_ROWMAJOR && ((g.N % 8) != 0 || (g.ldc % 8) != 0)) return GL_ERR_BAD_ARG;
+    if (g.out_mode < 0 || g.out_mode > GL_OUT_F32_ROWMAJOR) return GL_ERR_BAD_ARG;
+    if (g.out_mode != GL_OUT_F32_NCHW && ((g.N % 8) != 0 || (g.ldc % 8) != 0)) return GL_ERR_BAD_ARG;
+    if (g.out_mode == GL_OUT_F32_ROWMAJOR && g.out2 != nullptr && (g.ldc2 % 8) != 0) return GL_ERR_BAD_ARG;
+    if (g.out_mode == GL_OUT_F32_ROWMAJOR && g.epi == GL_EPI_GEGLU) return GL_ERR_UNSUPPORTED;
     if (g.res != nullptr && (g.ldres % 8) != 0) return GL_ERR_BAD_ARG;
     if (g.rowbias != nullptr && (g.ld_rowbias % 8) != 0) return GL_ERR_BAD_ARG;
     if (g.epi == GL_EPI_GEGLU && (g.N % 64) != 0) return GL_ERR_BAD_ARG;
@@ -860,31 +698,14 @@ int dispatch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     if ((g.epi == GL_EPI_RES || g.epi == GL_EPI_GATE_RES) && g.res == nullptr) return GL_ERR_BAD_ARG;
     if (g.epi == GL_EPI_GATE_RES && g.gate == nullptr) return GL_ERR_BAD_ARG;
     if (g.epi == GL_EPI_ROWBIAS && (g.rowbias == nullptr || g.rows_per_sample <= 0)) return GL_ERR_BAD_ARG;
-    if constexpr (CONV) {
-        if (g_opt_halo && halo_conv_ok(g, cg) && (g_opt_halo == 2 || (g.M / 256) * gl_cdiv(g.N, 160) >= g_opt_halo_tiles))
-            return launch_halo(g, cg, st);
-    }
-    if (g_opt_pipe == 1) return dispatch_shape<CONV, 32, 3>(g, cg, st);
-    if (g_opt_pipe == 3) return dispatch_shape<CONV, 32, 2>(g, cg, st);
-    if (g_opt_pipe == 5 && g.out_mode == GL_OUT_F16_ROWMAJOR && g.epi != GL_EPI_GEGLU && (g.N % 160) == 0) {
-        // experiment: 2-wave blocks with 64 x 160 wave tiles (0.7 fragment reads per MFMA WITHOUT a K-split exchange),
-        // BK 32 so that four blocks (8 waves) fit a CU
-        return launch<128, 160, 2, 1, CONV, 32, 2>(g, cg, st);
-    }
-    if (g_opt_pipe == 4 && g.out_mode == GL_OUT_F16_ROWMAJOR && g.epi != GL_EPI_GEGLU && (g.N % 160) == 0 && g.K >= 1024) {
-        // experiment: K-split tile with BK 32 and a 4-stage ring (3 sub-tiles = 96 K-columns in flight per block)
-        return launch<128, 160, 2, 1, CONV, 32, 4, 2>(g, cg, st);
-    }
     // GEGLU with a short K (levels 0/1: K = 320/640, 5-10 k-tiles) spends a large share of each block in its
     // erf epilogue; BK 32 / 2-stage needs 35 KiB of LDS and 114 registers, so 4 blocks/CU are resident and
     // one block's epilogue overlaps the others' main loops (measured 150 -> 135 us and 109 -> 100 us; long-K
     // GEMMs and convs lose 10-20 % to the doubled barrier count, so they stay on BK 64)
-    if (!CONV && g_opt_pipe == 0 && g_opt_geglu32 && g.epi == GL_EPI_GEGLU && g.K <= 640)
-        return dispatch_shape<CONV, 32, 2>(g, cg, st);
     if constexpr (!CONV) {
-        if (g_opt_pipe == 2 && (g.K % 128) == 0 && g.N >= 256) return dispatch_shape<false, 128, 2>(g, cg, st);
+        if (g_opt_geglu32 && g.epi == GL_EPI_GEGLU && g.K <= 640 && g.a2 == nullptr) return dispatch_shape<false, 32>(g, cg, st);
     }
-    return dispatch_shape<CONV, 64, 2>(g, cg, st);
+    return dispatch_shape<CONV, 64>(g, cg, st);
 }
 
 }  // namespace
@@ -900,6 +721,7 @@ extern "C" int gl_conv3x3(const gl_conv_args* a, void* stream) {
     if ((a->Cin % 64) != 0) return GL_ERR_BAD_ARG;
     if (a->stride != 1 && a->stride != 2) return GL_ERR_BAD_ARG;
     if (a->upsample2x && (a->stride != 1 || a->Hout != 2 * a->Hin || a->Wout != 2 * a->Win)) return GL_ERR_BAD_ARG;
+    if (a->B >= 2048 || a->Hout >= 1024 || a->Wout >= 1024) return GL_ERR_BAD_ARG;     // packed (b, oy, ox) row coordinates
     gl_gemm_args g = a->g;
     g.a = a->in;
     g.a2 = nullptr;
@@ -910,71 +732,40 @@ extern "C" int gl_conv3x3(const gl_conv_args* a, void* stream) {
     return dispatch<true>(g, cg, (hipStream_t)stream);
 }
 
-template <int BM, int BN, int WM, int WN, int BKT, int NST, int WK = 1>
+template <int BM, int BN, int WM, int WN, bool CONV, int BKT, int WK = 1>
 int set_lds_attr() {
-    hipError_t e;
-    const int lds = lds_bytes<BM, BN, BKT, NST, WM * WN * WK>();
-    e = hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WM, WN, false, BKT, NST, WK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WM, WN, true, BKT, NST, WK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
-    return 0;
-}
-
-template <int BM, int BN, int WM, int WN, int BKT, int NST, int WK = 1>
-int set_lds_attr_plain() {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WM, WN, false, BKT, NST, WK>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<BM, BN, BKT, NST, WM * WN * WK>());
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WM, WN, CONV, BKT, WK>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<BM, BN, BKT, WM * WN * WK>());
     return e == hipSuccess ? 0 : (int)e;
+}
+template <int BM, int BN, int WM, int WN, int BKT, int WK = 1>
+int set_lds_attr2() {
+    int e = set_lds_attr<BM, BN, WM, WN, false, BKT, WK>();
+    return e ? e : set_lds_attr<BM, BN, WM, WN, true, BKT, WK>();
 }
 
 extern "C" int gl_init_gemm(void) {
     int e;
-    if ((e = set_lds_attr_plain<64, 128, 2, 2, 128, 2>())) return e;
-    if ((e = set_lds_attr_plain<128, 128, 2, 2, 128, 2>())) return e;
-    if ((e = set_lds_attr_plain<128, 160, 4, 1, 128, 2>())) return e;
-    if ((e = set_lds_attr<256, 160, 8, 1, 64, 3>())) return e;
-    if ((e = set_lds_attr<256, 128, 4, 2, 64, 3>())) return e;
-    if ((e = set_lds_attr<64, 128, 2, 2, 32, 3>())) return e;
-    if ((e = set_lds_attr<64, 128, 2, 2, 64, 2>())) return e;
-    if ((e = set_lds_attr<64, 128, 2, 2, 32, 2>())) return e;
-    if ((e = set_lds_attr<128, 128, 2, 2, 32, 2>())) return e;
-    if ((e = set_lds_attr<128, 160, 4, 1, 32, 2>())) return e;
-    if ((e = set_lds_attr<256, 64, 4, 1, 32, 2>())) return e;
-    if ((e = set_lds_attr<256, 160, 4, 1, 32, 2>())) return e;
-    if ((e = set_lds_attr<256, 128, 4, 1, 32, 2>())) return e;
-    if ((e = set_lds_attr<128, 128, 2, 2, 32, 3>())) return e;
-    if ((e = set_lds_attr<128, 160, 4, 1, 32, 3>())) return e;
-    if ((e = set_lds_attr<256, 64, 4, 1, 32, 3>())) return e;
-    if ((e = set_lds_attr<128, 128, 2, 2, 64, 2>())) return e;
-    if ((e = set_lds_attr<128, 160, 4, 1, 64, 2>())) return e;
-    if ((e = set_lds_attr<256, 64, 4, 1, 64, 2>())) return e;
-    if ((e = set_lds_attr<128, 160, 2, 1, 64, 2, 2>())) return e;
-    if ((e = set_lds_attr<128, 128, 2, 1, 64, 2, 2>())) return e;
-    if ((e = set_lds_attr<128, 160, 2, 1, 32, 2>())) return e;
-    if ((e = set_lds_attr_plain<64, 128, 1, 2, 64, 2, 2>())) return e;
-    if ((e = set_lds_attr<256, 160, 4, 1, 64, 3, 2>())) return e;
-    if ((e = set_lds_attr<256, 128, 4, 1, 64, 3, 2>())) return e;
-    if ((e = set_lds_attr<128, 160, 2, 1, 32, 4, 2>())) return e;
-    {
-        hipError_t he = hipFuncSetAttribute((const void*)gemm_kernel<256, 160, 4, 1, true, 64, 2, 2, true>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes_halo(160));
-        if (he != hipSuccess) return (int)he;
-    }
+    if ((e = set_lds_attr2<64, 128, 2, 2, 64>())) return e;
+    if ((e = set_lds_attr2<128, 128, 2, 2, 64>())) return e;
+    if ((e = set_lds_attr2<128, 160, 4, 1, 64>())) return e;
+    if ((e = set_lds_attr2<256, 64, 4, 1, 64>())) return e;
+    if ((e = set_lds_attr2<128, 160, 2, 1, 64, 2>())) return e;
+    if ((e = set_lds_attr2<128, 128, 2, 1, 64, 2>())) return e;
+    if ((e = set_lds_attr<64, 128, 1, 2, false, 64, 2>())) return e;
+    if ((e = set_lds_attr2<256, 160, 4, 1, 32>())) return e;
+    if ((e = set_lds_attr2<256, 128, 4, 1, 32>())) return e;
+    if ((e = set_lds_attr<64, 128, 2, 2, false, 32>())) return e;
+    if ((e = set_lds_attr<128, 128, 2, 2, false, 32>())) return e;
     return 0;
 }
 
 extern "C" int gl_set_option_gemm(int key, int value) {
-    if (key == 1) { g_opt_pipe = value; return 0; }
     if (key == 2) { g_opt_tile = value; return 0; }
     if (key == 4) { g_opt_small = value; return 0; }
     if (key == 7) { g_opt_big = value; return 0; }
     if (key == 8) { g_opt_geglu32 = value; return 0; }
-    if (key == 9) { g_opt_big_kind = value; return 0; }
-    if (key == 12) { g_opt_dbg = value; return 0; }
     if (key == 13) { g_opt_ksplit = value; return 0; }
-    if (key == 14) { g_opt_halo = value; return 0; }
-    if (key == 15) { g_opt_halo_tiles = value; return 0; }
     if (key == 5) { g_opt_splitk_tiles = value; g_opt_splitk_tiles_conv = value; return 0; }
     if (key == 6) { g_opt_splitk_nk = value; return 0; }
     return GL_ERR_BAD_ARG;

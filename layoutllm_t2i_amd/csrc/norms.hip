@@ -22,21 +22,28 @@ __device__ __forceinline__ const half_t* src_ptr(const half_t* x1, int C1, const
 }
 
 // grid (nchunk, B); block 256.  thread -> fixed 8-channel vector(s), strided over the chunk's pixels.
-// Per-channel partial sums go to LDS as [pixel-lane][channel]; 32 threads then fold them per group in
-// a fixed order (bitwise reproducible).
+//
+// Statistics are gathered Welford-style (torch's GroupNorm uses a Welford update; a one-pass E[x^2] - mean^2 in
+// fp32 loses the variance of a channel whose |mean| >> std, which real checkpoints have): every thread sums
+// (x - s) and (x - s)^2 about a per-channel shift s = the first value it sees, converts to (mean, M2 = sum of squared
+// deviations) and the partials are merged with the exact pairwise formula
+//     mean = sum_i n_i mean_i / N ,   M2 = sum_i [ M2_i + n_i (mean_i - mean)^2 ]
+// in a fixed order (bitwise reproducible, no atomics).  partial[b][chunk][group] = (mean, M2); the element count of
+// a chunk follows from the geometry.
 constexpr int GN_MAX_C = 2560;
 __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict__ x1, int C1,
                                                        const half_t* __restrict__ x2, int C2, int HW, int nchunk,
                                                        float* __restrict__ partial) {
-    __shared__ float lsum[GN_MAX_C];
-    __shared__ float lsq[GN_MAX_C];
+    __shared__ float lmean[GN_MAX_C];
+    __shared__ float lm2[GN_MAX_C];
+    __shared__ float lcnt[256];
     const int C = C1 + C2;
     const int cpg = C / 32;
     const int nvec = C / 8;
     const int b = blockIdx.y;
     const int chunk = blockIdx.x;
     const int ppc = (HW + nchunk - 1) / nchunk;
-    const int p0 = chunk * ppc;
+    const int p0 = min(HW, chunk * ppc);
     const int p1 = min(HW, p0 + ppc);
 
     const int vlanes = min(nvec, 256);       // vectors handled side by side
@@ -44,60 +51,82 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict_
     const int plane = threadIdx.x / vlanes;
     const int v0 = threadIdx.x - plane * vlanes;
     if (plane < nplanes) {
+        const int first = p0 + plane;
+        const int npix = first < p1 ? (p1 - first + nplanes - 1) / nplanes : 0;
+        if (v0 == 0) lcnt[plane] = (float)npix;
         for (int vec = v0; vec < nvec; vec += vlanes) {
-            float s[8], ss[8];
+            float s[8], ss[8], sh[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { s[j] = 0.0f; ss[j] = 0.0f; }
+            for (int j = 0; j < 8; ++j) { s[j] = 0.0f; ss[j] = 0.0f; sh[j] = 0.0f; }
             const int c = vec * 8;
-            int cl;
-            const half_t* base = src_ptr(x1, C1, x2, C2, (size_t)b * HW + p0 + plane, c, &cl) + cl;
-            const size_t step = (size_t)nplanes * (c < C1 ? C1 : C2);
-            int pix = p0 + plane;
-            // 4 independent 16-byte loads in flight per thread
-            for (; pix + 3 * nplanes < p1; pix += 4 * nplanes, base += 4 * step) {
-                uint4 raw[4];
+            if (npix > 0) {
+                int cl;
+                const half_t* base = src_ptr(x1, C1, x2, C2, (size_t)b * HW + first, c, &cl) + cl;
+                const size_t step = (size_t)nplanes * (c < C1 ? C1 : C2);
+                {
+                    uint4 raw = ld16(base);
+                    const half8_t hv = *reinterpret_cast<half8_t*>(&raw);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) raw[u] = ld16(base + u * step);
+                    for (int j = 0; j < 8; ++j) sh[j] = (float)hv[j];
+                }
+                int pix = first;
+                // 4 independent 16-byte loads in flight per thread
+                for (; pix + 3 * nplanes < p1; pix += 4 * nplanes, base += 4 * step) {
+                    uint4 raw[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const half8_t hv = *reinterpret_cast<half8_t*>(&raw[u]);
+                    for (int u = 0; u < 4; ++u) raw[u] = ld16(base + u * step);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const half8_t hv = *reinterpret_cast<half8_t*>(&raw[u]);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float f = (float)hv[j] - sh[j];
+                            s[j] += f;
+                            ss[j] = fmaf(f, f, ss[j]);
+                        }
+                    }
+                }
+                for (; pix < p1; pix += nplanes, base += step) {
+                    uint4 raw = ld16(base);
+                    const half8_t hv = *reinterpret_cast<half8_t*>(&raw);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float f = (float)hv[j];
+                        const float f = (float)hv[j] - sh[j];
                         s[j] += f;
-                        ss[j] += f * f;
+                        ss[j] = fmaf(f, f, ss[j]);
                     }
                 }
             }
-            for (; pix < p1; pix += nplanes, base += step) {
-                uint4 raw = ld16(base);
-                const half8_t hv = *reinterpret_cast<half8_t*>(&raw);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float f = (float)hv[j];
-                    s[j] += f;
-                    ss[j] += f * f;
-                }
-            }
+            const float inv = npix > 0 ? 1.0f / (float)npix : 0.0f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                lsum[plane * C + c + j] = s[j];
-                lsq[plane * C + c + j] = ss[j];
+                const float dm = s[j] * inv;                      // mean - shift
+                lmean[plane * C + c + j] = sh[j] + dm;
+                lm2[plane * C + c + j] = fmaxf(ss[j] - s[j] * dm, 0.0f);
             }
         }
     }
     __syncthreads();
     if (threadIdx.x < 32) {
         const int g = threadIdx.x;
-        float s = 0.0f, ss = 0.0f;
-        for (int pl = 0; pl < nplanes; ++pl)
+        float sw = 0.0f, wsum = 0.0f;
+        for (int pl = 0; pl < nplanes; ++pl) {
+            const float n = lcnt[pl];
+            for (int cc = 0; cc < cpg; ++cc) sw = fmaf(n, lmean[pl * C + g * cpg + cc], sw);
+            wsum += n * (float)cpg;
+        }
+        const float mean = wsum > 0.0f ? sw / wsum : 0.0f;
+        float m2 = 0.0f;
+        for (int pl = 0; pl < nplanes; ++pl) {
+            const float n = lcnt[pl];
             for (int cc = 0; cc < cpg; ++cc) {
-                s += lsum[pl * C + g * cpg + cc];
-                ss += lsq[pl * C + g * cpg + cc];
+                const float d = lmean[pl * C + g * cpg + cc] - mean;
+                m2 += lm2[pl * C + g * cpg + cc] + n * d * d;
             }
+        }
         float* pp = partial + (((size_t)b * nchunk + chunk) * 32 + g) * 2;
-        pp[0] = s;
-        pp[1] = ss;
+        pp[0] = mean;
+        pp[1] = m2;
     }
 }
 
@@ -118,28 +147,40 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
     const int nvec = C / 8;
     const int b = blockIdx.y;
     {
-        // fold the <= 64 per-chunk partials: 8 slices x 32 groups in parallel (independent loads), then a
-        // fixed-order sum over the slices -- the serial 64-step version cost ~25 us of dependent L2 latency
+        // merge the <= 64 per-chunk (mean, M2) partials (weights n_c = chunk pixels x channels per group): 8 slices x 32
+        // groups in parallel (independent loads), then fixed-order sums over the slices; two passes (mean, then M2)
         const int g = threadIdx.x & 31, sl = threadIdx.x >> 5;
-        float s = 0.0f, ss = 0.0f;
+        const int ppc = (HW + nchunk - 1) / nchunk;
+        float sw = 0.0f;
         for (int ch = sl; ch < nchunk; ch += 8) {
-            const float* pp = partial + (((size_t)b * nchunk + ch) * 32 + g) * 2;
-            s += pp[0];
-            ss += pp[1];
+            const float n = (float)(max(0, min(HW, (ch + 1) * ppc) - min(HW, ch * ppc)) * cpg);
+            sw = fmaf(n, partial[(((size_t)b * nchunk + ch) * 32 + g) * 2], sw);
         }
-        red_s[sl][g] = s;
-        red_q[sl][g] = ss;
+        red_s[sl][g] = sw;
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            float s = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += red_s[k][threadIdx.x];
+            mean_s[threadIdx.x] = s / ((float)cpg * (float)HW);
+        }
+        __syncthreads();
+        const float mean = mean_s[g];
+        float m2 = 0.0f;
+        for (int ch = sl; ch < nchunk; ch += 8) {
+            const float n = (float)(max(0, min(HW, (ch + 1) * ppc) - min(HW, ch * ppc)) * cpg);
+            const float* pp = partial + (((size_t)b * nchunk + ch) * 32 + g) * 2;
+            const float d = pp[0] - mean;
+            m2 += pp[1] + n * d * d;
+        }
+        red_q[sl][g] = m2;
     }
     __syncthreads();
     if (threadIdx.x < 32) {
-        float s = 0.0f, ss = 0.0f;
+        float ss = 0.0f;
 #pragma unroll
-        for (int sl = 0; sl < 8; ++sl) { s += red_s[sl][threadIdx.x]; ss += red_q[sl][threadIdx.x]; }
-        const float n = (float)cpg * (float)HW;
-        const float mean = s / n;
-        float var = ss / n - mean * mean;
-        var = fmaxf(var, 0.0f);
-        mean_s[threadIdx.x] = mean;
+        for (int sl = 0; sl < 8; ++sl) ss += red_q[sl][threadIdx.x];
+        const float var = ss / ((float)cpg * (float)HW);
         rstd_s[threadIdx.x] = rsqrtf(var + eps);
     }
     __syncthreads();
@@ -199,103 +240,88 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
     }
 }
 
-// One wave per row, RPW rows per wave with all their loads issued before the first reduction (the kernel is
-// latency-bound: 8k resident waves x one 640-byte row each left HBM at ~30 %); up to NV x 64 8-channel
-// vectors per row.
-template <int RPW, int NV>
-__global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, int ldx, half_t* __restrict__ y,
+// One wave per row; up to NV x 64 8-channel vectors per row.  XF32: the input row is fp32 (the residual stream), else
+// fp16.  Two-pass statistics in registers (mean, then sum of squared deviations).  Optionally stores (mean, rstd) per
+// input row so that a consumer can re-evaluate the normalisation in fp32 (rela_merge).
+template <bool XF32, int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__ xv, int ldx, half_t* __restrict__ y,
                                                         int ldy, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int nrows, int rows_in,
-                                                        int rows_out, int row_off, int C, float eps) {
+                                                        int rows_out, int row_off, int C, float eps,
+                                                        float* __restrict__ stats) {
     const int lane = threadIdx.x & 63;
-    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
-    if (row0 >= nrows) return;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
     const int nvec = C / 8;
-    half8_t v[RPW][NV];
-    float s[RPW];
+    float v[NV][8];
 #pragma unroll
-    for (int r = 0; r < RPW; ++r) {
-        const int row = min(row0 + r, nrows - 1);
-        const half_t* xr = x + (size_t)row * ldx;
+    for (int i = 0; i < NV; ++i) {
+        const int vec = lane + 64 * i;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int vec = lane + 64 * i;
-            uint4 raw = make_uint4(0u, 0u, 0u, 0u);
-            if (vec < nvec) raw = ld16(xr + vec * 8);
-            v[r][i] = *reinterpret_cast<half8_t*>(&raw);
-        }
-    }
+        for (int j = 0; j < 8; ++j) v[i][j] = 0.0f;
+        if (vec < nvec) {
+            if constexpr (XF32) {
+                const float* xr = reinterpret_cast<const float*>(xv) + (size_t)row * ldx + vec * 8;
+                const float4 a = *reinterpret_cast<const float4*>(xr);
+                const float4 c = *reinterpret_cast<const float4*>(xr + 4);
+                v[i][0] = a.x; v[i][1] = a.y; v[i][2] = a.z; v[i][3] = a.w;
+                v[i][4] = c.x; v[i][5] = c.y; v[i][6] = c.z; v[i][7] = c.w;
+            } else {
+                uint4 raw = ld16(reinterpret_cast<const half_t*>(xv) + (size_t)row * ldx + vec * 8);
+                const half8_t hv = *reinterpret_cast<half8_t*>(&raw);
 #pragma unroll
-    for (int r = 0; r < RPW; ++r) {
-        float a = 0.0f;
-#pragma unroll
-        for (int i = 0; i < NV; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) a += (float)v[r][i][j];      // lanes past the row hold zeros
-        s[r] = a;
-    }
-    float mean[RPW], rstd[RPW];
-#pragma unroll
-    for (int r = 0; r < RPW; ++r) mean[r] = wave_sum(s[r]) / (float)C;
-#pragma unroll
-    for (int r = 0; r < RPW; ++r) {
-        float ss = 0.0f;
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int vec = lane + 64 * i;
-            if (vec < nvec) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float dlt = (float)v[r][i][j] - mean[r];
-                    ss += dlt * dlt;
-                }
+                for (int j = 0; j < 8; ++j) v[i][j] = (float)hv[j];
             }
         }
-        s[r] = ss;
     }
+    float a = 0.0f;
 #pragma unroll
-    for (int r = 0; r < RPW; ++r) rstd[r] = rsqrtf(wave_sum(s[r]) / (float)C + eps);
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a += v[i][j];              // lanes past the row hold zeros
+    const float mean = wave_sum(a) / (float)C;
+    float ss = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if (lane + 64 * i < nvec) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float dlt = v[i][j] - mean;
+                ss = fmaf(dlt, dlt, ss);
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)C + eps);
+    if (stats != nullptr && lane == 0) {
+        stats[(size_t)row * 2] = mean;
+        stats[(size_t)row * 2 + 1] = rstd;
+    }
+    const int bidx = row / rows_in;
+    const int i_in = row - bidx * rows_in;
+    half_t* yr = y + ((size_t)bidx * rows_out + row_off + i_in) * ldy;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int vec = lane + 64 * i;
         if (vec < nvec) {
-            float g[8], bt[8];
+            const float4 g0 = *reinterpret_cast<const float4*>(gamma + vec * 8);
+            const float4 g1 = *reinterpret_cast<const float4*>(gamma + vec * 8 + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(beta + vec * 8);
+            const float4 b1 = *reinterpret_cast<const float4*>(beta + vec * 8 + 4);
+            const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            const float bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            half8_t ov;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                g[j] = gamma[vec * 8 + j];
-                bt[j] = beta[vec * 8 + j];
-            }
-#pragma unroll
-            for (int r = 0; r < RPW; ++r) {
-                const int row = row0 + r;
-                if (row < nrows) {
-                    const int bidx = row / rows_in;
-                    const int i_in = row - bidx * rows_in;
-                    half_t* yr = y + ((size_t)bidx * rows_out + row_off + i_in) * ldy;
-                    half8_t ov;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) ov[j] = (half_t)(((float)v[r][i][j] - mean[r]) * rstd[r] * g[j] + bt[j]);
-                    st16(yr + vec * 8, *reinterpret_cast<uint4*>(&ov));
-                }
-            }
+            for (int j = 0; j < 8; ++j) ov[j] = (half_t)((v[i][j] - mean) * rstd * g[j] + bt[j]);
+            st16(yr + vec * 8, *reinterpret_cast<uint4*>(&ov));
         }
     }
 }
 
-template <int RPW, int NV>
-void launch_ln(const half_t* x, int ldx, half_t* y, int ldy, const float* gamma, const float* beta, int nrows,
-               int rows_in, int rows_out, int row_off, int C, float eps, hipStream_t st) {
-    layernorm_kernel<RPW, NV><<<dim3(gl_cdiv(nrows, 4 * RPW)), dim3(256), 0, st>>>(x, ldx, y, ldy, gamma, beta, nrows, rows_in,
-                                                                             rows_out, row_off, C, eps);
-}
-
-int g_ln_rpw = 0;   // rows per wave override for A/B (0 = auto)
 int g_gn_ppb = 16;  // GroupNorm apply: pixels per pixel-lane per block (A/B knob 16)
 
 }  // namespace
 
 extern "C" int gl_set_option_norm(int key, int value) {
-    if (key == 11) { g_ln_rpw = value; return 0; }
     if (key == 16) { g_gn_ppb = value > 0 ? value : 16; return 0; }
     return GL_ERR_BAD_ARG;
 }
@@ -331,25 +357,22 @@ extern "C" int gl_groupnorm_apply(const void* x1, int32_t C1, const void* x2, in
     return 0;
 }
 
-extern "C" int gl_layernorm(const void* x, int32_t ldx, void* y, int32_t ldy, const float* gamma, const float* beta,
-                            int32_t B, int32_t rows_in, int32_t rows_out, int32_t row_off, int32_t C, float eps,
-                            void* stream) {
+extern "C" int gl_layernorm(const void* x, int32_t ldx, int32_t x_f32, void* y, int32_t ldy, const float* gamma,
+                            const float* beta, int32_t B, int32_t rows_in, int32_t rows_out, int32_t row_off, int32_t C,
+                            float eps, float* stats, void* stream) {
     if (!x || !y || !gamma || !beta || C <= 0 || (C % 8) || C > 2048 || (ldx % 8) || (ldy % 8)) return GL_ERR_BAD_ARG;
     const int nrows = B * rows_in;
     if (nrows <= 0) return GL_ERR_BAD_ARG;
-    const half_t* xp = reinterpret_cast<const half_t*>(x);
     half_t* yp = reinterpret_cast<half_t*>(y);
     hipStream_t st = (hipStream_t)stream;
     const int nv = gl_cdiv(C / 8, 64);
-    // rows per wave: 2 / 4 measured equal to 1 on MI355X (12.1-12.9 us at 32768 x 320) -- the kernel sits on its
-    // launch + dependent-load latency floor, not on bytes in flight -- so 1 stays the default (option 11 = A/B)
-    int rpw = g_ln_rpw ? g_ln_rpw : 1;
-    if (nv > 2 && rpw > 2) rpw = 2;
-#define GL_LN(R, V) launch_ln<R, V>(xp, ldx, yp, ldy, gamma, beta, nrows, rows_in, rows_out, row_off, C, eps, st)
-    if (nv == 1) { if (rpw == 4) GL_LN(4, 1); else if (rpw == 2) GL_LN(2, 1); else GL_LN(1, 1); }
-    else if (nv == 2) { if (rpw == 4) GL_LN(4, 2); else if (rpw == 2) GL_LN(2, 2); else GL_LN(1, 2); }
-    else if (nv == 3) { if (rpw == 2) GL_LN(2, 3); else GL_LN(1, 3); }
-    else { if (rpw == 2) GL_LN(2, 4); else GL_LN(1, 4); }
+    const dim3 grid(gl_cdiv(nrows, 4)), blk(256);
+#define GL_LN(F, V) layernorm_kernel<F, V><<<grid, blk, 0, st>>>(x, ldx, yp, ldy, gamma, beta, nrows, rows_in, rows_out, row_off, C, eps, stats)
+    if (x_f32) {
+        if (nv == 1) GL_LN(true, 1); else if (nv == 2) GL_LN(true, 2); else if (nv == 3) GL_LN(true, 3); else GL_LN(true, 4);
+    } else {
+        if (nv == 1) GL_LN(false, 1); else if (nv == 2) GL_LN(false, 2); else if (nv == 3) GL_LN(false, 3); else GL_LN(false, 4);
+    }
 #undef GL_LN
     GL_CHECK_LAUNCH();
     return 0;

@@ -87,12 +87,16 @@ __global__ __launch_bounds__(256) void rela_pool_kernel(const half_t* __restrict
     }
 }
 
-// elementwise over [B, H*W, C]: 8 channels per thread
-__global__ __launch_bounds__(256) void rela_merge_kernel(const half_t* __restrict__ x, const half_t* __restrict__ hid,
-                                                         const half_t* __restrict__ f, int H, int W, int C,
-                                                         const int* __restrict__ rects, const int* __restrict__ nvalid,
-                                                         const int* __restrict__ poison, int max_objs,
-                                                         half_t* __restrict__ y, size_t total) {
+// elementwise over [B, H*W, C]: 8 channels per thread.  XF32: x and y are the fp32 residual stream and hid = LN3(x) is
+// RE-EVALUATED in fp32 from the per-row (mean, rstd) the LayerNorm kernel stored, instead of being read back rounded to
+// fp16 -- hid enters the residual stream directly here (attention.py:354-358,398), not through a matrix product.
+template <bool XF32>
+__global__ __launch_bounds__(256) void rela_merge_kernel(const void* __restrict__ xv, const half_t* __restrict__ hid,
+                                                         const float* __restrict__ ln_stats, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const half_t* __restrict__ f,
+                                                         int H, int W, int C, const int* __restrict__ rects,
+                                                         const int* __restrict__ nvalid, const int* __restrict__ poison,
+                                                         int max_objs, void* __restrict__ yv, size_t total) {
     const int nvec = C / 8;
     const int HW = H * W;
     const float inv_mo = 1.0f / (float)max_objs;
@@ -102,10 +106,28 @@ __global__ __launch_bounds__(256) void rela_merge_kernel(const half_t* __restric
         const int b = (int)(tok / HW);
         const int p = (int)(tok - (size_t)b * HW);
         const int py = p / W, px = p - py * W;
-        uint4 rx = ld16(x + tok * C + vec * 8);
-        uint4 rh = ld16(hid + tok * C + vec * 8);
-        const half8_t xv = *reinterpret_cast<half8_t*>(&rx);
-        const half8_t hv = *reinterpret_cast<half8_t*>(&rh);
+        float xf[8], hf[8];
+        if constexpr (XF32) {
+            const float* xr = reinterpret_cast<const float*>(xv) + tok * C + vec * 8;
+            const float4 a = *reinterpret_cast<const float4*>(xr);
+            const float4 c = *reinterpret_cast<const float4*>(xr + 4);
+            xf[0] = a.x; xf[1] = a.y; xf[2] = a.z; xf[3] = a.w; xf[4] = c.x; xf[5] = c.y; xf[6] = c.z; xf[7] = c.w;
+        } else {
+            uint4 rx = ld16(reinterpret_cast<const half_t*>(xv) + tok * C + vec * 8);
+            const half8_t x8 = *reinterpret_cast<half8_t*>(&rx);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xf[j] = (float)x8[j];
+        }
+        if (ln_stats != nullptr) {
+            const float mean = ln_stats[tok * 2], rstd = ln_stats[tok * 2 + 1];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hf[j] = (xf[j] - mean) * rstd * gamma[vec * 8 + j] + beta[vec * 8 + j];
+        } else {
+            uint4 rh = ld16(hid + tok * C + vec * 8);
+            const half8_t hv = *reinterpret_cast<half8_t*>(&rh);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hf[j] = (float)hv[j];
+        }
         float acc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
@@ -121,14 +143,22 @@ __global__ __launch_bounds__(256) void rela_merge_kernel(const half_t* __restric
             }
         }
         const bool bad = poison[b] != 0;
-        half8_t ov;
+        float o[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float o = 0.5f * (((float)hv[j] + acc[j] * inv_mo) + (float)xv[j]);
-            if (bad) o = __builtin_nanf("");
-            ov[j] = (half_t)o;
+            o[j] = 0.5f * ((hf[j] + acc[j] * inv_mo) + xf[j]);
+            if (bad) o[j] = __builtin_nanf("");
         }
-        st16(y + tok * C + vec * 8, *reinterpret_cast<uint4*>(&ov));
+        if constexpr (XF32) {
+            float* yr = reinterpret_cast<float*>(yv) + tok * C + vec * 8;
+            *reinterpret_cast<float4*>(yr) = make_float4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<float4*>(yr + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        } else {
+            half8_t ov;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ov[j] = (half_t)o[j];
+            st16(reinterpret_cast<half_t*>(yv) + tok * C + vec * 8, *reinterpret_cast<uint4*>(&ov));
+        }
     }
 }
 
@@ -143,16 +173,23 @@ extern "C" int gl_rela_pool(const void* hid, int32_t B, int32_t H, int32_t W, in
     return 0;
 }
 
-extern "C" int gl_rela_merge(const void* x, const void* hid, const void* f, int32_t B, int32_t H, int32_t W, int32_t C,
-                             const int32_t* rects, const int32_t* nvalid, const int32_t* poison, int32_t max_objs,
-                             void* y, void* stream) {
-    if (!x || !hid || !f || !rects || !nvalid || !poison || !y || C <= 0 || (C % 8)) return GL_ERR_BAD_ARG;
+extern "C" int gl_rela_merge(const void* x, int32_t x_f32, const void* hid, const float* ln_stats, const float* gamma,
+                             const float* beta, const void* f, int32_t B, int32_t H, int32_t W, int32_t C,
+                             const int32_t* rects, const int32_t* nvalid, const int32_t* poison, int32_t max_objs, void* y,
+                             void* stream) {
+    if (!x || !f || !rects || !nvalid || !poison || !y || C <= 0 || (C % 8)) return GL_ERR_BAD_ARG;
+    if (ln_stats ? (!gamma || !beta) : !hid) return GL_ERR_BAD_ARG;
     const size_t total = (size_t)B * H * W * (C / 8);
     int nblk = (int)((total + 255) / 256);
     if (nblk > 2048) nblk = 2048;
-    rela_merge_kernel<<<dim3(nblk), dim3(256), 0, (hipStream_t)stream>>>(
-        reinterpret_cast<const half_t*>(x), reinterpret_cast<const half_t*>(hid), reinterpret_cast<const half_t*>(f), H,
-        W, C, rects, nvalid, poison, max_objs, reinterpret_cast<half_t*>(y), total);
+    const half_t* hp = reinterpret_cast<const half_t*>(hid);
+    const half_t* fp = reinterpret_cast<const half_t*>(f);
+    if (x_f32)
+        rela_merge_kernel<true><<<dim3(nblk), dim3(256), 0, (hipStream_t)stream>>>(x, hp, ln_stats, gamma, beta, fp, H, W, C, rects,
+                                                                                  nvalid, poison, max_objs, y, total);
+    else
+        rela_merge_kernel<false><<<dim3(nblk), dim3(256), 0, (hipStream_t)stream>>>(x, hp, ln_stats, gamma, beta, fp, H, W, C, rects,
+                                                                                   nvalid, poison, max_objs, y, total);
     GL_CHECK_LAUNCH();
     return 0;
 }

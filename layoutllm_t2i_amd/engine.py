@@ -10,7 +10,12 @@ the reference that are *result-identical*  and where the time goes
     rela_fuse K/V projections, integer box rectangles per resolution;
   * the gated-SA fuser is skipped outright when the sampler sets scale == 0 (exact identity);
   * the RelationCrossAttention injection runs in closed form (two small kernels + tiny GEMMs);
-  * a whole forward is captured into a HIP graph per (fuser on/off, first-conv variant) and replayed.
+  * a whole forward is captured into a HIP graph per (fuser on/off, first-conv variant) and replayed;
+  * the RESIDUAL STREAM is fp32: every block output (ResBlock sum, transformer-block x after each of its residual
+    adds, proj_out + x_in, conv_in / down / up outputs) is accumulated and stored in fp32 by the producing GEMM / conv
+    epilogue, with an fp16 copy only where a matrix-core consumer needs one (GroupNorm -> conv, 1x1 skip conv, down /
+    up convs, proj_out).  LayerNorm reads the fp32 stream; rela_fuse's LN3 term is re-evaluated in fp32 inside
+    rela_merge.  Only operands of matrix products are fp16 (tools/precision_sim.py: that floor is rel-L2 1.1e-3).
 
 No torch op touches activations on the hot path: torch provides device memory, streams and graphs.
 """
@@ -156,21 +161,29 @@ class UNetEngine:
         partial = self.buf("gn.partial", (Bn * 64 * 64,), F32)
         return ops.groupnorm(x1, x2, Bn, HW, self.W[p + ".g"], self.W[p + ".b"], eps, silu, out, partial)
 
+    def _stream(self, tag, M, C):
+        """fp32 residual-stream tensor + its fp16 copy for matrix-core consumers"""
+        return self.buf(tag + ".f32", (M, C), F32), self.buf(tag, (M, C))
+
     def _res_block(self, l: Layer, h, skip, Bn, side, emb_out, out_tag):
+        """h = (fp32, fp16) stream pair; skip = (fp32, fp16) pair popped from the skip stack or None."""
         W, p = self.W, l.prefix
         HW = side * side
-        t = self._groupnorm(h, skip, Bn, HW, p + ".in_layers.0", 1e-5, True, "rb.gn1")
+        h32, h16 = h
+        s16 = skip[1] if skip is not None else None
+        t = self._groupnorm(h16, s16, Bn, HW, p + ".in_layers.0", 1e-5, True, "rb.gn1")
         off = self.P.emb_offsets[p]
         h1 = ops.conv3x3(t, W[p + ".in_layers.2.w"], self.buf("rb.h1", (Bn * HW, l.cout)), Bn, side, side,
                          W[p + ".in_layers.2.b"], epi=EPI_ROWBIAS, rowbias=emb_out[:, off:off + l.cout], rows_per_sample=HW)
         t2 = self._groupnorm(h1, None, Bn, HW, p + ".out_layers.0", 1e-5, True, "rb.gn2")
         if l.cin != l.cout:
-            sk = ops.gemm(h, W[p + ".skip_connection.w"], self.buf("rb.skip", (Bn * HW, l.cout)), W[p + ".skip_connection.b"], a2=skip)
+            sk = ops.gemm(h16, W[p + ".skip_connection.w"], self.buf("rb.skip.f32", (Bn * HW, l.cout), F32), W[p + ".skip_connection.b"], a2=s16)
         else:
             assert skip is None
-            sk = h
-        return ops.conv3x3(t2, W[p + ".out_layers.3.w"], self.buf(out_tag, (Bn * HW, l.cout)), Bn, side, side,
-                           W[p + ".out_layers.3.b"], epi=EPI_RES, res=sk)
+            sk = h32
+        o32, o16 = self._stream(out_tag, Bn * HW, l.cout)
+        ops.conv3x3(t2, W[p + ".out_layers.3.w"], o32, Bn, side, side, W[p + ".out_layers.3.b"], epi=EPI_RES, res=sk, out16=o16)
+        return o32, o16
 
     def _self_attention(self, src, rows_per_b, Nq, Nk, C, d, wp, tagp):
         """src [Bn*rows_per_b, C] (already normalised) -> attention output [Bn*Nq, C] (before to_out)."""
@@ -183,14 +196,15 @@ class UNetEngine:
                       Bn, H, d, Nq, Nk, d ** -0.5)
         return att
 
-    def _feed_forward(self, xn, res, p, M, C, out_tag, gate=None):
+    def _feed_forward(self, xn, res, p, M, C, out, gate=None):
         W = self.W
         hg = ops.gemm(xn, W[p + ".ff1.w"], self.buf("ff.h", (M, 4 * C)), W[p + ".ff1.b"], EPI_GEGLU)
         if gate is None:
-            return ops.gemm(hg, W[p + ".ff2.w"], self.buf(out_tag, (M, C)), W[p + ".ff2.b"], EPI_RES, res=res)
-        return ops.gemm(hg, W[p + ".ff2.w"], self.buf(out_tag, (M, C)), W[p + ".ff2.b"], EPI_GATE_RES, res=res, gate=gate)
+            return ops.gemm(hg, W[p + ".ff2.w"], out, W[p + ".ff2.b"], EPI_RES, res=res)
+        return ops.gemm(hg, W[p + ".ff2.w"], out, W[p + ".ff2.b"], EPI_GATE_RES, res=res, gate=gate)
 
     def _spatial_transformer(self, l: Layer, li: int, x_in, Bn, side, fuser_on, out_tag):
+        """x_in = (fp32, fp16) stream pair.  Inside the block x lives in fp32 only (two ping-pong buffers)."""
         W, c, cfg = self.W, self.cond, self.cfg
         p = l.prefix
         t = p + ".transformer_blocks.0"
@@ -198,12 +212,15 @@ class UNetEngine:
         N = side * side
         M = Bn * N
         mo, R, Lc = c["mo"], c["R"], c["Lc"]
-        g0 = self._groupnorm(x_in, None, Bn, N, p + ".norm", 1e-6, False, "st.gn")
-        x = ops.gemm(g0, W[p + ".proj_in.w"], self.buf("st.x0", (M, C)), W[p + ".proj_in.b"])
+        xin32, xin16 = x_in
+        xa, xb = self.buf("st.xa", (M, C), F32), self.buf("st.xb", (M, C), F32)
+        g0 = self._groupnorm(xin16, None, Bn, N, p + ".norm", 1e-6, False, "st.gn")
+        x = ops.gemm(g0, W[p + ".proj_in.w"], xa, W[p + ".proj_in.b"])
+        nxt = lambda cur: xb if cur is xa else xa
         # --- attn1 (attention.py:395)
         n1 = ops.layernorm(x, self.buf("st.ln", (M, C)), W[t + ".norm1.g"], W[t + ".norm1.b"], Bn, N)
         att = self._self_attention(n1, N, N, N, C, d, t + ".attn1", "st.sa")
-        x = ops.gemm(att, W[t + ".attn1.o.w"], self.buf("st.x1", (M, C)), W[t + ".attn1.o.b"], EPI_RES, res=x)
+        x = ops.gemm(att, W[t + ".attn1.o.w"], nxt(x), W[t + ".attn1.o.b"], EPI_RES, res=x)
         # --- gated self-attention fuser over [x ; objs] (attention.py:226-234); exact identity at scale 0
         if fuser_on:
             f = t + ".fuser"
@@ -211,14 +228,15 @@ class UNetEngine:
             ops.layernorm(x, cat, W[f + ".norm1.g"], W[f + ".norm1.b"], Bn, N, N + mo, 0)
             ops.layernorm(c[f"objs.{li}"], cat, W[f + ".norm1.g"], W[f + ".norm1.b"], Bn, mo, N + mo, N)
             att = self._self_attention(cat, N + mo, N, N + mo, C, d, f + ".attn", "st.fa")
-            x = ops.gemm(att, W[f + ".attn.o.w"], self.buf("st.x2", (M, C)), W[f + ".attn.o.b"], EPI_GATE_RES, res=x,
+            x = ops.gemm(att, W[f + ".attn.o.w"], nxt(x), W[f + ".attn.o.b"], EPI_GATE_RES, res=x,
                          gate=self._gates[f + ".tanh_attn"])
             n2 = ops.layernorm(x, self.buf("st.ln", (M, C)), W[f + ".norm2.g"], W[f + ".norm2.b"], Bn, N)
-            x = self._feed_forward(n2, x, f + ".ff", M, C, "st.x3", gate=self._gates[f + ".tanh_dense"])
+            x = self._feed_forward(n2, x, f + ".ff", M, C, nxt(x), gate=self._gates[f + ".tanh_dense"])
         # --- relation injection (attention.py:315-359, :398), closed form
         r = t + ".rela_fuse"
         rects, nvalid, poison = c[f"rects.{side}"], c[f"nvalid.{side}"], c[f"poison.{side}"]
-        hid = ops.layernorm(x, self.buf("st.hid", (M, C)), W[r + ".norm3.g"], W[r + ".norm3.b"], Bn, N)
+        stats = self.buf("st.lnstats", (M, 2), F32)
+        hid = ops.layernorm(x, self.buf("st.hid", (M, C)), W[r + ".norm3.g"], W[r + ".norm3.b"], Bn, N, stats=stats)
         Mo = Bn * mo
         feat = ops.rela_pool(hid, Bn, side, side, C, rects, nvalid, poison, mo, self.buf("rl.feat", (Mo, C)))
         fn = ops.layernorm(feat, self.buf("rl.ln", (Mo, C)), W[r + ".norm1.g"], W[r + ".norm1.b"], Bn, mo)
@@ -232,19 +250,22 @@ class UNetEngine:
         hg = ops.gemm(fn2, W[r + ".ff.ff1.w"], self.buf("rl.ffh", (Mo, 4 * C)), W[r + ".ff.ff1.b"], EPI_GEGLU)
         f2 = ops.gemm(hg, W[r + ".ff.ff2.w"], self.buf("rl.f2", (Mo, C)), W[r + ".ff.ff2.b"], EPI_GATE_RES, res=f1,
                       gate=self._gates[r + ".tanh_dense"])
-        x = ops.rela_merge(x, hid, f2, Bn, side, side, C, rects, nvalid, poison, mo, self.buf("st.x4", (M, C)))
+        x = ops.rela_merge(x, None, f2, Bn, side, side, C, rects, nvalid, poison, mo, nxt(x), ln_stats=stats,
+                           gamma=W[r + ".norm3.g"], beta=W[r + ".norm3.b"])
         # --- attn2: text cross-attention with hoisted K/V (attention.py:400)
         n = ops.layernorm(x, self.buf("st.ln", (M, C)), W[t + ".norm2.g"], W[t + ".norm2.b"], Bn, N)
         q2 = ops.gemm(n, W[t + ".attn2.q.w"], self.buf("st.q2", (M, C)))
         a2 = self.buf("st.att2", (M, C))
         ops.attention(q2, N * C, C, c[f"kvctx.{li}"], Lc * 2 * C, 2 * C, c[f"vtctx.{li}"], a2, N * C, C, Bn, H, d, N, Lc,
                       d ** -0.5)
-        x = ops.gemm(a2, W[t + ".attn2.o.w"], self.buf("st.x5", (M, C)), W[t + ".attn2.o.b"], EPI_RES, res=x)
-        # --- GEGLU feed-forward (attention.py:401)
+        x = ops.gemm(a2, W[t + ".attn2.o.w"], nxt(x), W[t + ".attn2.o.b"], EPI_RES, res=x)
+        # --- GEGLU feed-forward (attention.py:401): the sum is only consumed by proj_out's matrix product -> fp16
         n3 = ops.layernorm(x, self.buf("st.ln", (M, C)), W[t + ".norm3.g"], W[t + ".norm3.b"], Bn, N)
-        x = self._feed_forward(n3, x, t + ".ff", M, C, "st.x6")
+        x16 = self._feed_forward(n3, x, t + ".ff", M, C, self.buf("st.x6", (M, C)))
         # --- proj_out + residual (attention.py:444-446)
-        return ops.gemm(x, W[p + ".proj_out.w"], self.buf(out_tag, (M, C)), W[p + ".proj_out.b"], EPI_RES, res=x_in)
+        o32, o16 = self._stream(out_tag, M, C)
+        ops.gemm(x16, W[p + ".proj_out.w"], o32, W[p + ".proj_out.b"], EPI_RES, res=xin32, out16=o16)
+        return o32, o16
 
     # ------------------------------------------------------------------ one forward (eager launch sequence)
     def _launch_forward(self, x_lat: torch.Tensor, t_buf: torch.Tensor, reps: int, fuser_on: bool, sd_conv: bool,
@@ -261,8 +282,10 @@ class UNetEngine:
         # first conv on the zero-padded NHWC latent (openaimodel.py:299, :393-405)
         xin = ops.pack_latent(x_lat, CIN_PAD, reps, self.buf("in.x", (Bn * side * side, CIN_PAD)))
         fc = "sd_first_conv" if sd_conv else "input_blocks.0.0"
-        h = ops.conv3x3(xin, W[fc + ".w"], self.buf("skip.0", (Bn * side * side, mc)), Bn, side, side, W[fc + ".b"])
-        skips: List[Tuple[torch.Tensor, int]] = [(h, side)]
+        M0 = Bn * side * side
+        h = self._stream("skip.0", M0, mc)
+        ops.conv3x3(xin, W[fc + ".w"], h[0], Bn, side, side, W[fc + ".b"], out16=h[1])
+        skips: List[Tuple[Tuple[torch.Tensor, torch.Tensor], int]] = [(h, side)]
 
         def run_block(b: Block, h, side, bi: str, skip=None):
             for j, l in enumerate(b.layers):
@@ -273,12 +296,14 @@ class UNetEngine:
                 elif l.kind == "st":
                     h = self._spatial_transformer(l, st_index[l.prefix], h, Bn, side, fuser_on, tag)
                 elif l.kind == "down":
-                    h = ops.conv3x3(h, W[l.prefix + ".w"], self.buf(tag, (Bn * (side // 2) ** 2, l.cout)), Bn, side, side,
-                                    W[l.prefix + ".b"], stride=2)
+                    o = self._stream(tag, Bn * (side // 2) ** 2, l.cout)
+                    ops.conv3x3(h[1], W[l.prefix + ".w"], o[0], Bn, side, side, W[l.prefix + ".b"], stride=2, out16=o[1])
+                    h = o
                     side //= 2
                 elif l.kind == "up":
-                    h = ops.conv3x3(h, W[l.prefix + ".w"], self.buf(tag, (Bn * (side * 2) ** 2, l.cout)), Bn, side, side,
-                                    W[l.prefix + ".b"], upsample2x=True)
+                    o = self._stream(tag, Bn * (side * 2) ** 2, l.cout)
+                    ops.conv3x3(h[1], W[l.prefix + ".w"], o[0], Bn, side, side, W[l.prefix + ".b"], upsample2x=True, out16=o[1])
+                    h = o
                     side *= 2
             return h, side
 
@@ -290,7 +315,7 @@ class UNetEngine:
             sk, sside = skips.pop()
             assert sside == side
             h, side = run_block(b, h, side, f"out.{i}", skip=sk)
-        g = self._groupnorm(h, None, Bn, side * side, "out.0", 1e-5, True, "fin.gn")
+        g = self._groupnorm(h[1], None, Bn, side * side, "out.0", 1e-5, True, "fin.gn")
         ops.conv3x3(g, W["out.2.w"], eps_out, Bn, side, side, W["out.2.b"], nchw_hw=side * side)
 
     # ------------------------------------------------------------------ public forward

@@ -12,7 +12,7 @@ import torch
 
 from . import _lib
 from ._lib import (EPI_BIAS, EPI_GATE_RES, EPI_GEGLU, EPI_RES, EPI_ROWBIAS, EPI_SILU, OUT_F16_ROWMAJOR, OUT_F32_NCHW,
-                   AttnArgs, ConvArgs, GemmArgs, check)
+                   OUT_F32_ROWMAJOR, AttnArgs, ConvArgs, GemmArgs, check)
 
 F16 = torch.float16
 F32 = torch.float32
@@ -68,7 +68,9 @@ def _workspace(device) -> torch.Tensor:
     return t
 
 
-def _fill_epilogue(g: GemmArgs, epi, out, N_out, bias, res, gate, rowbias, rows_per_sample, nchw_hw):
+def _fill_epilogue(g: GemmArgs, epi, out, N_out, bias, res, gate, rowbias, rows_per_sample, nchw_hw, out16=None):
+    """``out`` fp16 [M, N] (plain), fp32 [M, N] (residual stream; ``out16`` = optional fp16 copy) or, with ``nchw_hw``,
+    fp32 NCHW.  ``res`` may be fp16 or fp32 (residual stream)."""
     ws = _workspace(out.device)
     g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     g.bias = _ptr(bias)
@@ -80,14 +82,24 @@ def _fill_epilogue(g: GemmArgs, epi, out, N_out, bias, res, gate, rowbias, rows_
         g.out_mode, g.hw = OUT_F32_NCHW, nchw_hw
         g.out, g.ldc = out.data_ptr(), 0
     else:
-        _req(out, F16, "out", 8)
+        f32out = out.dtype == F32
+        _req(out, F32 if f32out else F16, "out", 16 if f32out else 8)
         r, c, ld = _rows(out, "out")
         if c != N_out:
             raise ValueError(f"out has {c} columns, expected {N_out}")
-        g.out_mode, g.hw = OUT_F16_ROWMAJOR, 0
+        g.out_mode, g.hw = (OUT_F32_ROWMAJOR if f32out else OUT_F16_ROWMAJOR), 0
         g.out, g.ldc = out.data_ptr(), ld
+        if out16 is not None:
+            if not f32out:
+                raise ValueError("out16 (fp16 copy) only goes with an fp32 out")
+            _req(out16, F16, "out16", 8)
+            r2, c2, ld2 = _rows(out16, "out16")
+            if (r2, c2) != (r, c):
+                raise ValueError("out16 shape mismatch")
+            g.out2, g.ldc2 = out16.data_ptr(), ld2
     if res is not None:
-        _req(res, F16, "res", 8)
+        g.res_f32 = int(res.dtype == F32)
+        _req(res, F32 if g.res_f32 else F16, "res", 16 if g.res_f32 else 8)
         g.res, g.ldres = res.data_ptr(), _rows(res, "res")[2]
     if gate is not None:
         _req(gate, F32, "gate", 4)
@@ -98,7 +110,7 @@ def _fill_epilogue(g: GemmArgs, epi, out, N_out, bias, res, gate, rowbias, rows_
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias=None, epi: int = EPI_BIAS, res=None, gate=None,
-         rowbias=None, rows_per_sample: int = 0, a2: Optional[torch.Tensor] = None, nchw_hw: int = 0) -> torch.Tensor:
+         rowbias=None, rows_per_sample: int = 0, a2: Optional[torch.Tensor] = None, nchw_hw: int = 0, out16=None) -> torch.Tensor:
     """out = [a | a2] @ w.T (+ epilogue).  a [M, K1], a2 [M, K2] (optional), w [N, K1+K2] fp16."""
     _req(a, F16, "a")
     _req(w, F16, "w")
@@ -118,14 +130,14 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias=None, epi: in
         raise ValueError(f"a has K={K1}, w has K={K}")
     g.w = w.data_ptr()
     g.M, g.N, g.K = M, N, K
-    _fill_epilogue(g, epi, out, N // 2 if epi == EPI_GEGLU else N, bias, res, gate, rowbias, rows_per_sample, nchw_hw)
+    _fill_epilogue(g, epi, out, N // 2 if epi == EPI_GEGLU else N, bias, res, gate, rowbias, rows_per_sample, nchw_hw, out16)
     check(_lib.lib().gl_gemm(C.byref(g), _stream()), "gl_gemm")
     return out
 
 
 def conv3x3(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, B: int, Hin: int, Win: int, bias=None,
             stride: int = 1, upsample2x: bool = False, epi: int = EPI_BIAS, res=None, rowbias=None,
-            rows_per_sample: int = 0, nchw_hw: int = 0, n_valid: Optional[int] = None) -> torch.Tensor:
+            rows_per_sample: int = 0, nchw_hw: int = 0, n_valid: Optional[int] = None, out16=None) -> torch.Tensor:
     """x [B*Hin*Win, Cin] fp16 NHWC; w [Cout, 9*Cin] fp16 (tap-major, channel-minor)."""
     _req(x, F16, "x")
     _req(w, F16, "w")
@@ -145,7 +157,7 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, B: int, Hin: in
     a.stride, a.upsample2x = stride, int(upsample2x)
     a.g.w = w.data_ptr()
     a.g.N = N if n_valid is None else n_valid
-    _fill_epilogue(a.g, epi, out, a.g.N, bias, res, None, rowbias, rows_per_sample, nchw_hw)
+    _fill_epilogue(a.g, epi, out, a.g.N, bias, res, None, rowbias, rows_per_sample, nchw_hw, out16)
     check(_lib.lib().gl_conv3x3(C.byref(a), _stream()), "gl_conv3x3")
     return out
 
@@ -219,17 +231,23 @@ def groupnorm(x1: torch.Tensor, x2: Optional[torch.Tensor], B: int, HW: int, gam
 
 
 def layernorm(x: torch.Tensor, y: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, B: int, rows_in: int,
-              rows_out: Optional[int] = None, row_off: int = 0, eps: float = 1e-5) -> torch.Tensor:
-    """x [B*rows_in, C] -> y rows b*rows_out + row_off + i (y is [B*rows_out, C])."""
-    _req(x, F16, "x")
+              rows_out: Optional[int] = None, row_off: int = 0, eps: float = 1e-5, stats: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [B*rows_in, C] fp16 or fp32 (residual stream) -> y fp16 rows b*rows_out + row_off + i (y is [B*rows_out, C]);
+    ``stats`` (optional fp32 [B*rows_in, 2]) receives (mean, rstd) per row."""
+    xf32 = x.dtype == F32
+    _req(x, F32 if xf32 else F16, "x")
     _req(y, F16, "y")
     _req(gamma, F32, "gamma")
     _req(beta, F32, "beta")
     _, Cc, ldx = _rows(x, "x")
     _, _, ldy = _rows(y, "y")
     rows_out = rows_in if rows_out is None else rows_out
-    check(_lib.lib().gl_layernorm(x.data_ptr(), ldx, y.data_ptr(), ldy, gamma.data_ptr(), beta.data_ptr(), B, rows_in,
-                                  rows_out, row_off, Cc, eps, _stream()), "gl_layernorm")
+    if stats is not None:
+        _req(stats, F32, "stats", 8)
+        if stats.numel() < 2 * B * rows_in:
+            raise ValueError("stats buffer too small")
+    check(_lib.lib().gl_layernorm(x.data_ptr(), ldx, int(xf32), y.data_ptr(), ldy, gamma.data_ptr(), beta.data_ptr(), B, rows_in,
+                                  rows_out, row_off, Cc, eps, _ptr(stats), _stream()), "gl_layernorm")
     return y
 
 
@@ -243,11 +261,20 @@ def rela_pool(hid, B, H, W, Cc, rects, nvalid, poison, max_objs, feat):
     return feat
 
 
-def rela_merge(x, hid, f, B, H, W, Cc, rects, nvalid, poison, max_objs, y):
-    for t, n in ((x, "x"), (hid, "hid"), (f, "f"), (y, "y")):
-        _req(t, F16, n)
-    check(_lib.lib().gl_rela_merge(x.data_ptr(), hid.data_ptr(), f.data_ptr(), B, H, W, Cc, rects.data_ptr(),
-                                   nvalid.data_ptr(), poison.data_ptr(), max_objs, y.data_ptr(), _stream()),
+def rela_merge(x, hid, f, B, H, W, Cc, rects, nvalid, poison, max_objs, y, ln_stats=None, gamma=None, beta=None):
+    """y = 0.5 * (x + hid + (1/max_objs) sum_i 1[p in rect_i] f_i); x / y fp16 or fp32 (same dtype).  With ``ln_stats``
+    (+ gamma, beta) hid = LayerNorm(x) is re-evaluated in fp32 from the stored (mean, rstd) instead of read from ``hid``."""
+    xf32 = x.dtype == F32
+    for t, n in ((x, "x"), (y, "y")):
+        _req(t, F32 if xf32 else F16, n)
+    _req(f, F16, "f")
+    if ln_stats is None:
+        _req(hid, F16, "hid")
+    else:
+        for t, n in ((ln_stats, "ln_stats"), (gamma, "gamma"), (beta, "beta")):
+            _req(t, F32, n, 8)
+    check(_lib.lib().gl_rela_merge(x.data_ptr(), int(xf32), _ptr(hid), _ptr(ln_stats), _ptr(gamma), _ptr(beta), f.data_ptr(), B, H, W,
+                                   Cc, rects.data_ptr(), nvalid.data_ptr(), poison.data_ptr(), max_objs, y.data_ptr(), _stream()),
           "gl_rela_merge")
     return y
 

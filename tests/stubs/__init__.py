@@ -97,7 +97,7 @@ def write_synthetic_checkpoint(path, cfg, vae_cfg, seed=0, max_relations=10, wit
     """A checkpoint with the reference's container: {model, autoencoder, text_encoder, diffusion, config_dict._content}
     (interface.py:79-94) holding recipe weights of ``cfg`` / ``vae_cfg``; the text encoder node targets StubTextEncoder."""
     from layoutllm_t2i_amd import recipe
-    t = lambda d: {k: torch.from_numpy(np.ascontiguousarray(np.asarray(v, dtype=np.float32))) for k, v in d.items()}
+    t = lambda d: {k: torch.tensor(np.asarray(v, dtype=np.float32)) for k, v in d.items()}     # 0-d gates stay 0-d
     content = {
         "model": {"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel",
                   "params": {"image_size": cfg.image_size, "in_channels": cfg.in_channels, "model_channels": cfg.model_channels,
