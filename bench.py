@@ -151,19 +151,20 @@ def main():
            recipe.synth_inputs(cfg, B, side, n_boxes=args.boxes, n_rel=3, seed=1234 + rank).items()}
     batch = dict(boxes=inp["boxes"], masks=inp["masks"], text_embeddings=inp["positive_embeddings"])
 
-    # ---- HIP-event timing of every UNet forward launch (graph replay) on the launch stream
+    # ---- HIP-event timing of every UNet forward launch (graph replay) on the launch stream.  The sampler issues one
+    # gl_plms_step per evaluation = the forward's graph + two tiny elementwise kernels (CFG combine, x_prev update).
     eng = model.engine
     fwd_events = []
-    orig_forward = eng.forward
+    orig_step = eng.plms_step
 
-    def timed_forward(x_lat, t, fuser_scale=1.0, sd_conv=False, reps=1, eps_out=None):
+    def timed_step(x_eval, x_base, x_out, e_out, e_terms, coefs, div, t, reps, guidance, fuser_scale, sd_conv, *sched):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        out = orig_forward(x_lat, t, fuser_scale, sd_conv, reps, eps_out)
+        out = orig_step(x_eval, x_base, x_out, e_out, e_terms, coefs, div, t, reps, guidance, fuser_scale, sd_conv, *sched)
         e1.record()
-        fwd_events.append((e0, e1, fuser_scale != 0, x_lat.shape[0] * reps))
+        fwd_events.append((e0, e1, fuser_scale != 0, x_eval.shape[0] * reps))
         return out
-    eng.forward = timed_forward
+    eng.plms_step = timed_step
 
     vae_events = []
 
@@ -263,7 +264,8 @@ def main():
                    "parallelism": f"replicas x{world}, one weight broadcast, no per-step collectives"},
         "unet_step_ms": round(gpu_ms / max(n_fwd, 1), 3),
         "vae_decode_ms_per_batch": (round(sum(a.elapsed_time(b) for a, b in vae_events) / max(len(vae_events), 1), 2) if vae_events else None),
-        "step_includes": f"PLMS denoise ({args.plms_steps + 1} x 2B UNet forward)" + (" + VAE decode to fp32 images" if vae is not None else ""),
+        "step_includes": f"PLMS denoise ({args.plms_steps + 1} x gl_plms_step: 2B UNet forward + CFG + update)" + (" + VAE decode to fp32 images" if vae is not None else ""),
+        "launches_per_forward": eng.num_launches(),
         "images_per_sec_per_gpu": round(value / world, 4),
         "roofline": roofline,
         "setup_s": round(setup_s, 1),
@@ -303,7 +305,7 @@ def main():
         # the oracle as CHECKER of the batch the benchmark actually ran (same tiles / split-K dispatch): sample 0 of the
         # 2B batch = synth sample 0 (cond), sample B = its unconditional twin; unrounded fp32 weights on the oracle side
         cat = lambda a, b: torch.cat([a, b], 0)
-        eng.forward = orig_forward
+        eng.plms_step = orig_step
         eng.set_conditioning(cat(inp["context"], inp["uc"]), cat(inp["relations"], inp["relations"]), cat(inp["boxes"], zz(inp["boxes"])),
                              cat(inp["masks"], zz(inp["masks"])), cat(inp["positive_embeddings"], zz(inp["positive_embeddings"])), side)
         rl2 = lambda a, b: float((a.float().cpu() - b).norm() / b.norm())

@@ -203,6 +203,77 @@ int gl_latent_affine_pack(const float* z, const float* w, const float* bias, flo
                           int32_t hw, int32_t Cpad, void* out, void* stream);
 int gl_softmax_rows(void* x, int32_t rows, int32_t n, int32_t ld, float scale, void* stream);
 
+/* =====================================================================================================
+ * Forward-level API ("what a C-ABI replacement must export underneath"): one handle per device per
+ * thread owns the block plan, the packed weights' layout, the activation pool, the hoisted conditioning and the
+ * captured hipGraphs, so that a host in ANY language can run UNetModel.forward (openaimodel.py:413-459) and a PLMS
+ * step (plms.py:110-163) through plain C calls.  All data pointers are DEVICE pointers owned by the caller.
+ * ===================================================================================================== */
+typedef struct gl_unet_config {          /* UNetModel.__init__ arguments (openaimodel.py:234-262; coco2014.yaml:9-30) */
+    int32_t in_channels, model_channels, out_channels, num_res_blocks;
+    int32_t n_levels;            int32_t channel_mult[8];
+    int32_t n_attn_res;          int32_t attention_resolutions[8];     /* downsample factors that carry a transformer */
+    int32_t num_heads, context_dim;
+    int32_t pos_in_dim, pos_out_dim, fourier_freqs;                    /* PositionNet (text_grounding_net.py:7-24) */
+    int32_t max_objs;                                                  /* 30 (interface.py:158,425) */
+} gl_unet_config;
+
+typedef struct gl_engine gl_engine;      /* opaque */
+
+typedef struct gl_weight_info {          /* one packed tensor of the flat weight buffer */
+    char name[160];                      /* e.g. "input_blocks.1.1.transformer_blocks.0.attn1.qkv.w" (weights.py naming) */
+    int64_t offset, nbytes;              /* 256-byte aligned slot inside the flat buffer */
+    int32_t dtype;                       /* 0 = fp16, 1 = fp32 */
+    int32_t ndim;   int64_t shape[4];
+} gl_weight_info;
+
+/* gl_create builds the plan and the weight table (no GPU needed); gl_destroy frees pool, graphs and the handle. */
+int gl_create(const gl_unet_config* cfg, gl_engine** out);
+int gl_destroy(gl_engine* e);
+/* The packed-weight layout is defined HERE (the host packer fills it): count, i-th entry, total bytes. */
+int gl_num_weights(const gl_engine* e);
+int gl_weight_at(const gl_engine* e, int32_t i, gl_weight_info* info);
+int64_t gl_weights_bytes(const gl_engine* e);
+/* gl_load_weights: `packed` = device buffer laid out per the table (stays owned by the caller and must outlive the
+ * handle); has_sd_conv != 0 when the "sd_first_conv.*" slots are filled (GLIGEN/SD_input_conv_weight_bias.pth). */
+int gl_load_weights(gl_engine* e, const void* packed, int64_t bytes, int32_t has_sd_conv, void* stream);
+/* gl_set_conditioning: everything that depends only on the image's conditioning, hoisted out of the 102 forwards
+ * (PositionNet tokens text_grounding_net.py:26-43, fuser.linear attention.py:228, attn2 / rela_fuse K,V projections
+ * attention.py:124-125,348-349, integer box rectangles attention.py:321-346).  fp32 inputs: context [Bn, Lc, ctx],
+ * relations [Bn, R, ctx], boxes [Bn, max_objs, 4], masks [Bn, max_objs], pos_emb [Bn, max_objs, pos_in_dim]; null
+ * grounding = zeros (text_layout_tokinzer_input.py:47-62).  hw = latent side. */
+int gl_set_conditioning(gl_engine* e, const float* context, const float* relations, const float* boxes,
+                        const float* masks, const float* pos_emb, int32_t Bn, int32_t Lc, int32_t R, int32_t hw,
+                        void* stream);
+/* gl_unet_forward: eps[Bn, out_ch, hw, hw] fp32 = UNet(x, t | conditioning).  x fp32 NCHW [Bn / reps, in_ch, hw, hw]:
+ * with reps = 2 both CFG halves of a [cond ; uncond] conditioning batch share the latent.  t_dev: fp32 [Bn] device
+ * timesteps, or NULL to use t_host for every sample.  fuser_scale = what set_alpha_scale wrote (interface.py:34-38;
+ * 0 skips the gated self-attention exactly); sd_conv != 0 = restore_first_conv_from_SD is in effect
+ * (openaimodel.py:393-405).  Replays a hipGraph captured on first use of each (shape, fuser on/off, conv) variant
+ * unless use_graph == 0. */
+int gl_unet_forward(gl_engine* e, const float* x, const float* t_dev, float t_host, int32_t reps, float fuser_scale,
+                    int32_t sd_conv, float* eps, int32_t use_graph, void* stream);
+/* gl_plms_step: one denoiser evaluation + classifier-free guidance + the PLMS / DDIM-sigma-0 update
+ * (plms.py:110-163): eps = UNet(x_eval, t); e_out = eps_u + guidance (eps_c - eps_u) (reps == 2) or eps;
+ * e' = (sum_j coef[j] * e_terms[j]) / div over n_terms <= 4 terms (Adams-Bashforth forms plms.py:144-159; terms
+ * may alias e_out); x_out = sqrt_aprev * (x_base - s1m e') / sqrt_at + dir_coef * e', evaluated in the
+ * reference's operation order (bit-identical to torch fp32 given the same eps). */
+typedef struct gl_plms_step_args {
+    const float* x_eval;  const float* x_base;  float* x_out;       /* fp32 [B, C, hw, hw] */
+    float* e_out;                                                    /* guided eps of this evaluation */
+    const float* e_terms[4];  float coef[4];  int32_t n_terms;  float div;
+    float t;  int32_t reps;  float guidance;  float fuser_scale;  int32_t sd_conv;
+    float sqrt_at, s1m, sqrt_aprev, dir_coef;
+    int32_t use_graph;
+} gl_plms_step_args;
+int gl_plms_step(gl_engine* e, const gl_plms_step_args* a, void* stream);
+/* introspection for tests / tools */
+int64_t gl_pool_bytes(const gl_engine* e);
+int gl_num_launches(const gl_engine* e);       /* kernel launches of the last eagerly executed / captured forward */
+int gl_sizeof_unet_config(void);
+int gl_sizeof_weight_info(void);
+int gl_sizeof_plms_step_args(void);
+
 int gl_gemm(const gl_gemm_args* a, void* stream);
 int gl_conv3x3(const gl_conv_args* a, void* stream);
 int gl_attention(const gl_attn_args* a, void* stream);
@@ -217,7 +288,7 @@ int gl_sizeof_attn_args(void);
  * 3 always 8 waves, 4 always 4 waves); keys 4-7 = small-tile / split-K / 256-row-tile thresholds; key 8 = short-K GEGLU
  * GEMMs on the BK 32 / 4-blocks-per-CU variant (1 default, 0 off); key 10 = s_setprio around the attention MFMA
  * clusters (-1 auto, 0 off, 1 on); key 13 = intra-block K-split GEMM/conv variants (0 off, 1 auto = default, 2 always);
- * key 16 = GroupNorm apply pixels per block. */
+ * key 16 = GroupNorm apply pixels per block; key 20 = (tests) execute the gated-SA fuser even at fuser_scale 0. */
 int gl_set_option(int key, int value);
 /* one-time per-process setup (raises dynamic-LDS limits of the tiled kernels); idempotent */
 int gl_init(void);

@@ -66,6 +66,35 @@ class AttnArgs(C.Structure):
     ]
 
 
+class UNetConfigC(C.Structure):
+    """gl_unet_config"""
+    _fields_ = [
+        ("in_channels", i32), ("model_channels", i32), ("out_channels", i32), ("num_res_blocks", i32),
+        ("n_levels", i32), ("channel_mult", i32 * 8),
+        ("n_attn_res", i32), ("attention_resolutions", i32 * 8),
+        ("num_heads", i32), ("context_dim", i32),
+        ("pos_in_dim", i32), ("pos_out_dim", i32), ("fourier_freqs", i32),
+        ("max_objs", i32),
+    ]
+
+
+class WeightInfo(C.Structure):
+    """gl_weight_info"""
+    _fields_ = [("name", C.c_char * 160), ("offset", i64), ("nbytes", i64), ("dtype", i32), ("ndim", i32), ("shape", i64 * 4)]
+
+
+class PlmsStepArgs(C.Structure):
+    """gl_plms_step_args"""
+    _fields_ = [
+        ("x_eval", vp), ("x_base", vp), ("x_out", vp),
+        ("e_out", vp),
+        ("e_terms", vp * 4), ("coef", f32 * 4), ("n_terms", i32), ("div", f32),
+        ("t", f32), ("reps", i32), ("guidance", f32), ("fuser_scale", f32), ("sd_conv", i32),
+        ("sqrt_at", f32), ("s1m", f32), ("sqrt_aprev", f32), ("dir_coef", f32),
+        ("use_graph", i32),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/gligen_hip.h declares
 PROTOTYPES = {
     "gl_gemm": (i32, [C.POINTER(GemmArgs), vp]),
@@ -90,6 +119,20 @@ PROTOTYPES = {
     "gl_sizeof_conv_args": (i32, []),
     "gl_sizeof_attn_args": (i32, []),
     "gl_init": (i32, []),
+    "gl_create": (i32, [C.POINTER(UNetConfigC), C.POINTER(vp)]),
+    "gl_destroy": (i32, [vp]),
+    "gl_num_weights": (i32, [vp]),
+    "gl_weight_at": (i32, [vp, i32, C.POINTER(WeightInfo)]),
+    "gl_weights_bytes": (i64, [vp]),
+    "gl_load_weights": (i32, [vp, vp, i64, i32, vp]),
+    "gl_set_conditioning": (i32, [vp, fp, fp, fp, fp, fp, i32, i32, i32, i32, vp]),
+    "gl_unet_forward": (i32, [vp, fp, fp, f32, i32, f32, i32, fp, i32, vp]),
+    "gl_plms_step": (i32, [vp, C.POINTER(PlmsStepArgs), vp]),
+    "gl_pool_bytes": (i64, [vp]),
+    "gl_num_launches": (i32, [vp]),
+    "gl_sizeof_unet_config": (i32, []),
+    "gl_sizeof_weight_info": (i32, []),
+    "gl_sizeof_plms_step_args": (i32, []),
     "gl_set_option": (i32, [i32, i32]),
 }
 
@@ -123,7 +166,9 @@ def lib() -> C.CDLL:
         fn.argtypes = args
     if l.gl_abi_version() != ABI_VERSION:
         raise HipLibraryError(f"ABI version mismatch: lib {l.gl_abi_version()} vs host {ABI_VERSION}")
-    for cls, fn in ((GemmArgs, l.gl_sizeof_gemm_args), (ConvArgs, l.gl_sizeof_conv_args), (AttnArgs, l.gl_sizeof_attn_args)):
+    for cls, fn in ((GemmArgs, l.gl_sizeof_gemm_args), (ConvArgs, l.gl_sizeof_conv_args), (AttnArgs, l.gl_sizeof_attn_args),
+                    (UNetConfigC, l.gl_sizeof_unet_config), (WeightInfo, l.gl_sizeof_weight_info),
+                    (PlmsStepArgs, l.gl_sizeof_plms_step_args)):
         if C.sizeof(cls) != fn():
             raise HipLibraryError(f"struct size mismatch for {cls.__name__}: host {C.sizeof(cls)} vs lib {fn()}")
     _lib = l
@@ -140,6 +185,42 @@ def init_device(index=None) -> None:
         with torch.cuda.device(index):
             check(lib().gl_init(), "gl_init")
         _inited.add(index)
+
+
+def unet_config_c(cfg) -> UNetConfigC:
+    """arch.UNetConfig -> gl_unet_config"""
+    c = UNetConfigC()
+    c.in_channels, c.model_channels, c.out_channels, c.num_res_blocks = cfg.in_channels, cfg.model_channels, cfg.out_channels, cfg.num_res_blocks
+    if len(cfg.channel_mult) > 8 or len(cfg.attention_resolutions) > 8:
+        raise ValueError("at most 8 levels / attention resolutions")
+    c.n_levels = len(cfg.channel_mult)
+    for i, m in enumerate(cfg.channel_mult):
+        c.channel_mult[i] = int(m)
+    c.n_attn_res = len(cfg.attention_resolutions)
+    for i, m in enumerate(cfg.attention_resolutions):
+        c.attention_resolutions[i] = int(m)
+    c.num_heads, c.context_dim = cfg.num_heads, cfg.context_dim
+    c.pos_in_dim, c.pos_out_dim, c.fourier_freqs, c.max_objs = cfg.pos_in_dim, cfg.pos_out_dim, cfg.fourier_freqs, cfg.max_objs
+    return c
+
+
+def create_engine(cfg) -> int:
+    """gl_create: returns the opaque handle (an int address).  Needs no GPU."""
+    h = vp()
+    cc = unet_config_c(cfg)
+    check(lib().gl_create(C.byref(cc), C.byref(h)), "gl_create")
+    return h.value
+
+
+def weight_table(handle: int):
+    """[(name, offset, nbytes, dtype 0 = fp16 / 1 = fp32, shape)] of the flat packed-weight buffer, + total bytes"""
+    l = lib()
+    out = []
+    info = WeightInfo()
+    for i in range(l.gl_num_weights(handle)):
+        check(l.gl_weight_at(handle, i, C.byref(info)), "gl_weight_at")
+        out.append((info.name.decode(), int(info.offset), int(info.nbytes), int(info.dtype), tuple(int(info.shape[k]) for k in range(info.ndim))))
+    return out, int(l.gl_weights_bytes(handle))
 
 
 def check(code: int, what: str) -> None:

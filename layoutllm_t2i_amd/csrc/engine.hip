@@ -1,0 +1,938 @@
+// Forward-level engine behind the C ABI: UNetModel.forward (openaimodel.py:413-459) and one PLMS step
+// (plms.py:110-163) as a launch sequence over this library's kernels, with the block plan, the packed-weight
+// layout, the activation pool, the hoisted conditioning and hipGraph capture / replay owned by one handle.
+//
+// What is result-identical restructuring of the reference (verified in tests/):
+//   * token-major fp16 operands, fp32 residual stream: every block output / residual sum is produced in fp32 by the
+//     GEMM / conv epilogue (+ an fp16 copy where a matrix-core consumer needs one);
+//   * concat / residual / time-embedding / GEGLU / gates fused into GEMM and conv epilogues;
+//   * conditioning-only work hoisted into gl_set_conditioning (once per image instead of 102 times);
+//   * the gated self-attention fuser skipped outright at scale 0 (exact identity);
+//   * RelationCrossAttention in closed form (rela.hip);
+//   * one hipGraph per (shape, fuser on/off, first-conv variant), replayed per step.
+#include "common.h"
+#include "gligen_hip.h"
+
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <tuple>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+constexpr int CIN_PAD = 64;              // the 4-channel latent is zero-padded to one 64-channel K block
+constexpr int64_t ALIGN = 256;
+constexpr int64_t WS_BYTES = 96ll << 20; // split-K fp32 partial tiles
+int g_force_fuser = 0;                   // test knob (gl_set_option 20): execute the fuser even at scale 0 (zero gates)
+
+enum Kind { CONV_IN = 0, RES = 1, ST = 2, DOWN = 3, UP = 4 };
+struct LayerD {
+    int kind;
+    std::string prefix;
+    int cin, cout, d_head;
+};
+struct BlockD {
+    std::vector<LayerD> layers;
+};
+struct WInfo {
+    int64_t off, bytes;
+    int dtype, ndim;
+    int64_t shape[4];
+};
+
+__global__ void f32_to_f16_kernel(const float* __restrict__ x, half_t* __restrict__ y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = (half_t)x[i];
+}
+__global__ void fill_f32_kernel(float* __restrict__ y, float v, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = v;
+}
+
+// Integer pixel rectangles of RelationCrossAttention.forward (attention.py:321-346) for one resolution, one thread per
+// sample (the `break` at the first padded or degenerate box is sequential).  Arithmetic mirrors the reference exactly:
+// float32 multiply by the python int, truncation toward zero (.to(torch.int)), x1 / y1 clamped with torch.minimum,
+// x0 / y0 not clamped, then python slice semantics (negative indices wrap once, then clamp).  rects = (top, bottom, left,
+// right) of the EFFECTIVE slice; poison = 1 where a used box has an empty slice (torch.mean of nothing = NaN).
+#pragma clang fp contract(off)
+__device__ __forceinline__ void py_slice(int start, int stop, int len, int* s, int* e) {
+    if (start < 0) { start += len; if (start < 0) start = 0; } else if (start > len) start = len;
+    if (stop < 0) { stop += len; if (stop < 0) stop = 0; } else if (stop > len) stop = len;
+    *s = start;
+    *e = stop > start ? stop : start;
+}
+__global__ void rela_rects_kernel(const float* __restrict__ boxes, const float* __restrict__ masks, int B, int n, int h, int w,
+                                  int* __restrict__ rects, int* __restrict__ nvalid, int* __restrict__ poison) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= B) return;
+    float count = 0.0f;
+    for (int i = 0; i < n; ++i) count += masks[(size_t)k * n + i];
+    int nv = 0, bad = 0;
+    bool open = true;
+    for (int i = 0; i < n; ++i) {
+        int* r = rects + ((size_t)k * n + i) * 4;
+        r[0] = r[1] = r[2] = r[3] = 0;
+        if (!open) continue;
+        const float* bx = boxes + ((size_t)k * n + i) * 4;
+        const int left = (int)(bx[0] * (float)w);
+        const int top = (int)(bx[1] * (float)h);
+        const int right = (int)fminf(bx[2] * (float)w, (float)w);
+        const int bottom = (int)fminf(bx[3] * (float)h, (float)h);
+        if ((float)i < count && left != right && top != bottom) {
+            int t, b, l, rr;
+            py_slice(top, bottom, h, &t, &b);
+            py_slice(left, right, w, &l, &rr);
+            r[0] = t; r[1] = b; r[2] = l; r[3] = rr;
+            if ((b - t) * (rr - l) == 0) bad = 1;
+            nv = i + 1;
+        } else {
+            open = false;
+        }
+    }
+    nvalid[k] = nv;
+    poison[k] = bad;
+}
+#pragma clang fp contract(fast)
+
+}  // namespace
+
+struct gl_engine {
+    gl_unet_config cfg;
+    std::vector<BlockD> input_blocks, output_blocks;
+    BlockD middle;
+    int out_channels_last = 0;
+    std::vector<LayerD> st_layers;
+    // packed weights
+    std::vector<std::string> names;
+    std::unordered_map<std::string, WInfo> tab;
+    int64_t total_bytes = 0;
+    const char* wbase = nullptr;
+    bool has_sd = false;
+    std::unordered_map<std::string, int> emb_off;
+    int emb_total = 0;
+    std::vector<float> gate_tanh;      // [n_st][4]: fuser attn, fuser dense, rela attn, rela dense
+    // pool
+    struct Buf { void* p; size_t bytes; };
+    std::unordered_map<std::string, Buf> pool;
+    bool pool_changed = false, capturing = false;
+    int device = -1;
+    // conditioning
+    bool cond_set = false;
+    int Bn = 0, R = 0, Lc = 0, hw = 0;
+    // graphs
+    std::map<std::tuple<int, int, int, int, int, int, int>, hipGraphExec_t> graphs;
+    float fuser_scale_cur = -1e30f;
+    std::vector<float> gate_host;      // the [n_st][4] array last uploaded (kept alive for the async copy)
+    int launches = 0;
+    std::string err;
+    hipStream_t cap_stream = nullptr;  // graphs are captured on an engine-owned stream (the caller's may be the legacy
+                                       // default stream, which cannot be captured) and launched on the caller's
+
+    // ------------------------------------------------------------------ helpers
+    const WInfo* wi(const std::string& n) const {
+        auto it = tab.find(n);
+        return it == tab.end() ? nullptr : &it->second;
+    }
+    const void* W(const std::string& n) const {
+        auto it = tab.find(n);
+        if (it == tab.end() || wbase == nullptr) return nullptr;
+        return wbase + it->second.off;
+    }
+    const float* Wf(const std::string& n) const { return reinterpret_cast<const float*>(W(n)); }
+
+    void* buf(const std::string& tag, size_t bytes) {
+        auto it = pool.find(tag);
+        if (it != pool.end() && it->second.bytes >= bytes) return it->second.p;
+        if (capturing) { err = "pool allocation during graph capture: " + tag; return nullptr; }
+        if (it != pool.end()) { (void)hipFree(it->second.p); pool.erase(it); }
+        void* p = nullptr;
+        const size_t rounded = (bytes + 255) / 256 * 256;
+        if (hipMalloc(&p, rounded) != hipSuccess) { err = "hipMalloc failed for " + tag; return nullptr; }
+        pool[tag] = Buf{p, rounded};
+        pool_changed = true;
+        return p;
+    }
+    half_t* h16(const std::string& tag, size_t n) { return reinterpret_cast<half_t*>(buf(tag, n * 2)); }
+    float* f32(const std::string& tag, size_t n) { return reinterpret_cast<float*>(buf(tag, n * 4)); }
+
+    void drop_graphs() {
+        for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
+        graphs.clear();
+    }
+};
+
+namespace {
+
+void add_w(gl_engine* e, const std::string& name, int dtype, std::initializer_list<int64_t> shape) {
+    WInfo w{};
+    w.dtype = dtype;
+    w.ndim = (int)shape.size();
+    int64_t n = 1;
+    int i = 0;
+    for (int64_t s : shape) { w.shape[i++] = s; n *= s; }
+    w.bytes = n * (dtype == 0 ? 2 : 4);
+    w.off = e->total_bytes;
+    e->total_bytes += (w.bytes + ALIGN - 1) / ALIGN * ALIGN;
+    e->tab[name] = w;
+    e->names.push_back(name);
+}
+void add_lin(gl_engine* e, const std::string& p, int64_t n, int64_t k, bool bias = true) {
+    add_w(e, p + ".w", 0, {n, k});
+    if (bias) add_w(e, p + ".b", 1, {n});
+}
+void add_norm(gl_engine* e, const std::string& p, int64_t c) {
+    add_w(e, p + ".g", 1, {c});
+    add_w(e, p + ".b", 1, {c});
+}
+void add_conv3(gl_engine* e, const std::string& p, int64_t cin, int64_t cout) {
+    add_w(e, p + ".w", 0, {cout, 9 * cin});
+    add_w(e, p + ".b", 1, {cout});
+}
+void add_ff(gl_engine* e, const std::string& p, int64_t C) {
+    add_w(e, p + ".ff1.w", 0, {8 * C, C});
+    add_w(e, p + ".ff1.b", 1, {8 * C});
+    add_lin(e, p + ".ff2", C, 4 * C);
+}
+
+// UNetModel.__init__ (openaimodel.py:290-391) as data; mirrors arch.build_plan
+void build_plan(gl_engine* e) {
+    const gl_unet_config& c = e->cfg;
+    const int mc = c.model_channels, heads = c.num_heads;
+    auto has_attn = [&](int ds) {
+        for (int i = 0; i < c.n_attn_res; ++i) if (c.attention_resolutions[i] == ds) return true;
+        return false;
+    };
+    e->input_blocks.push_back(BlockD{{LayerD{CONV_IN, "input_blocks.0.0", c.in_channels, mc, 0}}});
+    std::vector<int> chans{mc};
+    int ch = mc, ds = 1;
+    for (int level = 0; level < c.n_levels; ++level) {
+        const int mult = c.channel_mult[level];
+        for (int r = 0; r < c.num_res_blocks; ++r) {
+            const int idx = (int)e->input_blocks.size();
+            BlockD b;
+            b.layers.push_back(LayerD{RES, "input_blocks." + std::to_string(idx) + ".0", ch, mult * mc, 0});
+            ch = mult * mc;
+            if (has_attn(ds)) b.layers.push_back(LayerD{ST, "input_blocks." + std::to_string(idx) + ".1", ch, ch, ch / heads});
+            e->input_blocks.push_back(b);
+            chans.push_back(ch);
+        }
+        if (level != c.n_levels - 1) {
+            const int idx = (int)e->input_blocks.size();
+            e->input_blocks.push_back(BlockD{{LayerD{DOWN, "input_blocks." + std::to_string(idx) + ".0.op", ch, ch, 0}}});
+            chans.push_back(ch);
+            ds *= 2;
+        }
+    }
+    e->middle.layers = {LayerD{RES, "middle_block.0", ch, ch, 0}, LayerD{ST, "middle_block.1", ch, ch, ch / heads},
+                        LayerD{RES, "middle_block.2", ch, ch, 0}};
+    for (int level = c.n_levels - 1; level >= 0; --level) {
+        const int mult = c.channel_mult[level];
+        for (int i = 0; i <= c.num_res_blocks; ++i) {
+            const int ich = chans.back();
+            chans.pop_back();
+            const int idx = (int)e->output_blocks.size();
+            BlockD b;
+            b.layers.push_back(LayerD{RES, "output_blocks." + std::to_string(idx) + ".0", ch + ich, mc * mult, 0});
+            ch = mc * mult;
+            if (has_attn(ds)) b.layers.push_back(LayerD{ST, "output_blocks." + std::to_string(idx) + ".1", ch, ch, ch / heads});
+            if (level && i == c.num_res_blocks) {
+                b.layers.push_back(LayerD{UP, "output_blocks." + std::to_string(idx) + "." + std::to_string(b.layers.size()) + ".conv", ch, ch, 0});
+                ds /= 2;
+            }
+            e->output_blocks.push_back(b);
+        }
+    }
+    e->out_channels_last = ch;
+}
+
+template <class F>
+void for_all_layers(gl_engine* e, F f) {
+    for (auto& b : e->input_blocks) for (auto& l : b.layers) f(l);
+    for (auto& l : e->middle.layers) f(l);
+    for (auto& b : e->output_blocks) for (auto& l : b.layers) f(l);
+}
+
+// the packed-weight table, in the order weights.pack_state_dict produces its tensors
+void build_table(gl_engine* e) {
+    const gl_unet_config& c = e->cfg;
+    const int mc = c.model_channels, te = 4 * mc, ctx = c.context_dim;
+    add_lin(e, "time_embed.0", te, mc);
+    add_lin(e, "time_embed.2", te, te);
+    add_conv3(e, "input_blocks.0.0", CIN_PAD, mc);
+    add_conv3(e, "sd_first_conv", CIN_PAD, mc);
+    int off = 0;
+    for_all_layers(e, [&](LayerD& l) {
+        const std::string& p = l.prefix;
+        if (l.kind == DOWN || l.kind == UP) {
+            add_conv3(e, p, l.cin, l.cout);
+        } else if (l.kind == RES) {
+            add_norm(e, p + ".in_layers.0", l.cin);
+            add_conv3(e, p + ".in_layers.2", l.cin, l.cout);
+            add_norm(e, p + ".out_layers.0", l.cout);
+            add_conv3(e, p + ".out_layers.3", l.cout, l.cout);
+            if (l.cin != l.cout) add_lin(e, p + ".skip_connection", l.cout, l.cin);
+            e->emb_off[p] = off;
+            off += l.cout;
+        } else if (l.kind == ST) {
+            const int C = l.cin;
+            e->st_layers.push_back(l);
+            add_norm(e, p + ".norm", C);
+            add_lin(e, p + ".proj_in", C, C);
+            add_lin(e, p + ".proj_out", C, C);
+            const std::string t = p + ".transformer_blocks.0";
+            add_w(e, t + ".attn1.qkv.w", 0, {3 * C, C});
+            add_lin(e, t + ".attn1.o", C, C);
+            add_w(e, t + ".attn2.q.w", 0, {C, C});
+            add_w(e, t + ".attn2.kv.w", 0, {2 * C, ctx});
+            add_lin(e, t + ".attn2.o", C, C);
+            add_ff(e, t + ".ff", C);
+            for (const char* n : {".norm1", ".norm2", ".norm3"}) add_norm(e, t + n, C);
+            const std::string f = t + ".fuser";
+            add_lin(e, f + ".linear", C, ctx);
+            add_w(e, f + ".attn.qkv.w", 0, {3 * C, C});
+            add_lin(e, f + ".attn.o", C, C);
+            add_ff(e, f + ".ff", C);
+            add_norm(e, f + ".norm1", C);
+            add_norm(e, f + ".norm2", C);
+            add_w(e, f + ".tanh_attn", 1, {1});
+            add_w(e, f + ".tanh_dense", 1, {1});
+            const std::string r = t + ".rela_fuse";
+            add_w(e, r + ".attn.q.w", 0, {C, C});
+            add_w(e, r + ".attn.kv.w", 0, {2 * C, ctx});
+            add_lin(e, r + ".attn.o", C, C);
+            add_ff(e, r + ".ff", C);
+            for (const char* n : {".norm1", ".norm2", ".norm3"}) add_norm(e, r + n, C);
+            add_w(e, r + ".tanh_attn", 1, {1});
+            add_w(e, r + ".tanh_dense", 1, {1});
+        }
+    });
+    e->emb_total = off;
+    add_lin(e, "emb_all", off, te);
+    add_norm(e, "out.0", e->out_channels_last);
+    add_conv3(e, "out.2", e->out_channels_last, c.out_channels);
+    add_w(e, "position_net.null_pos", 1, {c.pos_in_dim});
+    add_w(e, "position_net.null_xyxy", 1, {8 * c.fourier_freqs});
+    add_lin(e, "position_net.linears.0", 512, c.pos_in_dim + 8 * c.fourier_freqs);
+    add_lin(e, "position_net.linears.2", 512, 512);
+    add_lin(e, "position_net.linears.4", c.pos_out_dim, 512);
+}
+
+inline int vt_ld(int Nk) {
+    // row stride (keys) of a V^T buffer: Nk rounded up to the 64-key tile, plus one tile when that is a multiple of 512
+    // keys (a 1 KiB-multiple row stride maps the d rows of every V^T tile onto the same L1 sets: 307 vs 277 us at N = 4096)
+    const int n = (Nk + 63) / 64 * 64;
+    return (n % 512 == 0) ? n + 64 : n;
+}
+inline int gn_nchunk(int HW) {
+    if (HW <= 4096) { int c = HW / 4; if (c > 64) c = 64; return c < 1 ? 1 : c; }
+    int c = HW / 512;
+    return c > 512 ? 512 : c;
+}
+
+#define CK(expr)                                     \
+    do {                                             \
+        const int rc__ = (expr);                     \
+        if (rc__ != 0) return rc__;                  \
+    } while (0)
+#define CKP(ptr)                                     \
+    do {                                             \
+        if ((ptr) == nullptr) return GL_ERR_BAD_ARG; \
+    } while (0)
+
+// the launch sequence of one forward / of the conditioning hoists
+struct Run {
+    gl_engine* e;
+    hipStream_t st;
+    void* ws;
+    int launches = 0;
+
+    int gemm(const void* a, int lda, const std::string& w, int M, void* out, int ldc, int out_mode = GL_OUT_F16_ROWMAJOR,
+             const std::string& bias = "", int epi = GL_EPI_BIAS, const void* res = nullptr, int ldres = 0, int res_f32 = 0,
+             const float* gate = nullptr, void* out2 = nullptr, int ldc2 = 0, const void* a2 = nullptr, int lda2 = 0, int ksplit = 0) {
+        const WInfo* wi = e->wi(w);
+        if (!wi) return GL_ERR_BAD_ARG;
+        gl_gemm_args g{};
+        g.a = a; g.lda = lda; g.a2 = a2; g.lda2 = lda2; g.ksplit = ksplit;
+        g.w = e->W(w);
+        g.bias = bias.empty() ? nullptr : e->Wf(bias);
+        g.M = M; g.N = (int)wi->shape[0]; g.K = (int)wi->shape[1];
+        g.epi = epi; g.out_mode = out_mode; g.out = out; g.ldc = ldc;
+        g.res = res; g.ldres = ldres; g.res_f32 = res_f32; g.gate = gate;
+        g.out2 = out2; g.ldc2 = ldc2;
+        g.workspace = ws; g.workspace_bytes = WS_BYTES;
+        ++launches;
+        return gl_gemm(&g, st);
+    }
+    int conv(const void* in, const std::string& w, const std::string& bias, int B, int Hin, int Win, int Cin, int stride, int ups,
+             void* out, int out_mode, int epi = GL_EPI_BIAS, const void* res = nullptr, int ldres = 0, int res_f32 = 0,
+             const void* rowbias = nullptr, int ld_rowbias = 0, int rows_per_sample = 0, void* out2 = nullptr, int nchw_hw = 0) {
+        const WInfo* wi = e->wi(w);
+        if (!wi) return GL_ERR_BAD_ARG;
+        gl_conv_args a{};
+        a.in = in; a.B = B; a.Hin = Hin; a.Win = Win; a.Cin = Cin;
+        a.Hout = ups ? 2 * Hin : (Hin + 2 - 3) / stride + 1;
+        a.Wout = ups ? 2 * Win : (Win + 2 - 3) / stride + 1;
+        a.stride = stride; a.upsample2x = ups;
+        a.g.w = e->W(w); a.g.bias = e->Wf(bias); a.g.N = (int)wi->shape[0];
+        a.g.epi = epi; a.g.out_mode = out_mode; a.g.out = out; a.g.ldc = a.g.N; a.g.hw = nchw_hw;
+        a.g.res = res; a.g.ldres = ldres; a.g.res_f32 = res_f32;
+        a.g.rowbias = rowbias; a.g.ld_rowbias = ld_rowbias; a.g.rows_per_sample = rows_per_sample;
+        a.g.out2 = out2; a.g.ldc2 = a.g.N;
+        a.g.workspace = ws; a.g.workspace_bytes = WS_BYTES;
+        ++launches;
+        return gl_conv3x3(&a, st);
+    }
+    int ln(const void* x, int ldx, int x_f32, half_t* y, int ldy, const std::string& p, int B, int rows_in, int rows_out, int row_off,
+           int C, float* stats = nullptr) {
+        ++launches;
+        return gl_layernorm(x, ldx, x_f32, y, ldy, e->Wf(p + ".g"), e->Wf(p + ".b"), B, rows_in, rows_out, row_off, C, 1e-5f, stats, st);
+    }
+    int gn(const half_t* x1, int C1, const half_t* x2, int C2, int B, int HW, const std::string& p, float eps, int silu, half_t* out) {
+        const int nchunk = gn_nchunk(HW);
+        float* partial = e->f32("gn.partial", (size_t)B * nchunk * 64);
+        CKP(partial);
+        launches += 2;
+        CK(gl_groupnorm_stats(x1, C1, x2, C2, B, HW, partial, nchunk, st));
+        return gl_groupnorm_apply(x1, C1, x2, C2, B, HW, partial, nchunk, e->Wf(p + ".g"), e->Wf(p + ".b"), eps, silu, out, st);
+    }
+    int attn(const half_t* q, int64_t qb, int ldq, const half_t* k, int64_t kb, int ldk, const half_t* vt, int ldvt, half_t* out,
+             int64_t ob, int ldo, int B, int H, int d, int Nq, int Nk) {
+        gl_attn_args a{};
+        a.q = q; a.q_bstride = qb; a.ldq = ldq; a.k = k; a.k_bstride = kb; a.ldk = ldk; a.vt = vt; a.ldvt = ldvt;
+        a.out = out; a.o_bstride = ob; a.ldo = ldo; a.B = B; a.H = H; a.d = d; a.Nq = Nq; a.Nk = Nk;
+        a.scale = 1.0f / sqrtf((float)d);
+        ++launches;
+        return gl_attention(&a, st);
+    }
+    int transpose_v(const half_t* v, int64_t vb, int ldv, half_t* vt, int ldvt, int B, int H, int d, int Nk) {
+        ++launches;
+        return gl_transpose_v(v, vb, ldv, vt, ldvt, B, H, d, Nk, st);
+    }
+};
+
+struct Stream2 {            // a residual-stream tensor: fp32 master + fp16 copy for matrix-core consumers
+    float* f = nullptr;
+    half_t* h = nullptr;
+};
+
+int set_fuser_scale(gl_engine* e, float scale, hipStream_t st) {
+    if (e->fuser_scale_cur == scale) return 0;
+    const size_t n = e->st_layers.size();
+    float* gates = e->f32("gates", n * 4);
+    CKP(gates);
+    e->gate_host.resize(n * 4);
+    for (size_t i = 0; i < n; ++i) {
+        e->gate_host[i * 4 + 0] = scale * e->gate_tanh[i * 4 + 0];
+        e->gate_host[i * 4 + 1] = scale * e->gate_tanh[i * 4 + 1];
+        e->gate_host[i * 4 + 2] = e->gate_tanh[i * 4 + 2];
+        e->gate_host[i * 4 + 3] = e->gate_tanh[i * 4 + 3];
+    }
+    // pageable-source async copies are staged before the call returns, so gate_host may change afterwards
+    if (hipMemcpyAsync(gates, e->gate_host.data(), n * 4 * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess) return GL_ERR_BAD_ARG;
+    e->fuser_scale_cur = scale;
+    return 0;
+}
+
+// self-attention over src [Bn * rows_per_b, C] (already normalised): QKV GEMM -> V^T -> flash attention
+int self_attention(Run& r, const half_t* src, int rows_per_b, int Nq, int Nk, int C, int d, const std::string& wp, const std::string& tag,
+                   half_t** out) {
+    gl_engine* e = r.e;
+    const int Bn = e->Bn, H = e->cfg.num_heads;
+    half_t* qkv = e->h16(tag + ".qkv", (size_t)Bn * rows_per_b * 3 * C);
+    const int ldvt = vt_ld(Nk);
+    half_t* vt = e->h16(tag + ".vt", (size_t)Bn * H * d * ldvt);
+    half_t* att = e->h16(tag + ".att", (size_t)Bn * Nq * C);
+    CKP(qkv); CKP(vt); CKP(att);
+    CK(r.gemm(src, C, wp + ".qkv.w", Bn * rows_per_b, qkv, 3 * C));
+    CK(r.transpose_v(qkv + 2 * C, (int64_t)rows_per_b * 3 * C, 3 * C, vt, ldvt, Bn, H, d, Nk));
+    CK(r.attn(qkv, (int64_t)rows_per_b * 3 * C, 3 * C, qkv + C, (int64_t)rows_per_b * 3 * C, 3 * C, vt, ldvt, att, (int64_t)Nq * C, C, Bn, H, d,
+              Nq, Nk));
+    *out = att;
+    return 0;
+}
+
+int feed_forward(Run& r, const half_t* xn, const float* res, const std::string& p, int M, int C, void* out, int out_mode, const float* gate) {
+    half_t* hg = r.e->h16("ff.h", (size_t)M * 4 * C);
+    CKP(hg);
+    CK(r.gemm(xn, C, p + ".ff1.w", M, hg, 4 * C, GL_OUT_F16_ROWMAJOR, p + ".ff1.b", GL_EPI_GEGLU));
+    return r.gemm(hg, 4 * C, p + ".ff2.w", M, out, C, out_mode, p + ".ff2.b", gate ? GL_EPI_GATE_RES : GL_EPI_RES, res, C, 1, gate);
+}
+
+// ResBlock._forward (openaimodel.py:211-231); skip = the popped skip-stack tensor of an output block (th.cat folded in)
+int res_block(Run& r, const LayerD& l, Stream2 h, const Stream2* skip, int skip_c, int side, const half_t* emb_out, const std::string& tag,
+              Stream2* out) {
+    gl_engine* e = r.e;
+    const int Bn = e->Bn, HW = side * side, M = Bn * HW;
+    const std::string& p = l.prefix;
+    const int c1 = l.cin - skip_c;
+    half_t* t = e->h16("rb.gn1", (size_t)M * l.cin);
+    half_t* h1 = e->h16("rb.h1", (size_t)M * l.cout);
+    half_t* t2 = e->h16("rb.gn2", (size_t)M * l.cout);
+    CKP(t); CKP(h1); CKP(t2);
+    CK(r.gn(h.h, c1, skip ? skip->h : nullptr, skip_c, Bn, HW, p + ".in_layers.0", 1e-5f, 1, t));
+    const int off = e->emb_off[p];
+    CK(r.conv(t, p + ".in_layers.2.w", p + ".in_layers.2.b", Bn, side, side, l.cin, 1, 0, h1, GL_OUT_F16_ROWMAJOR, GL_EPI_ROWBIAS, nullptr, 0, 0,
+              emb_out + off, e->emb_total, HW));
+    CK(r.gn(h1, l.cout, nullptr, 0, Bn, HW, p + ".out_layers.0", 1e-5f, 1, t2));
+    const float* sk = h.f;
+    if (l.cin != l.cout) {
+        float* skb = e->f32("rb.skip.f32", (size_t)M * l.cout);
+        CKP(skb);
+        CK(r.gemm(h.h, c1, p + ".skip_connection.w", M, skb, l.cout, GL_OUT_F32_ROWMAJOR, p + ".skip_connection.b", GL_EPI_BIAS, nullptr, 0, 0, nullptr,
+                  nullptr, 0, skip ? skip->h : nullptr, skip_c, skip ? c1 : 0));
+        sk = skb;
+    } else if (skip) {
+        return GL_ERR_BAD_ARG;
+    }
+    out->f = e->f32(tag + ".f32", (size_t)M * l.cout);
+    out->h = e->h16(tag, (size_t)M * l.cout);
+    CKP(out->f); CKP(out->h);
+    return r.conv(t2, p + ".out_layers.3.w", p + ".out_layers.3.b", Bn, side, side, l.cout, 1, 0, out->f, GL_OUT_F32_ROWMAJOR, GL_EPI_RES, sk, l.cout, 1,
+                  nullptr, 0, 0, out->h);
+}
+
+// SpatialTransformer.forward + BasicTransformerBlock._forward (attention.py:436-446, :394-402)
+int spatial_transformer(Run& r, const LayerD& l, int li, Stream2 xin, int side, bool fuser_on, const std::string& tag, Stream2* out) {
+    gl_engine* e = r.e;
+    const gl_unet_config& cfg = e->cfg;
+    const std::string& p = l.prefix;
+    const std::string t = p + ".transformer_blocks.0";
+    const int C = l.cin, d = l.d_head, H = cfg.num_heads;
+    const int Bn = e->Bn, N = side * side, M = Bn * N, mo = cfg.max_objs, R = e->R, Lc = e->Lc;
+    const std::string sl = std::to_string(li);
+    float* xa = e->f32("st.xa", (size_t)M * C);
+    float* xb = e->f32("st.xb", (size_t)M * C);
+    half_t* g0 = e->h16("st.gn", (size_t)M * C);
+    half_t* lnb = e->h16("st.ln", (size_t)M * C);
+    CKP(xa); CKP(xb); CKP(g0); CKP(lnb);
+    const float* gates = e->f32("gates", e->st_layers.size() * 4) + (size_t)li * 4;
+    CK(r.gn(xin.h, C, nullptr, 0, Bn, N, p + ".norm", 1e-6f, 0, g0));
+    float* x = xa;
+    auto nxt = [&](float* cur) { return cur == xa ? xb : xa; };
+    CK(r.gemm(g0, C, p + ".proj_in.w", M, x, C, GL_OUT_F32_ROWMAJOR, p + ".proj_in.b"));
+    // --- attn1 (attention.py:395)
+    half_t* att = nullptr;
+    CK(r.ln(x, C, 1, lnb, C, t + ".norm1", Bn, N, N, 0, C));
+    CK(self_attention(r, lnb, N, N, N, C, d, t + ".attn1", "st.sa", &att));
+    {
+        float* y = nxt(x);
+        CK(r.gemm(att, C, t + ".attn1.o.w", M, y, C, GL_OUT_F32_ROWMAJOR, t + ".attn1.o.b", GL_EPI_RES, x, C, 1));
+        x = y;
+    }
+    // --- gated self-attention fuser over [x ; objs] (attention.py:226-234); exact identity at scale 0
+    if (fuser_on) {
+        const std::string f = t + ".fuser";
+        half_t* cat = e->h16("st.cat", (size_t)Bn * (N + mo) * C);
+        CKP(cat);
+        CK(r.ln(x, C, 1, cat, C, f + ".norm1", Bn, N, N + mo, 0, C));
+        CK(r.ln(e->h16("hoist.objs." + sl, (size_t)Bn * mo * C), C, 0, cat, C, f + ".norm1", Bn, mo, N + mo, N, C));
+        CK(self_attention(r, cat, N + mo, N, N + mo, C, d, f + ".attn", "st.fa", &att));
+        float* y = nxt(x);
+        CK(r.gemm(att, C, f + ".attn.o.w", M, y, C, GL_OUT_F32_ROWMAJOR, f + ".attn.o.b", GL_EPI_GATE_RES, x, C, 1, gates + 0));
+        x = y;
+        CK(r.ln(x, C, 1, lnb, C, f + ".norm2", Bn, N, N, 0, C));
+        y = nxt(x);
+        CK(feed_forward(r, lnb, x, f + ".ff", M, C, y, GL_OUT_F32_ROWMAJOR, gates + 1));
+        x = y;
+    }
+    // --- relation injection (attention.py:315-359, :398), closed form
+    {
+        const std::string rf = t + ".rela_fuse";
+        const std::string ss = std::to_string(side);
+        const int* rects = reinterpret_cast<const int*>(e->buf("cond.rects." + ss, (size_t)Bn * mo * 16));
+        const int* nvalid = reinterpret_cast<const int*>(e->buf("cond.nvalid." + ss, (size_t)Bn * 4));
+        const int* poison = reinterpret_cast<const int*>(e->buf("cond.poison." + ss, (size_t)Bn * 4));
+        const int Mo = Bn * mo;
+        float* stats = e->f32("st.lnstats", (size_t)M * 2);
+        half_t* hid = e->h16("st.hid", (size_t)M * C);
+        half_t* feat = e->h16("rl.feat", (size_t)Mo * C);
+        half_t* fn = e->h16("rl.ln", (size_t)Mo * C);
+        half_t* q = e->h16("rl.q", (size_t)Mo * C);
+        half_t* ar = e->h16("rl.att", (size_t)Mo * C);
+        half_t* f1 = e->h16("rl.f1", (size_t)Mo * C);
+        half_t* hg = e->h16("rl.ffh", (size_t)Mo * 4 * C);
+        half_t* f2 = e->h16("rl.f2", (size_t)Mo * C);
+        CKP(rects); CKP(nvalid); CKP(poison); CKP(stats); CKP(hid); CKP(feat); CKP(fn); CKP(q); CKP(ar); CKP(f1); CKP(hg); CKP(f2);
+        CK(r.ln(x, C, 1, hid, C, rf + ".norm3", Bn, N, N, 0, C, stats));
+        ++r.launches;
+        CK(gl_rela_pool(hid, Bn, side, side, C, rects, nvalid, poison, mo, feat, r.st));
+        CK(r.ln(feat, C, 0, fn, C, rf + ".norm1", Bn, mo, mo, 0, C));
+        CK(r.gemm(fn, C, rf + ".attn.q.w", Mo, q, C));
+        const half_t* kv = e->h16("hoist.kvrel." + sl, (size_t)Bn * R * 2 * C);
+        const int ldvt = vt_ld(R);
+        const half_t* vtr = e->h16("hoist.vtrel." + sl, (size_t)Bn * H * d * ldvt);
+        CKP(kv); CKP(vtr);
+        CK(r.attn(q, (int64_t)mo * C, C, kv, (int64_t)R * 2 * C, 2 * C, vtr, ldvt, ar, (int64_t)mo * C, C, Bn, H, d, mo, R));
+        CK(r.gemm(ar, C, rf + ".attn.o.w", Mo, f1, C, GL_OUT_F16_ROWMAJOR, rf + ".attn.o.b", GL_EPI_GATE_RES, feat, C, 0, gates + 2));
+        CK(r.ln(f1, C, 0, fn, C, rf + ".norm2", Bn, mo, mo, 0, C));
+        CK(r.gemm(fn, C, rf + ".ff.ff1.w", Mo, hg, 4 * C, GL_OUT_F16_ROWMAJOR, rf + ".ff.ff1.b", GL_EPI_GEGLU));
+        CK(r.gemm(hg, 4 * C, rf + ".ff.ff2.w", Mo, f2, C, GL_OUT_F16_ROWMAJOR, rf + ".ff.ff2.b", GL_EPI_GATE_RES, f1, C, 0, gates + 3));
+        float* y = nxt(x);
+        ++r.launches;
+        CK(gl_rela_merge(x, 1, nullptr, stats, e->Wf(rf + ".norm3.g"), e->Wf(rf + ".norm3.b"), f2, Bn, side, side, C, rects, nvalid, poison, mo, y,
+                         r.st));
+        x = y;
+    }
+    // --- attn2: text cross-attention with hoisted K/V (attention.py:400)
+    {
+        half_t* q2 = e->h16("st.q2", (size_t)M * C);
+        half_t* a2 = e->h16("st.att2", (size_t)M * C);
+        const half_t* kv = e->h16("hoist.kvctx." + sl, (size_t)Bn * Lc * 2 * C);
+        const int ldvt = vt_ld(Lc);
+        const half_t* vtc = e->h16("hoist.vtctx." + sl, (size_t)Bn * H * d * ldvt);
+        CKP(q2); CKP(a2); CKP(kv); CKP(vtc);
+        CK(r.ln(x, C, 1, lnb, C, t + ".norm2", Bn, N, N, 0, C));
+        CK(r.gemm(lnb, C, t + ".attn2.q.w", M, q2, C));
+        CK(r.attn(q2, (int64_t)N * C, C, kv, (int64_t)Lc * 2 * C, 2 * C, vtc, ldvt, a2, (int64_t)N * C, C, Bn, H, d, N, Lc));
+        float* y = nxt(x);
+        CK(r.gemm(a2, C, t + ".attn2.o.w", M, y, C, GL_OUT_F32_ROWMAJOR, t + ".attn2.o.b", GL_EPI_RES, x, C, 1));
+        x = y;
+    }
+    // --- GEGLU feed-forward (attention.py:401): the sum is only consumed by proj_out's matrix product -> fp16
+    half_t* x16 = e->h16("st.x6", (size_t)M * C);
+    CKP(x16);
+    CK(r.ln(x, C, 1, lnb, C, t + ".norm3", Bn, N, N, 0, C));
+    CK(feed_forward(r, lnb, x, t + ".ff", M, C, x16, GL_OUT_F16_ROWMAJOR, nullptr));
+    // --- proj_out + residual (attention.py:444-446)
+    out->f = e->f32(tag + ".f32", (size_t)M * C);
+    out->h = e->h16(tag, (size_t)M * C);
+    CKP(out->f); CKP(out->h);
+    return r.gemm(x16, C, p + ".proj_out.w", M, out->f, C, GL_OUT_F32_ROWMAJOR, p + ".proj_out.b", GL_EPI_RES, xin.f, C, 1, nullptr, out->h, C);
+}
+
+int launch_forward(gl_engine* e, int reps, bool fuser_on, bool sd_conv, hipStream_t st, int* n_launches) {
+    const gl_unet_config& cfg = e->cfg;
+    const int Bn = e->Bn, mc = cfg.model_channels;
+    int side = e->hw;
+    Run r{e, st, e->buf("splitk.ws", WS_BYTES)};
+    CKP(r.ws);
+    const float* x_lat = e->f32("in.xlat", (size_t)(Bn / reps) * cfg.in_channels * side * side);
+    const float* t_buf = e->f32("in.t", Bn);
+    float* eps = e->f32("out.eps", (size_t)Bn * cfg.out_channels * side * side);
+    CKP(x_lat); CKP(t_buf); CKP(eps);
+    // time embedding (openaimodel.py:428-429) and all emb_layers in one GEMM (:172-178, :220)
+    half_t* te = e->h16("te.sin", (size_t)Bn * mc);
+    half_t* e1 = e->h16("te.e1", (size_t)Bn * 4 * mc);
+    half_t* e2 = e->h16("te.e2", (size_t)Bn * 4 * mc);
+    half_t* emb_out = e->h16("te.out", (size_t)Bn * e->emb_total);
+    CKP(te); CKP(e1); CKP(e2); CKP(emb_out);
+    ++r.launches;
+    CK(gl_timestep_embedding(t_buf, Bn, mc, te, st));
+    CK(r.gemm(te, mc, "time_embed.0.w", Bn, e1, 4 * mc, GL_OUT_F16_ROWMAJOR, "time_embed.0.b", GL_EPI_SILU));
+    CK(r.gemm(e1, 4 * mc, "time_embed.2.w", Bn, e2, 4 * mc, GL_OUT_F16_ROWMAJOR, "time_embed.2.b", GL_EPI_SILU));
+    CK(r.gemm(e2, 4 * mc, "emb_all.w", Bn, emb_out, e->emb_total, GL_OUT_F16_ROWMAJOR, "emb_all.b"));
+    // first conv on the zero-padded NHWC latent (openaimodel.py:299, :393-405)
+    half_t* xin = e->h16("in.x", (size_t)Bn * side * side * CIN_PAD);
+    CKP(xin);
+    ++r.launches;
+    CK(gl_pack_latent(x_lat, Bn / reps, cfg.in_channels, side * side, CIN_PAD, reps, xin, st));
+    const std::string fc = sd_conv ? "sd_first_conv" : "input_blocks.0.0";
+    Stream2 h;
+    h.f = e->f32("skip.0.f32", (size_t)Bn * side * side * mc);
+    h.h = e->h16("skip.0", (size_t)Bn * side * side * mc);
+    CKP(h.f); CKP(h.h);
+    CK(r.conv(xin, fc + ".w", fc + ".b", Bn, side, side, CIN_PAD, 1, 0, h.f, GL_OUT_F32_ROWMAJOR, GL_EPI_BIAS, nullptr, 0, 0, nullptr, 0, 0, h.h));
+    struct Skip { Stream2 s; int side, c; };
+    std::vector<Skip> skips{{h, side, mc}};
+    int st_idx = 0;
+    int h_c = mc;
+
+    auto run_block = [&](const BlockD& b, const std::string& bi, const Skip* skip) -> int {
+        const Stream2* sk = skip ? &skip->s : nullptr;
+        int sk_c = skip ? skip->c : 0;
+        for (size_t j = 0; j < b.layers.size(); ++j) {
+            const LayerD& l = b.layers[j];
+            const std::string tag = bi + "." + std::to_string(j);
+            Stream2 o;
+            if (l.kind == RES) {
+                CK(res_block(r, l, h, sk, sk_c, side, emb_out, tag, &o));
+                sk = nullptr; sk_c = 0;
+            } else if (l.kind == ST) {
+                CK(spatial_transformer(r, l, st_idx++, h, side, fuser_on, tag, &o));
+            } else if (l.kind == DOWN) {
+                const int so = side / 2;
+                o.f = e->f32(tag + ".f32", (size_t)Bn * so * so * l.cout);
+                o.h = e->h16(tag, (size_t)Bn * so * so * l.cout);
+                CKP(o.f); CKP(o.h);
+                CK(r.conv(h.h, l.prefix + ".w", l.prefix + ".b", Bn, side, side, l.cin, 2, 0, o.f, GL_OUT_F32_ROWMAJOR, GL_EPI_BIAS, nullptr, 0, 0, nullptr,
+                          0, 0, o.h));
+                side = so;
+            } else if (l.kind == UP) {
+                const int so = side * 2;
+                o.f = e->f32(tag + ".f32", (size_t)Bn * so * so * l.cout);
+                o.h = e->h16(tag, (size_t)Bn * so * so * l.cout);
+                CKP(o.f); CKP(o.h);
+                CK(r.conv(h.h, l.prefix + ".w", l.prefix + ".b", Bn, side, side, l.cin, 1, 1, o.f, GL_OUT_F32_ROWMAJOR, GL_EPI_BIAS, nullptr, 0, 0, nullptr,
+                          0, 0, o.h));
+                side = so;
+            } else {
+                return GL_ERR_BAD_ARG;
+            }
+            h = o;
+            h_c = l.cout;
+        }
+        return 0;
+    };
+
+    for (size_t i = 1; i < e->input_blocks.size(); ++i) {
+        CK(run_block(e->input_blocks[i], "skip." + std::to_string(i), nullptr));
+        skips.push_back({h, side, h_c});
+    }
+    CK(run_block(e->middle, "mid", nullptr));
+    for (size_t i = 0; i < e->output_blocks.size(); ++i) {
+        const Skip sk = skips.back();
+        skips.pop_back();
+        if (sk.side != side) return GL_ERR_BAD_ARG;
+        CK(run_block(e->output_blocks[i], "out." + std::to_string(i), &sk));
+    }
+    half_t* g = e->h16("fin.gn", (size_t)Bn * side * side * e->out_channels_last);
+    CKP(g);
+    CK(r.gn(h.h, e->out_channels_last, nullptr, 0, Bn, side * side, "out.0", 1e-5f, 1, g));
+    CK(r.conv(g, "out.2.w", "out.2.b", Bn, side, side, e->out_channels_last, 1, 0, eps, GL_OUT_F32_NCHW, GL_EPI_BIAS, nullptr, 0, 0, nullptr, 0, 0, nullptr,
+              side * side));
+    if (n_launches) *n_launches = r.launches;
+    return 0;
+}
+
+}  // namespace
+
+// ====================================================================================== C ABI
+extern "C" int gl_create(const gl_unet_config* cfg, gl_engine** out) {
+    if (!cfg || !out) return GL_ERR_BAD_ARG;
+    if (cfg->n_levels <= 0 || cfg->n_levels > 8 || cfg->n_attn_res < 0 || cfg->n_attn_res > 8 || cfg->num_heads <= 0) return GL_ERR_BAD_ARG;
+    if (cfg->model_channels % 64 || cfg->context_dim % 64 || cfg->pos_in_dim % 8 || cfg->pos_out_dim != cfg->context_dim) return GL_ERR_UNSUPPORTED;
+    if ((cfg->pos_in_dim + 8 * cfg->fourier_freqs) % 64) return GL_ERR_UNSUPPORTED;
+    if (cfg->in_channels > CIN_PAD || cfg->max_objs <= 0 || cfg->max_objs > 64) return GL_ERR_UNSUPPORTED;
+    gl_engine* e = new gl_engine();
+    e->cfg = *cfg;
+    build_plan(e);
+    build_table(e);
+    *out = e;
+    return 0;
+}
+
+extern "C" int gl_destroy(gl_engine* e) {
+    if (!e) return GL_ERR_BAD_ARG;
+    e->drop_graphs();
+    for (auto& kv : e->pool) (void)hipFree(kv.second.p);
+    if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
+    delete e;
+    return 0;
+}
+
+extern "C" int gl_num_weights(const gl_engine* e) { return e ? (int)e->names.size() : GL_ERR_BAD_ARG; }
+extern "C" int64_t gl_weights_bytes(const gl_engine* e) { return e ? e->total_bytes : -1; }
+extern "C" int gl_weight_at(const gl_engine* e, int32_t i, gl_weight_info* info) {
+    if (!e || !info || i < 0 || i >= (int)e->names.size()) return GL_ERR_BAD_ARG;
+    const std::string& n = e->names[i];
+    if (n.size() >= sizeof(info->name)) return GL_ERR_BAD_ARG;
+    const WInfo& w = e->tab.at(n);
+    memset(info, 0, sizeof(*info));
+    memcpy(info->name, n.c_str(), n.size());
+    info->offset = w.off; info->nbytes = w.bytes; info->dtype = w.dtype; info->ndim = w.ndim;
+    for (int k = 0; k < 4; ++k) info->shape[k] = w.shape[k];
+    return 0;
+}
+
+extern "C" int gl_load_weights(gl_engine* e, const void* packed, int64_t bytes, int32_t has_sd_conv, void* stream) {
+    if (!e || !packed || bytes < e->total_bytes) return GL_ERR_BAD_ARG;
+    if (reinterpret_cast<uintptr_t>(packed) % 16) return GL_ERR_BAD_ARG;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return GL_ERR_BAD_ARG;
+    e->device = dev;
+    CK(gl_init());
+    e->wbase = reinterpret_cast<const char*>(packed);
+    e->has_sd = has_sd_conv != 0;
+    e->drop_graphs();
+    // the scalar gates tanh(alpha) live in the packed buffer; fetch them once (tiny, synchronous)
+    const size_t n = e->st_layers.size();
+    e->gate_tanh.assign(n * 4, 0.0f);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipStreamSynchronize(st) != hipSuccess) return GL_ERR_BAD_ARG;
+    for (size_t i = 0; i < n; ++i) {
+        const std::string t = e->st_layers[i].prefix + ".transformer_blocks.0";
+        const char* names[4] = {".fuser.tanh_attn", ".fuser.tanh_dense", ".rela_fuse.tanh_attn", ".rela_fuse.tanh_dense"};
+        for (int k = 0; k < 4; ++k)
+            if (hipMemcpy(&e->gate_tanh[i * 4 + k], e->W(t + names[k]), sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return GL_ERR_BAD_ARG;
+    }
+    e->fuser_scale_cur = -1e30f;
+    return 0;
+}
+
+extern "C" int gl_set_conditioning(gl_engine* e, const float* context, const float* relations, const float* boxes, const float* masks,
+                                   const float* pos_emb, int32_t Bn, int32_t Lc, int32_t R, int32_t hw, void* stream) {
+    if (!e || !e->wbase || !context || !relations || !boxes || !masks || !pos_emb || Bn <= 0 || Lc <= 0 || R <= 0 || hw <= 0) return GL_ERR_BAD_ARG;
+    const gl_unet_config& cfg = e->cfg;
+    hipStream_t st = (hipStream_t)stream;
+    const int mo = cfg.max_objs, ctx = cfg.context_dim, H = cfg.num_heads;
+    if (Bn != e->Bn || Lc != e->Lc || R != e->R || hw != e->hw) e->drop_graphs();     // shapes are part of the graph keys anyway
+    e->pool_changed = false;
+    e->Bn = Bn; e->Lc = Lc; e->R = R; e->hw = hw;
+    Run r{e, st, e->buf("splitk.ws", WS_BYTES)};
+    CKP(r.ws);
+    // --- grounding tokens: PositionNet (text_grounding_net.py:26-43)
+    const int pin_dim = cfg.pos_in_dim + 8 * cfg.fourier_freqs;
+    half_t* pin = e->h16("pn.in", (size_t)Bn * mo * pin_dim);
+    half_t* h1 = e->h16("pn.h1", (size_t)Bn * mo * 512);
+    half_t* h2 = e->h16("pn.h2", (size_t)Bn * mo * 512);
+    half_t* objs = e->h16("pn.objs", (size_t)Bn * mo * cfg.pos_out_dim);
+    half_t* ctx16 = e->h16("cond.ctx", (size_t)Bn * Lc * ctx);
+    half_t* rel16 = e->h16("cond.rel", (size_t)Bn * R * ctx);
+    CKP(pin); CKP(h1); CKP(h2); CKP(objs); CKP(ctx16); CKP(rel16);
+    CK(gl_posnet_input(boxes, masks, pos_emb, e->Wf("position_net.null_pos"), e->Wf("position_net.null_xyxy"), Bn * mo, cfg.pos_in_dim,
+                       cfg.fourier_freqs, pin, st));
+    CK(r.gemm(pin, pin_dim, "position_net.linears.0.w", Bn * mo, h1, 512, GL_OUT_F16_ROWMAJOR, "position_net.linears.0.b", GL_EPI_SILU));
+    CK(r.gemm(h1, 512, "position_net.linears.2.w", Bn * mo, h2, 512, GL_OUT_F16_ROWMAJOR, "position_net.linears.2.b", GL_EPI_SILU));
+    CK(r.gemm(h2, 512, "position_net.linears.4.w", Bn * mo, objs, cfg.pos_out_dim, GL_OUT_F16_ROWMAJOR, "position_net.linears.4.b"));
+    f32_to_f16_kernel<<<dim3(256), dim3(256), 0, st>>>(context, ctx16, (size_t)Bn * Lc * ctx);
+    f32_to_f16_kernel<<<dim3(64), dim3(256), 0, st>>>(relations, rel16, (size_t)Bn * R * ctx);
+    GL_CHECK_LAUNCH();
+    for (size_t li = 0; li < e->st_layers.size(); ++li) {
+        const LayerD& l = e->st_layers[li];
+        const std::string t = l.prefix + ".transformer_blocks.0";
+        const std::string sl = std::to_string(li);
+        const int C = l.cin, d = l.d_head;
+        // fuser.linear(objs) (attention.py:228)
+        half_t* o = e->h16("hoist.objs." + sl, (size_t)Bn * mo * C);
+        CKP(o);
+        CK(r.gemm(objs, cfg.pos_out_dim, t + ".fuser.linear.w", Bn * mo, o, C, GL_OUT_F16_ROWMAJOR, t + ".fuser.linear.b"));
+        // attn2 K/V of the text context (attention.py:124-125)
+        half_t* kv = e->h16("hoist.kvctx." + sl, (size_t)Bn * Lc * 2 * C);
+        const int ldc_ = vt_ld(Lc);
+        half_t* vt = e->h16("hoist.vtctx." + sl, (size_t)Bn * H * d * ldc_);
+        CKP(kv); CKP(vt);
+        CK(r.gemm(ctx16, ctx, t + ".attn2.kv.w", Bn * Lc, kv, 2 * C));
+        CK(r.transpose_v(kv + C, (int64_t)Lc * 2 * C, 2 * C, vt, ldc_, Bn, H, d, Lc));
+        // rela_fuse K/V of the relation tokens (attention.py:348-349)
+        half_t* kvr = e->h16("hoist.kvrel." + sl, (size_t)Bn * R * 2 * C);
+        const int ldr_ = vt_ld(R);
+        half_t* vtr = e->h16("hoist.vtrel." + sl, (size_t)Bn * H * d * ldr_);
+        CKP(kvr); CKP(vtr);
+        CK(r.gemm(rel16, ctx, t + ".rela_fuse.attn.kv.w", Bn * R, kvr, 2 * C));
+        CK(r.transpose_v(kvr + C, (int64_t)R * 2 * C, 2 * C, vtr, ldr_, Bn, H, d, R));
+    }
+    // --- integer rectangles per transformer resolution (attention.py:321-346)
+    {
+        std::vector<int> sides;
+        int cur = hw;
+        auto note = [&](int s) { for (int v : sides) if (v == s) return; sides.push_back(s); };
+        for (auto& b : e->input_blocks)
+            for (auto& l : b.layers) {
+                if (l.kind == DOWN) cur /= 2;
+                else if (l.kind == ST) note(cur);
+            }
+        note(cur);
+        for (int s : sides) {
+            const std::string ss = std::to_string(s);
+            int* rects = reinterpret_cast<int*>(e->buf("cond.rects." + ss, (size_t)Bn * mo * 16));
+            int* nvalid = reinterpret_cast<int*>(e->buf("cond.nvalid." + ss, (size_t)Bn * 4));
+            int* poison = reinterpret_cast<int*>(e->buf("cond.poison." + ss, (size_t)Bn * 4));
+            CKP(rects); CKP(nvalid); CKP(poison);
+            rela_rects_kernel<<<dim3((Bn + 63) / 64), dim3(64), 0, st>>>(boxes, masks, Bn, mo, s, s, rects, nvalid, poison);
+            GL_CHECK_LAUNCH();
+        }
+    }
+    if (e->pool_changed) e->drop_graphs();
+    e->cond_set = true;
+    return 0;
+}
+
+extern "C" int gl_unet_forward(gl_engine* e, const float* x, const float* t_dev, float t_host, int32_t reps, float fuser_scale, int32_t sd_conv,
+                               float* eps, int32_t use_graph, void* stream) {
+    if (!e || !e->cond_set || !x || !eps || reps < 1 || (e->Bn % reps) != 0) return GL_ERR_BAD_ARG;
+    if (sd_conv && !e->has_sd) return GL_ERR_BAD_ARG;
+    const gl_unet_config& cfg = e->cfg;
+    hipStream_t st = (hipStream_t)stream;
+    const int Bn = e->Bn, side = e->hw;
+    const size_t nx = (size_t)(Bn / reps) * cfg.in_channels * side * side;
+    const size_t ne = (size_t)Bn * cfg.out_channels * side * side;
+    e->pool_changed = false;
+    float* x_lat = e->f32("in.xlat", nx);
+    float* t_buf = e->f32("in.t", Bn);
+    float* eps_i = e->f32("out.eps", ne);
+    CKP(x_lat); CKP(t_buf); CKP(eps_i);
+    if (x != x_lat && hipMemcpyAsync(x_lat, x, nx * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return GL_ERR_BAD_ARG;
+    if (t_dev) {
+        if (hipMemcpyAsync(t_buf, t_dev, (size_t)Bn * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return GL_ERR_BAD_ARG;
+    } else {
+        fill_f32_kernel<<<dim3((Bn + 255) / 256), dim3(256), 0, st>>>(t_buf, t_host, Bn);
+        GL_CHECK_LAUNCH();
+    }
+    CK(set_fuser_scale(e, fuser_scale, st));
+    const bool fuser_on = fuser_scale != 0.0f || g_force_fuser != 0;
+    const auto key = std::make_tuple(Bn, side, e->R, e->Lc, (int)fuser_on, (int)(sd_conv != 0), (int)reps);
+    auto it = e->graphs.find(key);
+    if (use_graph && it == e->graphs.end()) {
+        // warm-up run allocates every pooled buffer, then the same launch sequence is captured
+        CK(launch_forward(e, reps, fuser_on, sd_conv != 0, st, &e->launches));
+        if (hipStreamSynchronize(st) != hipSuccess) return GL_ERR_BAD_ARG;
+        if (e->pool_changed) { e->drop_graphs(); e->pool_changed = false; }
+        hipGraph_t graph = nullptr;
+        if (e->cap_stream == nullptr && hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking) != hipSuccess) return GL_ERR_UNSUPPORTED;
+        if (hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return GL_ERR_UNSUPPORTED;
+        e->capturing = true;
+        const int rc = launch_forward(e, reps, fuser_on, sd_conv != 0, e->cap_stream, nullptr);
+        e->capturing = false;
+        const hipError_t ec = hipStreamEndCapture(e->cap_stream, &graph);
+        if (rc != 0 || ec != hipSuccess || graph == nullptr) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return rc != 0 ? rc : GL_ERR_UNSUPPORTED;
+        }
+        hipGraphExec_t exec = nullptr;
+        const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ei != hipSuccess) return GL_ERR_UNSUPPORTED;
+        it = e->graphs.emplace(key, exec).first;
+    }
+    if (use_graph) {
+        if (hipGraphLaunch(it->second, st) != hipSuccess) return GL_ERR_UNSUPPORTED;
+    } else {
+        CK(launch_forward(e, reps, fuser_on, sd_conv != 0, st, &e->launches));
+        if (e->pool_changed) { e->drop_graphs(); e->pool_changed = false; }
+    }
+    if (eps != eps_i && hipMemcpyAsync(eps, eps_i, ne * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return GL_ERR_BAD_ARG;
+    return 0;
+}
+
+extern "C" int gl_plms_step(gl_engine* e, const gl_plms_step_args* a, void* stream) {
+    if (!e || !a || !a->x_eval || !a->x_base || !a->x_out || !a->e_out || a->n_terms < 1 || a->n_terms > 4) return GL_ERR_BAD_ARG;
+    if (a->reps != 1 && a->reps != 2) return GL_ERR_BAD_ARG;
+    const gl_unet_config& cfg = e->cfg;
+    if (cfg.in_channels != cfg.out_channels) return GL_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int Bn = e->Bn, side = e->hw;
+    const size_t ne = (size_t)Bn * cfg.out_channels * side * side;
+    const size_t n = ne / a->reps;
+    float* eps_i = e->f32("out.eps", ne);
+    CKP(eps_i);
+    CK(gl_unet_forward(e, a->x_eval, nullptr, a->t, a->reps, a->fuser_scale, a->sd_conv, eps_i, a->use_graph, stream));
+    if (a->reps == 2) {
+        CK(gl_cfg_combine(eps_i, a->guidance, (int64_t)n, a->e_out, st));
+    } else if (hipMemcpyAsync(a->e_out, eps_i, n * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+        return GL_ERR_BAD_ARG;
+    }
+    const float* t[4] = {nullptr, nullptr, nullptr, nullptr};
+    float c[4] = {0, 0, 0, 0};
+    for (int j = 0; j < a->n_terms; ++j) { t[j] = a->e_terms[j]; c[j] = a->coef[j]; }
+    if (!t[0]) return GL_ERR_BAD_ARG;
+    return gl_plms_update(a->x_base, t[0], t[1], t[2], t[3], c[0], c[1], c[2], c[3], a->div, a->sqrt_at, a->s1m, a->sqrt_aprev, a->dir_coef,
+                          (int64_t)n, a->x_out, st);
+}
+
+extern "C" int gl_set_option_engine(int key, int value) {
+    if (key == 20) { g_force_fuser = value; return 0; }
+    return GL_ERR_BAD_ARG;
+}
+
+extern "C" int64_t gl_pool_bytes(const gl_engine* e) {
+    if (!e) return -1;
+    int64_t s = 0;
+    for (auto& kv : e->pool) s += (int64_t)kv.second.bytes;
+    return s;
+}
+extern "C" int gl_num_launches(const gl_engine* e) { return e ? e->launches : GL_ERR_BAD_ARG; }
+extern "C" int gl_sizeof_unet_config(void) { return (int)sizeof(gl_unet_config); }
+extern "C" int gl_sizeof_weight_info(void) { return (int)sizeof(gl_weight_info); }
+extern "C" int gl_sizeof_plms_step_args(void) { return (int)sizeof(gl_plms_step_args); }

@@ -5,7 +5,8 @@ are independent units, so the path shards by prompt with zero exchange during de
 One process per GPU (``torch.distributed``; backend "nccl" is RCCL over xGMI on ROCm, "gloo" in CPU
 tests).  Rank 0 loads + packs the checkpoint, then every packed tensor travels in a single
 ``broadcast`` of one flat byte buffer (2.5 GB fp16 UNet: one large xGMI-friendly message instead of
-1238 small ones); the other ranks carve views out of it by a small manifest sent alongside.
+1238 small ones); the buffer's layout is the C engine's weight table (gl_weight_at), so every rank hands the received
+bytes straight to gl_load_weights and carves its tensor views out of them by the same table.
 """
 from __future__ import annotations
 
@@ -25,43 +26,17 @@ def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_items, world))
 
 
-def _layout(entries: List[Tuple[str, Tuple[int, ...], torch.dtype]]) -> Tuple[Dict[str, int], int]:
-    off, offsets = 0, {}
-    for name, shape, dtype in entries:
-        n = 1
-        for s in shape:
-            n *= s
-        offsets[name] = off
-        off += (n * torch.empty((), dtype=dtype).element_size() + _ALIGN - 1) // _ALIGN * _ALIGN
-    return offsets, off
-
-
 def flatten_packed(P: PackedWeights) -> Tuple[torch.Tensor, dict]:
-    """All tensors of P into one uint8 buffer (256-byte aligned slots) + the manifest to rebuild them."""
-    entries = [(k, tuple(v.shape), v.dtype) for k, v in P.w.items()]
-    offsets, total = _layout(entries)
-    flat = torch.zeros(total, dtype=torch.uint8, device=P.device)
-    for name, shape, dtype in entries:
-        src = P.w[name].contiguous().view(-1).view(torch.uint8)
-        flat[offsets[name]:offsets[name] + src.numel()].copy_(src)
-    manifest = dict(entries=entries, scalars=dict(P.s), emb_offsets=dict(P.emb_offsets), emb_total=P.emb_total, total=total)
-    return flat, manifest
+    """The flat byte buffer of P (its layout is the C engine's weight table, weights.PackedWeights.to_flat) + the few
+    host-side facts the receivers need."""
+    if P.flat is None:
+        P.to_flat()
+    return P.flat, dict(total=int(P.flat.numel()), has_sd_conv=bool(P.has_sd_conv))
 
 
 def unflatten_packed(flat: torch.Tensor, manifest: dict, cfg: UNetConfig, device) -> PackedWeights:
-    P = PackedWeights(cfg, build_plan(cfg), device)
-    offsets, total = _layout(manifest["entries"])
-    assert total == manifest["total"] == flat.numel()
-    for name, shape, dtype in manifest["entries"]:
-        n = 1
-        for s in shape:
-            n *= s
-        nbytes = n * torch.empty((), dtype=dtype).element_size()
-        P.w[name] = flat[offsets[name]:offsets[name] + nbytes].view(dtype).view(shape)
-    P.s.update(manifest["scalars"])
-    P.emb_offsets.update(manifest["emb_offsets"])
-    P.emb_total = manifest["emb_total"]
-    return P
+    assert manifest["total"] == flat.numel()
+    return PackedWeights.from_flat(flat, cfg, device, manifest["has_sd_conv"])
 
 
 def broadcast_packed(P: Optional[PackedWeights], cfg: UNetConfig, device, src: int = 0) -> PackedWeights:

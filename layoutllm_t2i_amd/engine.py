@@ -1,69 +1,64 @@
-"""The MI355X UNet engine: walks the block plan and launches the HIP kernels of libgligen_hip.so.
+"""Python face of the MI355X UNet engine.  The engine itself is C++ behind the forward-level C ABI of
+``include/gligen_hip.h`` (``csrc/engine.hip``): block plan, packed-weight layout, activation pool, hoisted
+conditioning, launch sequence and hipGraph capture / replay all live behind ``gl_create`` / ``gl_load_weights`` /
+``gl_set_conditioning`` / ``gl_unet_forward`` / ``gl_plms_step``.  This class only turns torch tensors (device memory
+and streams) into raw pointers for those calls -- it replaces ``UNetModel.forward`` (openaimodel.py:413-459) for the
+Python callers (``model.UNetModel``, ``sampler.PLMSSampler``).
 
-Replaces ``UNetModel.forward`` (openaimodel.py:413-459) and everything below it.  Differences from
-the reference that are *result-identical*  and where the time goes:
-
-  * token-major fp16 activations end to end; concat / residual / time-embedding / GEGLU / gates are
-    fused into GEMM and conv epilogues; attention never materialises the N x N score tensor;
-  * everything that depends only on the conditioning is hoisted into ``set_conditioning`` (once per
-    image instead of 102 times): PositionNet tokens, fuser.linear(objs) per layer, attn2 and
-    rela_fuse K/V projections, integer box rectangles per resolution;
-  * the gated-SA fuser is skipped outright when the sampler sets scale == 0 (exact identity);
-  * the RelationCrossAttention injection runs in closed form (two small kernels + tiny GEMMs);
-  * a whole forward is captured into a HIP graph per (fuser on/off, first-conv variant) and replayed;
-  * the RESIDUAL STREAM is fp32: every block output (ResBlock sum, transformer-block x after each of its residual
-    adds, proj_out + x_in, conv_in / down / up outputs) is accumulated and stored in fp32 by the producing GEMM / conv
-    epilogue, with an fp16 copy only where a matrix-core consumer needs one (GroupNorm -> conv, 1x1 skip conv, down /
-    up convs, proj_out).  LayerNorm reads the fp32 stream; rela_fuse's LN3 term is re-evaluated in fp32 inside
-    rela_merge.  Only operands of matrix products are fp16 (tools/precision_sim.py: that floor is rel-L2 1.1e-3).
-
-No torch op touches activations on the hot path: torch provides device memory, streams and graphs.
+No torch op touches activations on the hot path, and there is no fallback: a missing library, a CPU tensor or a
+missing GPU raises.
 """
 from __future__ import annotations
 
-import math
+import ctypes as C
 from typing import Dict, List, Optional, Tuple
 
-import numpy as np
 import torch
 
-from . import host, ops
-from ._lib import EPI_BIAS, EPI_GATE_RES, EPI_GEGLU, EPI_RES, EPI_ROWBIAS, EPI_SILU, init_device
-from .arch import Block, Layer, UNetConfig
-from .weights import CIN_PAD, PackedWeights
+from . import _lib
+from ._lib import PlmsStepArgs, check, init_device
+from .arch import UNetConfig
+from .weights import PackedWeights
 
 F16, F32 = torch.float16, torch.float32
-
-
-def _rup(x: int, m: int) -> int:
-    return (x + m - 1) // m * m
 
 
 class UNetEngine:
     def __init__(self, packed: PackedWeights):
         if not torch.cuda.is_available():
             raise RuntimeError("UNetEngine needs a GPU: the denoising path has no CPU fallback")
-        init_device()
+        if packed.flat is None or not packed.flat.is_cuda:
+            raise _lib.HipLibraryError("packed weights must be a flat buffer on the GPU (PackedWeights.to_flat on a cuda device)")
         self.P = packed
         self.cfg: UNetConfig = packed.cfg
         self.plan = packed.plan
-        self.dev = packed.device
+        self.dev = torch.device(packed.device)
+        if self.dev.index is None:
+            self.dev = torch.device("cuda", torch.cuda.current_device())
         self.W, self.S = packed.w, packed.s
+        init_device(self.dev.index)
+        self._lib = _lib.lib()
+        self.handle = _lib.create_engine(self.cfg)
+        with torch.cuda.device(self.dev):
+            check(self._lib.gl_load_weights(self.handle, packed.flat.data_ptr(), packed.flat.numel(), int(packed.has_sd_conv), self._stream()),
+                  "gl_load_weights")
         self._pool: Dict[Tuple, torch.Tensor] = {}
-        self._gates: Dict[str, torch.Tensor] = {}
-        self.st_layers: List[Layer] = self.plan.st_layers()
-        # constant gates of rela_fuse, per-step gates of the fuser (scale * tanh(alpha))
-        for l in self.st_layers:
-            t = l.prefix + ".transformer_blocks.0"
-            for k in ("tanh_attn", "tanh_dense"):
-                self._gates[f"{t}.rela_fuse.{k}"] = torch.full((1,), self.S[f"{t}.rela_fuse.{k}"], dtype=F32, device=self.dev)
-                self._gates[f"{t}.fuser.{k}"] = torch.zeros((1,), dtype=F32, device=self.dev)
-        self._fuser_scale: Optional[float] = None
         self.cond: Optional[dict] = None
-        self._graphs: Dict[Tuple, torch.cuda.CUDAGraph] = {}
+        self._cond_refs: Tuple = ()
         self.use_graphs = True
 
-    # ------------------------------------------------------------------ memory
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            try:
+                self._lib.gl_destroy(h)
+            except Exception:
+                pass
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    # ------------------------------------------------------------------ torch-side scratch (sampler state, outputs)
     def buf(self, tag: str, shape, dtype=F16, zero: bool = False) -> torch.Tensor:
         key = (tag, tuple(shape), dtype)
         t = self._pool.get(key)
@@ -73,7 +68,12 @@ class UNetEngine:
         return t
 
     def pool_bytes(self) -> int:
-        return sum(t.numel() * t.element_size() for t in self._pool.values())
+        """bytes of the engine's activation pool (C side) + the torch-side sampler buffers"""
+        return int(self._lib.gl_pool_bytes(self.handle)) + sum(t.numel() * t.element_size() for t in self._pool.values())
+
+    def num_launches(self) -> int:
+        """kernel launches of one forward (as counted by the last eager / capture pass)"""
+        return int(self._lib.gl_num_launches(self.handle))
 
     # ------------------------------------------------------------------ conditioning (once per image)
     @torch.no_grad()
@@ -81,281 +81,85 @@ class UNetEngine:
         """context [Bn,77,ctx], relations [Bn,R,ctx], boxes [Bn,30,4], masks [Bn,30],
         positive_embeddings [Bn,30,in_dim]: fp32 tensors (any device).  Null grounding = zeros
         (text_layout_tokinzer_input.py:47-62).  ``hw`` = latent side (64 for 512x512)."""
-        dev, cfg, W = self.dev, self.cfg, self.W
+        dev = self.dev
         f32 = lambda t: torch.as_tensor(t, dtype=F32).to(dev).contiguous()
         context, relations = f32(context), f32(relations)
         boxes, masks, pe = f32(boxes), f32(masks), f32(positive_embeddings)
         Bn, mo = boxes.shape[0], boxes.shape[1]
-        R = relations.shape[1]
-        Lc = context.shape[1]
-        c: dict = dict(Bn=Bn, mo=mo, R=R, Lc=Lc, hw=hw)
-        # --- grounding tokens: PositionNet (text_grounding_net.py:26-43)
-        pin = self.buf("pn.in", (Bn * mo, cfg.pos_in_dim + cfg.position_dim))
-        ops.posnet_input(boxes, masks, pe, W["position_net.null_pos"], W["position_net.null_xyxy"], cfg.fourier_freqs, pin)
-        h1 = ops.gemm(pin, W["position_net.linears.0.w"], self.buf("pn.h1", (Bn * mo, 512)), W["position_net.linears.0.b"], EPI_SILU)
-        h2 = ops.gemm(h1, W["position_net.linears.2.w"], self.buf("pn.h2", (Bn * mo, 512)), W["position_net.linears.2.b"], EPI_SILU)
-        objs = ops.gemm(h2, W["position_net.linears.4.w"], self.buf("pn.objs", (Bn * mo, cfg.pos_out_dim)), W["position_net.linears.4.b"])
-        c["objs"] = objs
-        ctx16 = self.buf("cond.ctx", (Bn * Lc, cfg.context_dim))
-        ctx16.copy_(context.reshape(Bn * Lc, -1))
-        rel16 = self.buf("cond.rel", (Bn * R, cfg.context_dim))
-        rel16.copy_(relations.reshape(Bn * R, -1))
-        H = cfg.num_heads
-        for li, l in enumerate(self.st_layers):
-            t = l.prefix + ".transformer_blocks.0"
-            C, d = l.cin, l.d_head
-            # fuser.linear(objs) (attention.py:228)
-            c[f"objs.{li}"] = ops.gemm(objs, W[f"{t}.fuser.linear.w"], self.buf(f"hoist.objs.{li}", (Bn * mo, C)), W[f"{t}.fuser.linear.b"])
-            # attn2 K/V of the text context (attention.py:124-125)
-            kv = ops.gemm(ctx16, W[f"{t}.attn2.kv.w"], self.buf(f"hoist.kvctx.{li}", (Bn * Lc, 2 * C)))
-            vt = self.buf(f"hoist.vtctx.{li}", (Bn, H, d, ops.vt_ld(Lc)))
-            ops.transpose_v(kv[:, C:], Lc * 2 * C, 2 * C, vt, Bn, H, d, Lc)
-            c[f"kvctx.{li}"], c[f"vtctx.{li}"] = kv, vt
-            # rela_fuse K/V of the relation tokens (attention.py:348-349)
-            kvr = ops.gemm(rel16, W[f"{t}.rela_fuse.attn.kv.w"], self.buf(f"hoist.kvrel.{li}", (Bn * R, 2 * C)))
-            vtr = self.buf(f"hoist.vtrel.{li}", (Bn, H, d, ops.vt_ld(R)))
-            ops.transpose_v(kvr[:, C:], R * 2 * C, 2 * C, vtr, Bn, H, d, R)
-            c[f"kvrel.{li}"], c[f"vtrel.{li}"] = kvr, vtr
-        # --- integer rectangles per resolution (host, fp32; attention.py:321-346)
-        bx, mk = boxes.cpu().numpy(), masks.cpu().numpy()
-        seen = set()
-        for level_hw in self._st_resolutions(hw):
-            if level_hw in seen:
-                continue
-            seen.add(level_hw)
-            rects, nvalid, poison = host.box_rects(bx, mk, level_hw, level_hw)
-            # pooled (address-stable) buffers, so captured graphs stay valid across images
-            for nm, arr in (("rects", rects), ("nvalid", nvalid), ("poison", poison)):
-                t = self.buf(f"cond.{nm}.{level_hw}", arr.shape, torch.int32)
-                t.copy_(torch.from_numpy(arr))
-                c[f"{nm}.{level_hw}"] = t
-        self.cond = c
-        torch.cuda.current_stream().synchronize()
+        if mo != self.cfg.max_objs:
+            raise ValueError(f"{mo} grounding slots, the model was built for {self.cfg.max_objs}")
+        if context.shape[-1] != self.cfg.context_dim or relations.shape[-1] != self.cfg.context_dim or pe.shape[-1] != self.cfg.pos_in_dim:
+            raise ValueError("conditioning feature dims do not match the model config")
+        if not (context.shape[0] == relations.shape[0] == masks.shape[0] == pe.shape[0] == Bn):
+            raise ValueError("conditioning batch sizes differ")
+        R, Lc = relations.shape[1], context.shape[1]
+        with torch.cuda.device(dev):
+            check(self._lib.gl_set_conditioning(self.handle, context.data_ptr(), relations.data_ptr(), boxes.data_ptr(), masks.data_ptr(),
+                                                pe.data_ptr(), Bn, Lc, R, hw, self._stream()), "gl_set_conditioning")
+        self._cond_refs = (context, relations, boxes, masks, pe)      # read asynchronously by the launched kernels
+        self.cond = dict(Bn=Bn, mo=mo, R=R, Lc=Lc, hw=hw)
 
-    def _st_resolutions(self, hw: int) -> List[int]:
-        out, cur = [], hw
-        for b in self.plan.input_blocks:
-            for l in b.layers:
-                if l.kind == "down":
-                    cur //= 2
-                elif l.kind == "st":
-                    out.append(cur)
-        out.append(cur)  # middle
-        return sorted(set(out), reverse=True)
-
-    # ------------------------------------------------------------------ per-step scalars
-    def set_fuser_scale(self, scale: float) -> None:
-        """set_alpha_scale (interface.py:34-38): only GatedSelfAttentionDense is gated."""
-        if self._fuser_scale == scale:
-            return
-        for l in self.st_layers:
-            f = l.prefix + ".transformer_blocks.0.fuser"
-            self._gates[f + ".tanh_attn"].fill_(scale * self.S[f + ".tanh_attn"])
-            self._gates[f + ".tanh_dense"].fill_(scale * self.S[f + ".tanh_dense"])
-        self._fuser_scale = scale
-
-    # ------------------------------------------------------------------ layers
-    def _groupnorm(self, x1, x2, Bn, HW, p, eps, silu, tag):
-        C = x1.shape[-1] + (x2.shape[-1] if x2 is not None else 0)
-        out = self.buf(tag, (Bn * HW, C))
-        partial = self.buf("gn.partial", (Bn * 64 * 64,), F32)
-        return ops.groupnorm(x1, x2, Bn, HW, self.W[p + ".g"], self.W[p + ".b"], eps, silu, out, partial)
-
-    def _stream(self, tag, M, C):
-        """fp32 residual-stream tensor + its fp16 copy for matrix-core consumers"""
-        return self.buf(tag + ".f32", (M, C), F32), self.buf(tag, (M, C))
-
-    def _res_block(self, l: Layer, h, skip, Bn, side, emb_out, out_tag):
-        """h = (fp32, fp16) stream pair; skip = (fp32, fp16) pair popped from the skip stack or None."""
-        W, p = self.W, l.prefix
-        HW = side * side
-        h32, h16 = h
-        s16 = skip[1] if skip is not None else None
-        t = self._groupnorm(h16, s16, Bn, HW, p + ".in_layers.0", 1e-5, True, "rb.gn1")
-        off = self.P.emb_offsets[p]
-        h1 = ops.conv3x3(t, W[p + ".in_layers.2.w"], self.buf("rb.h1", (Bn * HW, l.cout)), Bn, side, side,
-                         W[p + ".in_layers.2.b"], epi=EPI_ROWBIAS, rowbias=emb_out[:, off:off + l.cout], rows_per_sample=HW)
-        t2 = self._groupnorm(h1, None, Bn, HW, p + ".out_layers.0", 1e-5, True, "rb.gn2")
-        if l.cin != l.cout:
-            sk = ops.gemm(h16, W[p + ".skip_connection.w"], self.buf("rb.skip.f32", (Bn * HW, l.cout), F32), W[p + ".skip_connection.b"], a2=s16)
-        else:
-            assert skip is None
-            sk = h32
-        o32, o16 = self._stream(out_tag, Bn * HW, l.cout)
-        ops.conv3x3(t2, W[p + ".out_layers.3.w"], o32, Bn, side, side, W[p + ".out_layers.3.b"], epi=EPI_RES, res=sk, out16=o16)
-        return o32, o16
-
-    def _self_attention(self, src, rows_per_b, Nq, Nk, C, d, wp, tagp):
-        """src [Bn*rows_per_b, C] (already normalised) -> attention output [Bn*Nq, C] (before to_out)."""
-        Bn, H = self.cond["Bn"], self.cfg.num_heads
-        qkv = ops.gemm(src, self.W[wp + ".qkv.w"], self.buf(tagp + ".qkv", (Bn * rows_per_b, 3 * C)))
-        vt = self.buf(tagp + ".vt", (Bn, H, d, ops.vt_ld(Nk)))
-        ops.transpose_v(qkv[:, 2 * C:], rows_per_b * 3 * C, 3 * C, vt, Bn, H, d, Nk)
-        att = self.buf(tagp + ".att", (Bn * Nq, C))
-        ops.attention(qkv, rows_per_b * 3 * C, 3 * C, qkv[:, C:], rows_per_b * 3 * C, 3 * C, vt, att, Nq * C, C,
-                      Bn, H, d, Nq, Nk, d ** -0.5)
-        return att
-
-    def _feed_forward(self, xn, res, p, M, C, out, gate=None):
-        W = self.W
-        hg = ops.gemm(xn, W[p + ".ff1.w"], self.buf("ff.h", (M, 4 * C)), W[p + ".ff1.b"], EPI_GEGLU)
-        if gate is None:
-            return ops.gemm(hg, W[p + ".ff2.w"], out, W[p + ".ff2.b"], EPI_RES, res=res)
-        return ops.gemm(hg, W[p + ".ff2.w"], out, W[p + ".ff2.b"], EPI_GATE_RES, res=res, gate=gate)
-
-    def _spatial_transformer(self, l: Layer, li: int, x_in, Bn, side, fuser_on, out_tag):
-        """x_in = (fp32, fp16) stream pair.  Inside the block x lives in fp32 only (two ping-pong buffers)."""
-        W, c, cfg = self.W, self.cond, self.cfg
-        p = l.prefix
-        t = p + ".transformer_blocks.0"
-        C, d, H = l.cin, l.d_head, cfg.num_heads
-        N = side * side
-        M = Bn * N
-        mo, R, Lc = c["mo"], c["R"], c["Lc"]
-        xin32, xin16 = x_in
-        xa, xb = self.buf("st.xa", (M, C), F32), self.buf("st.xb", (M, C), F32)
-        g0 = self._groupnorm(xin16, None, Bn, N, p + ".norm", 1e-6, False, "st.gn")
-        x = ops.gemm(g0, W[p + ".proj_in.w"], xa, W[p + ".proj_in.b"])
-        nxt = lambda cur: xb if cur is xa else xa
-        # --- attn1 (attention.py:395)
-        n1 = ops.layernorm(x, self.buf("st.ln", (M, C)), W[t + ".norm1.g"], W[t + ".norm1.b"], Bn, N)
-        att = self._self_attention(n1, N, N, N, C, d, t + ".attn1", "st.sa")
-        x = ops.gemm(att, W[t + ".attn1.o.w"], nxt(x), W[t + ".attn1.o.b"], EPI_RES, res=x)
-        # --- gated self-attention fuser over [x ; objs] (attention.py:226-234); exact identity at scale 0
-        if fuser_on:
-            f = t + ".fuser"
-            cat = self.buf("st.cat", (Bn * (N + mo), C))
-            ops.layernorm(x, cat, W[f + ".norm1.g"], W[f + ".norm1.b"], Bn, N, N + mo, 0)
-            ops.layernorm(c[f"objs.{li}"], cat, W[f + ".norm1.g"], W[f + ".norm1.b"], Bn, mo, N + mo, N)
-            att = self._self_attention(cat, N + mo, N, N + mo, C, d, f + ".attn", "st.fa")
-            x = ops.gemm(att, W[f + ".attn.o.w"], nxt(x), W[f + ".attn.o.b"], EPI_GATE_RES, res=x,
-                         gate=self._gates[f + ".tanh_attn"])
-            n2 = ops.layernorm(x, self.buf("st.ln", (M, C)), W[f + ".norm2.g"], W[f + ".norm2.b"], Bn, N)
-            x = self._feed_forward(n2, x, f + ".ff", M, C, nxt(x), gate=self._gates[f + ".tanh_dense"])
-        # --- relation injection (attention.py:315-359, :398), closed form
-        r = t + ".rela_fuse"
-        rects, nvalid, poison = c[f"rects.{side}"], c[f"nvalid.{side}"], c[f"poison.{side}"]
-        stats = self.buf("st.lnstats", (M, 2), F32)
-        hid = ops.layernorm(x, self.buf("st.hid", (M, C)), W[r + ".norm3.g"], W[r + ".norm3.b"], Bn, N, stats=stats)
-        Mo = Bn * mo
-        feat = ops.rela_pool(hid, Bn, side, side, C, rects, nvalid, poison, mo, self.buf("rl.feat", (Mo, C)))
-        fn = ops.layernorm(feat, self.buf("rl.ln", (Mo, C)), W[r + ".norm1.g"], W[r + ".norm1.b"], Bn, mo)
-        q = ops.gemm(fn, W[r + ".attn.q.w"], self.buf("rl.q", (Mo, C)))
-        kv = c[f"kvrel.{li}"]
-        ar = self.buf("rl.att", (Mo, C))
-        ops.attention(q, mo * C, C, kv, R * 2 * C, 2 * C, c[f"vtrel.{li}"], ar, mo * C, C, Bn, H, d, mo, R, d ** -0.5)
-        f1 = ops.gemm(ar, W[r + ".attn.o.w"], self.buf("rl.f1", (Mo, C)), W[r + ".attn.o.b"], EPI_GATE_RES, res=feat,
-                      gate=self._gates[r + ".tanh_attn"])
-        fn2 = ops.layernorm(f1, self.buf("rl.ln", (Mo, C)), W[r + ".norm2.g"], W[r + ".norm2.b"], Bn, mo)
-        hg = ops.gemm(fn2, W[r + ".ff.ff1.w"], self.buf("rl.ffh", (Mo, 4 * C)), W[r + ".ff.ff1.b"], EPI_GEGLU)
-        f2 = ops.gemm(hg, W[r + ".ff.ff2.w"], self.buf("rl.f2", (Mo, C)), W[r + ".ff.ff2.b"], EPI_GATE_RES, res=f1,
-                      gate=self._gates[r + ".tanh_dense"])
-        x = ops.rela_merge(x, None, f2, Bn, side, side, C, rects, nvalid, poison, mo, nxt(x), ln_stats=stats,
-                           gamma=W[r + ".norm3.g"], beta=W[r + ".norm3.b"])
-        # --- attn2: text cross-attention with hoisted K/V (attention.py:400)
-        n = ops.layernorm(x, self.buf("st.ln", (M, C)), W[t + ".norm2.g"], W[t + ".norm2.b"], Bn, N)
-        q2 = ops.gemm(n, W[t + ".attn2.q.w"], self.buf("st.q2", (M, C)))
-        a2 = self.buf("st.att2", (M, C))
-        ops.attention(q2, N * C, C, c[f"kvctx.{li}"], Lc * 2 * C, 2 * C, c[f"vtctx.{li}"], a2, N * C, C, Bn, H, d, N, Lc,
-                      d ** -0.5)
-        x = ops.gemm(a2, W[t + ".attn2.o.w"], nxt(x), W[t + ".attn2.o.b"], EPI_RES, res=x)
-        # --- GEGLU feed-forward (attention.py:401): the sum is only consumed by proj_out's matrix product -> fp16
-        n3 = ops.layernorm(x, self.buf("st.ln", (M, C)), W[t + ".norm3.g"], W[t + ".norm3.b"], Bn, N)
-        x16 = self._feed_forward(n3, x, t + ".ff", M, C, self.buf("st.x6", (M, C)))
-        # --- proj_out + residual (attention.py:444-446)
-        o32, o16 = self._stream(out_tag, M, C)
-        ops.gemm(x16, W[p + ".proj_out.w"], o32, W[p + ".proj_out.b"], EPI_RES, res=xin32, out16=o16)
-        return o32, o16
-
-    # ------------------------------------------------------------------ one forward (eager launch sequence)
-    def _launch_forward(self, x_lat: torch.Tensor, t_buf: torch.Tensor, reps: int, fuser_on: bool, sd_conv: bool,
-                        eps_out: torch.Tensor) -> None:
-        W, cfg, c = self.W, self.cfg, self.cond
+    # ------------------------------------------------------------------ forward
+    def _check_x(self, x_lat: torch.Tensor, reps: int):
+        c = self.cond
+        if c is None:
+            raise RuntimeError("call set_conditioning() first")
         Bn, side = c["Bn"], c["hw"]
-        mc = cfg.model_channels
-        st_index = {l.prefix: i for i, l in enumerate(self.st_layers)}
-        # time embedding (openaimodel.py:428-429) and all 22 emb_layers in one GEMM (:172-178, :220)
-        te = ops.timestep_embedding(t_buf, mc, self.buf("te.sin", (Bn, mc)))
-        e1 = ops.gemm(te, W["time_embed.0.w"], self.buf("te.e1", (Bn, 4 * mc)), W["time_embed.0.b"], EPI_SILU)
-        e2 = ops.gemm(e1, W["time_embed.2.w"], self.buf("te.e2", (Bn, 4 * mc)), W["time_embed.2.b"], EPI_SILU)
-        emb_out = ops.gemm(e2, W["emb_all.w"], self.buf("te.out", (Bn, self.P.emb_total)), W["emb_all.b"])
-        # first conv on the zero-padded NHWC latent (openaimodel.py:299, :393-405)
-        xin = ops.pack_latent(x_lat, CIN_PAD, reps, self.buf("in.x", (Bn * side * side, CIN_PAD)))
-        fc = "sd_first_conv" if sd_conv else "input_blocks.0.0"
-        M0 = Bn * side * side
-        h = self._stream("skip.0", M0, mc)
-        ops.conv3x3(xin, W[fc + ".w"], h[0], Bn, side, side, W[fc + ".b"], out16=h[1])
-        skips: List[Tuple[Tuple[torch.Tensor, torch.Tensor], int]] = [(h, side)]
+        if x_lat.shape[0] * reps != Bn or x_lat.shape[-1] != side or x_lat.shape[1] != self.cfg.in_channels:
+            raise ValueError(f"latent batch {tuple(x_lat.shape)} x reps {reps} does not match conditioning batch {Bn} @ {side}")
+        if not x_lat.is_cuda or x_lat.dtype != F32 or not x_lat.is_contiguous():
+            raise _lib.HipLibraryError("latent must be a contiguous fp32 GPU tensor (the HIP path has no CPU fallback)")
+        return Bn, side
 
-        def run_block(b: Block, h, side, bi: str, skip=None):
-            for j, l in enumerate(b.layers):
-                tag = f"{bi}.{j}"
-                if l.kind == "res":
-                    h = self._res_block(l, h, skip, Bn, side, emb_out, tag)
-                    skip = None
-                elif l.kind == "st":
-                    h = self._spatial_transformer(l, st_index[l.prefix], h, Bn, side, fuser_on, tag)
-                elif l.kind == "down":
-                    o = self._stream(tag, Bn * (side // 2) ** 2, l.cout)
-                    ops.conv3x3(h[1], W[l.prefix + ".w"], o[0], Bn, side, side, W[l.prefix + ".b"], stride=2, out16=o[1])
-                    h = o
-                    side //= 2
-                elif l.kind == "up":
-                    o = self._stream(tag, Bn * (side * 2) ** 2, l.cout)
-                    ops.conv3x3(h[1], W[l.prefix + ".w"], o[0], Bn, side, side, W[l.prefix + ".b"], upsample2x=True, out16=o[1])
-                    h = o
-                    side *= 2
-            return h, side
-
-        for i, b in enumerate(self.plan.input_blocks[1:], start=1):
-            h, side = run_block(b, h, side, f"skip.{i}")
-            skips.append((h, side))
-        h, side = run_block(self.plan.middle, h, side, "mid")
-        for i, b in enumerate(self.plan.output_blocks):
-            sk, sside = skips.pop()
-            assert sside == side
-            h, side = run_block(b, h, side, f"out.{i}", skip=sk)
-        g = self._groupnorm(h[1], None, Bn, side * side, "out.0", 1e-5, True, "fin.gn")
-        ops.conv3x3(g, W["out.2.w"], eps_out, Bn, side, side, W["out.2.b"], nchw_hw=side * side)
-
-    # ------------------------------------------------------------------ public forward
     @torch.no_grad()
     def forward(self, x_lat: torch.Tensor, t, fuser_scale: float = 1.0, sd_conv: bool = False, reps: int = 1,
                 eps_out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x_lat fp32 [Bn/reps, 4, hw, hw] (NCHW, like the reference); returns eps fp32 [Bn, 4, hw, hw].
         With reps=2 the latent is shared by both CFG halves of a [cond ; uncond] conditioning batch."""
-        c = self.cond
-        if c is None:
-            raise RuntimeError("call set_conditioning() first")
-        Bn, side = c["Bn"], c["hw"]
-        if x_lat.shape[0] * reps != Bn or x_lat.shape[-1] != side:
-            raise ValueError(f"latent batch {tuple(x_lat.shape)} x reps {reps} does not match conditioning batch {Bn} @ {side}")
-        if sd_conv and "sd_first_conv.w" not in self.W:
+        Bn, side = self._check_x(x_lat, reps)
+        if sd_conv and not self.P.has_sd_conv:
             raise RuntimeError("SD first-conv weights were not packed")
-        t_buf = self.buf("in.t", (Bn,), F32)
-        if torch.is_tensor(t):
-            t_buf.copy_(t.to(F32).reshape(-1).expand(Bn) if t.numel() == 1 else t.to(F32))
-        else:
-            t_buf.fill_(float(t))
-        self.set_fuser_scale(float(fuser_scale))
-        fuser_on = fuser_scale != 0
         if eps_out is None:
             eps_out = self.buf("out.eps", (Bn, self.cfg.out_channels, side, side), F32)
-        x_static = self.buf("in.xlat", tuple(x_lat.shape), F32)
-        if x_lat.data_ptr() != x_static.data_ptr():
-            x_static.copy_(x_lat)
-        if not self.use_graphs:
-            self._launch_forward(x_static, t_buf, reps, fuser_on, sd_conv, eps_out)
-            return eps_out
-        key = (Bn, side, c["R"], c["Lc"], c["mo"], fuser_on, sd_conv, reps, eps_out.data_ptr(), tuple(x_lat.shape))
-        g = self._graphs.get(key)
-        if g is None:
-            # warm-up run allocates every pooled buffer, then capture the same launch sequence
-            self._launch_forward(x_static, t_buf, reps, fuser_on, sd_conv, eps_out)
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._launch_forward(x_static, t_buf, reps, fuser_on, sd_conv, eps_out)
-            self._graphs[key] = g
-        g.replay()
+        t_dev, t_host, keep = None, 0.0, None
+        if torch.is_tensor(t):
+            if t.numel() == 1:
+                t_host = float(t.reshape(-1)[0])
+            else:
+                keep = t.to(self.dev, F32).reshape(-1).contiguous()
+                if keep.numel() != Bn:
+                    raise ValueError("timesteps must have one entry per sample")
+                t_dev = keep.data_ptr()
+        else:
+            t_host = float(t)
+        with torch.cuda.device(self.dev):
+            check(self._lib.gl_unet_forward(self.handle, x_lat.data_ptr(), t_dev, t_host, reps, float(fuser_scale), int(bool(sd_conv)),
+                                            eps_out.data_ptr(), int(self.use_graphs), self._stream()), "gl_unet_forward")
         return eps_out
+
+    @torch.no_grad()
+    def plms_step(self, x_eval: torch.Tensor, x_base: torch.Tensor, x_out: torch.Tensor, e_out: torch.Tensor, e_terms: List[torch.Tensor],
+                  coefs, div: float, t: float, reps: int, guidance: float, fuser_scale: float, sd_conv: bool, sqrt_at: float, s1m: float,
+                  sqrt_aprev: float, dir_coef: float) -> torch.Tensor:
+        """One gl_plms_step: UNet(x_eval, t) -> CFG combine into ``e_out`` -> e' = sum coefs[j] * e_terms[j] / div ->
+        x_out = PLMS / DDIM(sigma 0) update of x_base (plms.py:110-163)."""
+        self._check_x(x_eval, reps)
+        a = PlmsStepArgs()
+        for tns, name in ((x_eval, "x_eval"), (x_base, "x_base"), (x_out, "x_out"), (e_out, "e_out"), *[(e, "e_term") for e in e_terms]):
+            if not tns.is_cuda or tns.dtype != F32 or not tns.is_contiguous() or tns.shape != x_eval.shape:
+                raise _lib.HipLibraryError(f"{name}: need a contiguous fp32 GPU tensor of the latent's shape")
+        a.x_eval, a.x_base, a.x_out, a.e_out = x_eval.data_ptr(), x_base.data_ptr(), x_out.data_ptr(), e_out.data_ptr()
+        if not 1 <= len(e_terms) <= 4 or len(coefs) != len(e_terms):
+            raise ValueError("1..4 eps terms with one coefficient each")
+        for j, (e, c) in enumerate(zip(e_terms, coefs)):
+            a.e_terms[j] = e.data_ptr()
+            a.coef[j] = float(c)
+        a.n_terms, a.div = len(e_terms), float(div)
+        a.t, a.reps, a.guidance, a.fuser_scale, a.sd_conv = float(t), int(reps), float(guidance), float(fuser_scale), int(bool(sd_conv))
+        a.sqrt_at, a.s1m, a.sqrt_aprev, a.dir_coef = float(sqrt_at), float(s1m), float(sqrt_aprev), float(dir_coef)
+        a.use_graph = int(self.use_graphs)
+        if sd_conv and not self.P.has_sd_conv:
+            raise RuntimeError("SD first-conv weights were not packed")
+        with torch.cuda.device(self.dev):
+            check(self._lib.gl_plms_step(self.handle, C.byref(a), self._stream()), "gl_plms_step")
+        return x_out

@@ -94,7 +94,6 @@ class PLMSSampler(object):
             reps = 1
         model.set_conditioning(ctx, rel, grounding, side, key=None)
 
-        eps_nb = eng.buf("plms.eps_nb", (reps * b, x.shape[1], side, side), torch.float32)
         ring = [eng.buf(f"plms.e{j}", tuple(x.shape), torch.float32) for j in range(4)]
         x_a = eng.buf("plms.x", tuple(x.shape), torch.float32)    # running latent (the engine copies it per forward)
         x_mid = eng.buf("plms.xmid", tuple(x.shape), torch.float32)
@@ -102,19 +101,13 @@ class PLMSSampler(object):
         old: List[torch.Tensor] = []      # newest last, <= 3 entries; tensors are slots of `ring`
         free = list(ring)
 
-        def model_output(x_in: torch.Tensor, t_val: int, e_dst: torch.Tensor) -> torch.Tensor:
-            eng.forward(x_in, float(t_val), model.fuser_scale, model.use_sd_conv, reps, eps_out=eps_nb)
-            if cfg_on:
-                ops.cfg_combine(eps_nb, float(guidance_scale), e_dst)
-            else:
-                e_dst.copy_(eps_nb)
-            return e_dst
-
-        def update(x_src, e, olds, coefs, div, index, x_dst):
+        def step_eval(x_eval, t_val, e_out, e_terms, coefs, div, index, x_out):
+            """one gl_plms_step: UNet (2B batch) -> CFG combine into e_out -> e' -> x_out = update of x_a"""
             sq_at, s1m, sq_ap, dirc = host.step_coefs(self._sched, index)
             if self.mirror_rng:
-                torch.randn_like(x_src)
-            return ops.plms_update(x_src, e, olds, coefs, div, sq_at, s1m, sq_ap, dirc, x_dst)
+                torch.randn_like(x_a)          # plms.py:138 draws noise * sigma (= 0) on every update: keep the RNG stream aligned
+            eng.plms_step(x_eval, x_a, x_out, e_out, e_terms, coefs, div, float(t_val), reps, float(guidance_scale),
+                          model.fuser_scale, model.use_sd_conv, sq_at, s1m, sq_ap, dirc)
 
         for i, step in enumerate(time_range):
             if alphas is not None:
@@ -123,15 +116,16 @@ class PLMSSampler(object):
                     model.restore_first_conv_from_SD()
             index = total_steps - i - 1
             t_next = time_range[min(i + 1, len(time_range) - 1)]
-            e_t = model_output(x_a, int(step), free.pop())
+            e_t = free.pop()
             if len(old) == 0:
-                update(x_a, e_t, [], (1.0,), 1.0, index, x_mid)
-                e_next = model_output(x_mid, int(t_next), free[-1])   # scratch slot, not kept
+                # step 0 evaluates twice (plms.py:144-150): x_mid from e_t alone, then e' = (e_t + e(x_mid, t_next)) / 2
+                step_eval(x_a, int(step), e_t, [e_t], (1.0,), 1.0, index, x_mid)
+                e_next = free[-1]                                   # scratch slot, not kept
                 coefs, div = host.PLMS_COEFS[0]
-                update(x_a, e_t, [e_next], coefs, div, index, x_a)
+                step_eval(x_mid, int(t_next), e_next, [e_t, e_next], coefs, div, index, x_a)
             else:
                 coefs, div = host.PLMS_COEFS[min(len(old), 3)]
-                update(x_a, e_t, old[::-1][:len(coefs) - 1], coefs, div, index, x_a)
+                step_eval(x_a, int(step), e_t, [e_t] + old[::-1][:len(coefs) - 1], coefs, div, index, x_a)
             old.append(e_t)
             if len(old) >= 4:
                 free.append(old.pop(0))

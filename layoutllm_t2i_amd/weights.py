@@ -63,7 +63,9 @@ def geglu_interleave(t: torch.Tensor) -> torch.Tensor:
 
 
 class PackedWeights:
-    """Flat container: ``w[name]`` tensors on device + python scalars in ``s[name]``."""
+    """``w[name]`` packed tensors + python scalars ``s[name]``.  After ``to_flat()`` every tensor is a VIEW into one
+    flat byte buffer ``flat`` whose layout is defined by the C engine's weight table (gl_weight_at, include/gligen_hip.h):
+    that buffer is what gl_load_weights consumes and what dist.broadcast_packed sends in one collective."""
 
     def __init__(self, cfg: UNetConfig, plan: Plan, device):
         self.cfg, self.plan, self.device = cfg, plan, device
@@ -71,9 +73,71 @@ class PackedWeights:
         self.s: Dict[str, float] = {}
         self.emb_offsets: Dict[str, int] = {}
         self.emb_total = 0
+        self.flat: torch.Tensor | None = None
+        self.has_sd_conv = False
 
     def nbytes(self) -> int:
-        return sum(t.numel() * t.element_size() for t in self.w.values())
+        return int(self.flat.numel()) if self.flat is not None else sum(t.numel() * t.element_size() for t in self.w.values())
+
+    def to_flat(self) -> "PackedWeights":
+        """Moves every packed tensor into the flat buffer at the offsets the C engine dictates and rebinds ``w`` to views."""
+        from . import _lib
+        handle = _lib.create_engine(self.cfg)
+        try:
+            table, total = _lib.weight_table(handle)
+        finally:
+            _lib.check(_lib.lib().gl_destroy(handle), "gl_destroy")
+        flat = torch.zeros(total, dtype=torch.uint8, device=self.device)
+        self.has_sd_conv = "sd_first_conv.w" in self.w
+        views: Dict[str, torch.Tensor] = {}
+        for name, off, nbytes, dtype, shape in table:
+            td = torch.float16 if dtype == 0 else torch.float32
+            dst = flat[off:off + nbytes].view(td).view(shape)
+            if name in self.w:
+                src = self.w[name]
+                if tuple(src.shape) != tuple(shape) or src.dtype != td:
+                    raise ValueError(f"{name}: packed {tuple(src.shape)} {src.dtype} != engine table {shape} {td}")
+                dst.copy_(src)
+            elif name in self.s:
+                dst.fill_(float(self.s[name]))
+                self.s[name] = float(dst.item())       # the gates are fp32 on the device: keep the host copy identical
+            elif name.startswith("sd_first_conv."):
+                pass                                   # no SD conv given: slot stays zero, gl_load_weights(has_sd_conv=0)
+            else:
+                raise KeyError(f"engine weight table wants {name}, which the packer did not produce")
+            views[name] = dst
+        extra = set(self.w) - set(views)
+        if extra:
+            raise KeyError(f"packer produced tensors the engine does not know: {sorted(extra)[:3]}")
+        self.w, self.flat = views, flat
+        return self
+
+    @staticmethod
+    def from_flat(flat: torch.Tensor, cfg: UNetConfig, device, has_sd_conv: bool) -> "PackedWeights":
+        """Rebuilds the views (and the scalar gates) from a flat buffer, e.g. on the receiving ranks of the broadcast."""
+        from . import _lib
+        P = PackedWeights(cfg, build_plan(cfg), device)
+        handle = _lib.create_engine(cfg)
+        try:
+            table, total = _lib.weight_table(handle)
+        finally:
+            _lib.check(_lib.lib().gl_destroy(handle), "gl_destroy")
+        if flat.numel() != total:
+            raise ValueError(f"flat buffer has {flat.numel()} bytes, the engine table needs {total}")
+        for name, off, nbytes, dtype, shape in table:
+            td = torch.float16 if dtype == 0 else torch.float32
+            v = flat[off:off + nbytes].view(td).view(shape)
+            if name.endswith((".tanh_attn", ".tanh_dense")):
+                P.s[name] = float(v.item())
+            P.w[name] = v
+        off = 0
+        for l in P.plan.all_layers():
+            if l.kind == "res":
+                P.emb_offsets[l.prefix] = off
+                off += l.cout
+        P.emb_total = off
+        P.flat, P.has_sd_conv = flat, has_sd_conv
+        return P
 
 
 def pack_state_dict(sd: Mapping[str, object], cfg: UNetConfig, device, sd_first_conv: Mapping[str, object] | None = None
@@ -176,7 +240,7 @@ def pack_state_dict(sd: Mapping[str, object], cfg: UNetConfig, device, sd_first_
     W["position_net.null_xyxy"] = g("position_net.null_position_feature").contiguous()
     for i in (0, 2, 4):
         lin(f"position_net.linears.{i}")
-    return P
+    return P.to_flat()
 
 
 @torch.no_grad()

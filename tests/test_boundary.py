@@ -172,7 +172,7 @@ def test_run_batch_images_equals_the_oracle_pipeline(loaded):
     rl = float((captured["lat"].cpu() - lat_ref).norm() / lat_ref.norm())
     ri = float((captured["img"].float().cpu() - img_ref).norm() / img_ref.norm())
     print(f"[boundary] latent rel_l2={rl:.3e} decoded image rel_l2={ri:.3e}")
-    assert rl < 8e-3 and ri < 1.5e-2, (rl, ri)
+    assert rl < 4e-3 and ri < 4e-3, (rl, ri)          # measured 2.6e-3 / 2.7e-3 (fp32 reference weights, 10 chained forwards)
     assert len(imgs) == 2 and imgs[0].size == (32, 32) and imgs[0].mode == "RGB"
     want = (torch.clamp(img_ref, -1, 1) * 0.5 + 0.5).numpy().transpose(0, 2, 3, 1) * 255
     got = np.stack([np.asarray(im) for im in imgs]).astype(np.int32)
@@ -234,7 +234,7 @@ def test_gligen_inference_run_with_injected_clip(loaded, tmp_path):
     from layoutllm_t2i_amd import gligen_inference as gi
     gi._MODELS[p] = am
     meta = dict(ckpt=p, prompt=PROMPTS[0], phrases=PHRASES[0], locations=BOXES_LTRB[0], save_folder_name="t")
-    cfg = dict(batch_size=1, guidance_scale=7.5, no_plms=False, folder=str(tmp_path), device=DEV, steps=3)
+    cfg = dict(batch_size=1, guidance_scale=7.5, no_plms=False, folder=str(tmp_path), device=DEV, steps=4)
     torch.manual_seed(1)
     imgs = gi.run(meta, cfg, clip_model=clip, clip_processor=proc)
     assert len(imgs) == 1 and imgs[0].size == (128, 128)

@@ -95,7 +95,7 @@ def oracle_one(sd, cfg, inp, k, cond, tval, fuser_scale=1.0, first_conv=None):
 
 
 # measured on MI355X (round 2): see DESIGN.md section 4; asserts are <= 1.5x these
-BOUND_FULL = 2.6e-3
+BOUND_FULL = 1.8e-3          # measured 1.11e-3 .. 1.21e-3 over all six (batch, mode) cases and both 768px rows
 
 
 @pytest.mark.parametrize("B", [4, 16], ids=["configs1_2B8", "configs4_2B32"])
@@ -138,7 +138,7 @@ def test_config4_rollout_batch16_plms_runs():
     lat4 = denoise(am, sub["context"], sub["uc"], sub["relations"], {k: v[:4] for k, v in batch.items()}, sub["x"].to(DEV),
                    [0.3, 0.0, 0.7], 7.5, steps=5)
     r = report("B=16 vs B=4 rows", lat[:4], lat4)
-    assert r < 1e-2, r
+    assert r < 4e-3, r              # measured 2.7e-3: other tile / split-K choices at another batch change fp32 summation order
 
 
 def test_config3_768px_whole_unet_vs_oracle_and_50_steps():

@@ -1,0 +1,169 @@
+"""The C++ engine behind the forward-level C ABI (gl_create / gl_load_weights / gl_set_conditioning / gl_unet_forward /
+gl_plms_step, csrc/engine.hip) against an independent op-by-op restatement of the same launch sequence written in
+Python over the op-level ABI (tests/engine_pyref.py).  Both drive the same kernels, so the outputs must be BITWISE
+equal: this pins the C++ orchestration -- plan builder, weight table, buffer pool and aliasing, pointer / stride
+arithmetic, the device-side box rectangles (vs host.box_rects), graph capture / replay -- independently of precision.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.dirname(__file__))
+import golden_cases as gc
+from engine_pyref import PyRefEngine
+from layoutllm_t2i_amd import host, ops, recipe
+from layoutllm_t2i_amd.arch import TINY, UNetConfig
+from layoutllm_t2i_amd.engine import UNetEngine
+from layoutllm_t2i_amd.weights import pack_state_dict, random_state_dict
+
+DEV = "cuda:0"
+T = torch.from_numpy
+
+
+def same(a, b):
+    """bitwise equality, NaNs included (a poisoned sample is NaN everywhere in both)"""
+    return a.shape == b.shape and torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))
+
+
+def engines(cfg, seed=0, random=False):
+    dev = torch.device(DEV)
+    sd = random_state_dict(cfg, dev, seed=seed) if random else recipe.state_dict(cfg, seed)
+    fc = recipe.sd_first_conv(cfg, seed)
+    P = pack_state_dict(sd, cfg, dev, fc)
+    return UNetEngine(P), PyRefEngine(P)
+
+
+@pytest.mark.parametrize("variant", ["normal", "degenerate", "null", "clamp", "maskgap", "empty_slice", "negative"])
+def test_cpp_engine_equals_python_launch_sequence_tiny(variant):
+    """tiny UNet, B = 3, every box-rectangle edge case of attention.py:321-346 (the C++ side derives the rectangles
+    on the DEVICE, the Python side with host.box_rects); fuser on / skipped + SD conv; reps = 1 and the 2B CFG batch"""
+    eng, ref = engines(TINY)
+    B, hw = 3, 16
+    inp = {k: T(v) for k, v in recipe.synth_inputs(TINY, B, hw, n_boxes=4, n_rel=3, seed=5).items()}
+    if variant == "negative":
+        boxes = np.zeros((B, 30, 4), np.float32)
+        masks = np.zeros((B, 30), np.float32)
+        boxes[0, :2] = [(-0.5, 0.0, 0.5, 0.5), (0.2, 0.2, 0.8, 0.8)]        # slice(-8, 8) on 16 -> [8, 8): empty -> NaN sample
+        boxes[1, :3] = [(0.999, 0.0, 1.0, 1.0), (0.0, -0.3, 0.7, 0.6), (0.1, 0.1, 0.9, 2.5)]
+        boxes[2, :1] = [(0.3, 0.3, 0.30001, 0.9)]                           # zero width at every level -> break at box 0
+        masks[0, :2] = 1
+        masks[1, :3] = 1
+        masks[2, :1] = 1
+    else:
+        boxes, masks = gc.rela_boxes(variant, B)
+    inp["boxes"], inp["masks"] = T(boxes), T(masks)
+    x = inp["x"].to(DEV)
+    for e in (eng, ref):
+        e.set_conditioning(inp["context"], inp["relations"], inp["boxes"], inp["masks"], inp["positive_embeddings"], hw)
+    for fs, sdc in ((1.0, False), (0.0, True), (0.37, False)):
+        a = eng.forward(x, 481.0, fs, sdc, 1).clone()
+        b = ref.forward(x, 481.0, fs, sdc, 1).clone()
+        assert same(a, b), (variant, fs, float((torch.nan_to_num(a) - torch.nan_to_num(b)).abs().max()))
+        if variant in ("empty_slice", "negative"):
+            assert torch.isnan(a[0]).all() and torch.isfinite(a[2]).all()
+        elif variant != "null":
+            assert torch.isfinite(a).all()
+    # per-sample timesteps on the device
+    tt = torch.tensor([981.0, 481.0, 1.0])
+    assert same(eng.forward(x, tt, 1.0, False, 1).clone(), ref.forward(x, tt, 1.0, False, 1).clone())
+    # the 2B [cond ; uncond] batch sharing one latent
+    z = torch.zeros_like
+    cat = lambda p, q: torch.cat([p, q], 0)
+    for e in (eng, ref):
+        e.set_conditioning(cat(inp["context"], inp["uc"]), cat(inp["relations"], inp["relations"]), cat(inp["boxes"], z(inp["boxes"])),
+                           cat(inp["masks"], z(inp["masks"])), cat(inp["positive_embeddings"], z(inp["positive_embeddings"])), hw)
+    assert same(eng.forward(x, 21.0, 1.0, False, 2).clone(), ref.forward(x, 21.0, 1.0, False, 2).clone())
+
+
+def test_cpp_engine_graph_replay_eager_and_reconditioning():
+    eng, ref = engines(TINY)
+    B, hw = 2, 16
+    inp = {k: T(v) for k, v in recipe.synth_inputs(TINY, B, hw, n_boxes=4, n_rel=3, seed=9).items()}
+    x = inp["x"].to(DEV)
+    eng.set_conditioning(inp["context"], inp["relations"], inp["boxes"], inp["masks"], inp["positive_embeddings"], hw)
+    eng.use_graphs = False
+    a = eng.forward(x, 500.0, 1.0, False, 1).clone()
+    eng.use_graphs = True
+    b = eng.forward(x, 500.0, 1.0, False, 1).clone()
+    c = eng.forward(x, 500.0, 1.0, False, 1).clone()
+    assert torch.equal(a, b) and torch.equal(b, c), "graph replay must be bit-identical to eager launches"
+    assert 100 < eng.num_launches() < 2000
+    # new conditioning of the same shape re-uses the captured graph (the hoisted buffers are updated in place)
+    inp2 = {k: T(v) for k, v in recipe.synth_inputs(TINY, B, hw, n_boxes=2, n_rel=1, seed=10).items()}
+    eng.set_conditioning(inp2["context"], inp2["relations"], inp2["boxes"], inp2["masks"], inp2["positive_embeddings"], hw)
+    ref.set_conditioning(inp2["context"], inp2["relations"], inp2["boxes"], inp2["masks"], inp2["positive_embeddings"], hw)
+    d = eng.forward(x, 500.0, 1.0, False, 1).clone()
+    assert same(d, ref.forward(x, 500.0, 1.0, False, 1).clone()) and not torch.equal(d, c)
+    # a bigger batch / other latent size grows the pool: graphs are re-captured, results still equal
+    inp3 = {k: T(v) for k, v in recipe.synth_inputs(TINY, 5, 24, n_boxes=3, n_rel=2, seed=11).items()}
+    for e in (eng, ref):
+        e.set_conditioning(inp3["context"], inp3["relations"], inp3["boxes"], inp3["masks"], inp3["positive_embeddings"], 24)
+    x3 = inp3["x"].to(DEV)
+    assert same(eng.forward(x3, 77.0, 1.0, False, 1).clone(), ref.forward(x3, 77.0, 1.0, False, 1).clone())
+    # ... and going back to the first shape still matches
+    for e in (eng, ref):
+        e.set_conditioning(inp["context"], inp["relations"], inp["boxes"], inp["masks"], inp["positive_embeddings"], hw)
+    assert torch.equal(eng.forward(x, 500.0, 1.0, False, 1), a)
+    # scale-0 skip is an exact identity of the fuser: compare with the fuser EXECUTED under zero gates (test knob 20)
+    e0 = eng.forward(x, 500.0, 0.0, False, 1).clone()
+    ops.set_option(20, 1)
+    try:
+        e0_exec = eng.forward(x, 500.0, 0.0, False, 1).clone()
+    finally:
+        ops.set_option(20, 0)
+    assert torch.equal(e0, e0_exec), "skipping the fuser at scale 0 must equal executing it with zero gates"
+    with pytest.raises(Exception):
+        eng.forward(inp3["x"].to(DEV), 1.0)                     # latent does not match the conditioning batch / size
+
+
+def test_cpp_engine_equals_python_launch_sequence_full_model():
+    """the real 1.26 B-parameter config at 64x64, 2B = 4 (split-K, K-split, 64-row tiles all in play)"""
+    cfg = UNetConfig()
+    eng, ref = engines(cfg, seed=3, random=True)
+    B, hw = 2, 64
+    inp = {k: T(v) for k, v in recipe.synth_inputs(cfg, B, hw, n_boxes=8, n_rel=3, seed=77).items()}
+    z = torch.zeros_like
+    cat = lambda p, q: torch.cat([p, q], 0)
+    for e in (eng, ref):
+        e.set_conditioning(cat(inp["context"], inp["uc"]), cat(inp["relations"], inp["relations"]), cat(inp["boxes"], z(inp["boxes"])),
+                           cat(inp["masks"], z(inp["masks"])), cat(inp["positive_embeddings"], z(inp["positive_embeddings"])), hw)
+    x = inp["x"].to(DEV)
+    for fs, sdc in ((1.0, False), (0.0, True)):
+        a = eng.forward(x, 481.0, fs, sdc, 2).clone()
+        b = ref.forward(x, 481.0, fs, sdc, 2).clone()
+        assert torch.isfinite(a).all() and torch.equal(a, b), float((a - b).abs().max())
+    n = eng.num_launches()
+    print(f"[engine] kernel launches per forward (fuser off): {n}; engine pool {eng.pool_bytes() / 2**20:.0f} MiB")
+    del eng, ref
+    torch.cuda.empty_cache()
+
+
+def test_plms_step_composite_equals_separate_calls():
+    """gl_plms_step == gl_unet_forward + gl_cfg_combine + gl_plms_update issued one by one, bitwise"""
+    eng, _ = engines(TINY)
+    B, hw = 2, 16
+    inp = {k: T(v) for k, v in recipe.synth_inputs(TINY, B, hw, n_boxes=4, n_rel=3, seed=21).items()}
+    z = torch.zeros_like
+    cat = lambda p, q: torch.cat([p, q], 0)
+    eng.set_conditioning(cat(inp["context"], inp["uc"]), cat(inp["relations"], inp["relations"]), cat(inp["boxes"], z(inp["boxes"])),
+                         cat(inp["masks"], z(inp["masks"])), cat(inp["positive_embeddings"], z(inp["positive_embeddings"])), hw)
+    x = inp["x"].to(DEV).contiguous()
+    old = [torch.randn_like(x) for _ in range(3)]
+    sched = host.make_schedule(50, host.alphas_cumprod())
+    sq_at, s1m, sq_ap, dirc = host.step_coefs(sched, 30)
+    coefs, div = host.PLMS_COEFS[3]
+    e_out, x_out = torch.empty_like(x), torch.empty_like(x)
+    eng.plms_step(x, x, x_out, e_out, [e_out] + old, coefs, div, 601.0, 2, 7.5, 1.0, False, sq_at, s1m, sq_ap, dirc)
+    eps = eng.forward(x, 601.0, 1.0, False, 2).clone()
+    e2 = ops.cfg_combine(eps, 7.5, torch.empty_like(x))
+    x2 = ops.plms_update(x, e2, old, coefs, div, sq_at, s1m, sq_ap, dirc, torch.empty_like(x))
+    assert torch.equal(e_out, e2) and torch.equal(x_out, x2)
+    # in-place form the sampler uses (x_out aliases x_base / x_eval)
+    xa = x.clone()
+    eng.plms_step(xa, xa, xa, e_out, [e_out] + old, coefs, div, 601.0, 2, 7.5, 1.0, False, sq_at, s1m, sq_ap, dirc)
+    assert torch.equal(xa, x2)

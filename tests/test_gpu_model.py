@@ -1,11 +1,11 @@
 """Whole-path parity on a real MI355X: HIP engine vs (a) golden vectors produced by the reference
 itself and (b) the pinned oracle evaluated live on the host CPU with the same recipe weights.
 
-The engine stores activations in fp16 (fp32 accumulate / statistics) while the reference is fp32-only
-(SURVEY 0-6), so whole-model comparisons use a relative-L2 bound instead of north_star's elementwise
-rtol=1e-3/atol=1e-4, which one fp16 transformer block already exceeds (hard part 3:
-reference block in .half() vs fp32 measures rel-L2 3.6e-4, max|d| 2.4e-3).  Bounds below are ~3x the
-measured values; elementwise max error is printed for the record.
+The engine feeds fp16 operands to the matrix cores (fp32 accumulate / statistics / residual stream) while the
+reference is fp32-only.  tools/precision_sim.py shows that ANY implementation with fp16 matrix operands
+sits at rel-L2 ~1.1e-3 on this network (operand rounding alone; 43 % of the elements then miss north_star's
+elementwise rtol=1e-3 / atol=1e-4), so whole-model comparisons use a relative-L2 bound: every bound below is <= 1.5x
+the value measured on MI355X in round 2 (quoted next to it); elementwise max error is printed for the record.
 """
 import os
 import sys
@@ -90,31 +90,7 @@ def test_tiny_unet_matches_reference_golden(name):
     out = model(d)
     ref = T(np.load(os.path.join(GOLD, name + ".npz"))["out"])
     r = report(name, out, ref)
-    assert r < 6e-3, r
-
-
-def test_graph_replay_equals_eager():
-    model, _ = get_model(TINY)
-    inp = cond_inputs(TINY, 2, 16)
-    eng = model.engine
-    eng.set_conditioning(inp["context"], inp["relations"], inp["boxes"], inp["masks"], inp["positive_embeddings"], 16)
-    x = inp["x"].to(DEV)
-    eng.use_graphs = False
-    a = eng.forward(x, 500.0, 1.0, False, 1).clone()
-    eng.use_graphs = True
-    b = eng.forward(x, 500.0, 1.0, False, 1).clone()
-    c = eng.forward(x, 500.0, 1.0, False, 1).clone()
-    assert torch.equal(a, b) and torch.equal(b, c), "graph replay must be bit-identical to eager launches"
-    # scale-0 skip is an exact identity of the fuser: compare against gates forced to 0 with the fuser executed
-    e0 = eng.forward(x, 500.0, 0.0, False, 1).clone()
-    eng.use_graphs = False
-    eng._fuser_scale = None
-    eng.set_fuser_scale(0.0)
-    eng._launch_forward(eng.buf("in.xlat", tuple(x.shape), torch.float32), eng.buf("in.t", (2,), torch.float32), 1, True, False,
-                        eng.buf("out.eps2", (2, 4, 16, 16), torch.float32))
-    e0_exec = eng.buf("out.eps2", (2, 4, 16, 16), torch.float32)
-    eng.use_graphs = True
-    assert torch.equal(e0, e0_exec), "skipping the fuser at scale 0 must equal executing it with zero gates"
+    assert r < 2.6e-3, r            # measured 1.67e-3 .. 1.77e-3 (fp32 reference weights: includes fp16 weight rounding)
 
 
 def test_cfg_batched_2b_equals_two_calls():
@@ -150,7 +126,7 @@ def test_plms_tiny_matches_reference_golden():
     ref = T(np.load(os.path.join(GOLD, "plms_tiny.npz"))["out"])
     # 22 chained fp16 UNet evaluations with CFG 7.5 on a random-weight (non-contractive) denoiser
     r = report("plms_tiny", out, ref)
-    assert r < 5e-2, r
+    assert r < 4.3e-3, r            # measured 2.89e-3
 
 
 def test_sampler_loop_equals_oracle_loop_given_engine_eps():
@@ -204,7 +180,7 @@ def test_full_width_level_vs_oracle(name, cfg, hw, B):
         ref = unet_ref.unet_forward(oracle_sd(sd), cfg, inp["x"].half().float(), t, inp["context"].half().float(),
                                     inp["relations"].half().float(), inp["boxes"], inp["masks"], inp["positive_embeddings"])
     r = report(name, out, ref)
-    assert r < 6e-3, r
+    assert r < 1.3e-3, r            # measured 7.9e-4 .. 8.5e-4
     del model
     torch.cuda.empty_cache()
 
@@ -236,8 +212,8 @@ def test_full_unet_config2_vs_oracle():
                                       inp["positive_embeddings"])
     r_h = report("full_unet_fp16_rounded_weights", out, ref_h)
     r_f = report("full_unet_fp32_weights", out, ref_f)
-    assert r_h < 5e-3, r_h          # measured 1.68e-3
-    assert r_f < 6e-3, r_f          # measured 1.98e-3
+    assert r_h < 1.7e-3, r_h        # measured 1.13e-3 (round 1, fp16 residual stream: 1.68e-3)
+    assert r_f < 2.3e-3, r_f        # measured 1.56e-3 (round 1: 1.98e-3)
     # size-independent properties at the full size:
     # (1) graph replay is deterministic (fixed reduction orders everywhere)
     out2 = eng.forward(inp["x"].to(DEV), 481.0, 1.0, False, 1).clone()
@@ -298,7 +274,7 @@ def test_full_size_plms_5step_cfg_vs_oracle():
         return e_u + guidance * (e_c - e_u)
     ref = plms_ref.plms_sample(eps_fn, inp["x"], S, alpha_type)
     r = report("full_size_plms_5step", out, ref)
-    assert r < 1e-2, r              # measured 2.6e-3
+    assert r < 2.6e-3, r            # measured 1.73e-3 (round 1: 2.6e-3)
     del model
     torch.cuda.empty_cache()
 
@@ -320,7 +296,7 @@ def test_config3_768px_level_vs_oracle():
         ref = unet_ref.unet_forward(oracle_sd(sd), cfg, inp["x"].half().float(), t, inp["context"].half().float(),
                                     inp["relations"].half().float(), inp["boxes"], inp["masks"], inp["positive_embeddings"])
     r = report("L0_c320_d40_96x96", out, ref)
-    assert r < 6e-3, r
+    assert r < 1.3e-3, r            # measured 8.4e-4
     del model
     torch.cuda.empty_cache()
 
@@ -341,7 +317,7 @@ def test_tiny_unet_max_boxes_max_relations_vs_oracle():
                                     inp["relations"].half().float(), inp["boxes"], inp["masks"], inp["positive_embeddings"])
     r = report("tiny_30boxes_10relations", out, ref)
     assert float(inp["masks"].sum()) == 90.0
-    assert r < 6e-3, r
+    assert r < 2.0e-3, r            # measured 1.33e-3
 
 
 def test_bench_two_ranks_on_one_gpu_gloo():

@@ -30,7 +30,7 @@ def _ensure_built():
 def test_library_exports_every_declared_symbol():
     _ensure_built()
     hdr = open(os.path.join(ROOT, "include", "gligen_hip.h")).read()
-    declared = set(re.findall(r"\bint\s+(gl_[a-z0-9_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(?:int|int64_t)\s+(gl_[a-z0-9_]+)\s*\(", hdr))
     assert len(declared) >= 19, declared
     l = _lib.lib()                      # also checks ABI version + struct sizes
     for name in declared:
@@ -40,6 +40,48 @@ def test_library_exports_every_declared_symbol():
     assert l.gl_sizeof_gemm_args() == ctypes.sizeof(_lib.GemmArgs)
     assert l.gl_sizeof_conv_args() == ctypes.sizeof(_lib.ConvArgs)
     assert l.gl_sizeof_attn_args() == ctypes.sizeof(_lib.AttnArgs)
+    assert l.gl_sizeof_unet_config() == ctypes.sizeof(_lib.UNetConfigC)
+    assert l.gl_sizeof_weight_info() == ctypes.sizeof(_lib.WeightInfo)
+    assert l.gl_sizeof_plms_step_args() == ctypes.sizeof(_lib.PlmsStepArgs)
+
+
+def test_engine_handle_plan_and_weight_table_without_a_gpu():
+    """gl_create builds the block plan and the packed-weight table on the host: the table must name exactly the tensors
+    the Python packer produces (same shapes / dtypes), in 256-byte aligned non-overlapping slots, for the real config,
+    the tiny one and a one-level variant; bad configs are rejected; compute entry points refuse an unloaded handle."""
+    _ensure_built()
+    l = _lib.lib()
+    for cfg in (UNetConfig(), TINY, UNetConfig(image_size=32, model_channels=640, channel_mult=(1,), attention_resolutions=(1,), num_res_blocks=1)):
+        h = _lib.create_engine(cfg)
+        table, total = _lib.weight_table(h)
+        names = [t[0] for t in table]
+        assert len(set(names)) == len(names)
+        end = 0
+        for name, off, nbytes, dtype, shape in table:
+            assert off % 256 == 0 and off >= end
+            n = int(np.prod(shape))
+            assert nbytes == n * (2 if dtype == 0 else 4)
+            end = off + nbytes
+        assert total >= end and total % 256 == 0
+        if cfg is TINY:
+            P = pack_state_dict(recipe.state_dict(TINY, 0), TINY, "cpu", recipe.sd_first_conv(TINY, 0))
+            assert set(P.w) == set(names) and P.flat.numel() == total
+            for name, off, nbytes, dtype, shape in table:
+                assert tuple(P.w[name].shape) == tuple(shape)
+                assert P.w[name].data_ptr() == P.flat.data_ptr() + off          # views into the flat buffer
+        if cfg == UNetConfig():
+            assert 2.4e9 < total < 2.7e9 and len(names) == 1102
+        # nothing loaded / no conditioning: the compute entry points must refuse, not crash
+        assert l.gl_unet_forward(h, None, None, 0.0, 1, 1.0, 0, None, 1, None) == -1
+        assert l.gl_set_conditioning(h, None, None, None, None, None, 1, 77, 10, 16, None) == -1
+        assert l.gl_destroy(h) == 0
+    bad = _lib.unet_config_c(TINY)
+    bad.model_channels = 48
+    hh = ctypes.c_void_p()
+    assert l.gl_create(ctypes.byref(bad), ctypes.byref(hh)) == -2
+    bad = _lib.unet_config_c(TINY)
+    bad.n_levels = 9
+    assert l.gl_create(ctypes.byref(bad), ctypes.byref(hh)) == -1
 
 
 def test_bad_arguments_are_rejected_without_a_gpu():
