@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GL_ABI_VERSION 3
+#define GL_ABI_VERSION 4
 
 /* error codes (negative; positive values are hipError_t) */
 #define GL_ERR_BAD_ARG (-1)
@@ -76,6 +76,10 @@ typedef struct gl_gemm_args {
     void* workspace;    int64_t workspace_bytes;
     int32_t res_f32;                    /* != 0: res is fp32 [M, ldres] (residual stream), else fp16 */
     void* out2;         int32_t ldc2;   /* optional fp16 copy [M, N] of a GL_OUT_F32_ROWMAJOR output; NULL = none */
+    /* optional transposed tail (fused QKV projection, attention.py:160-162): columns [vt_col0, N) are NOT written to
+     * out but as gl_attention's V^T operand, vt[((b * vt_H + h) * vt_d + c) * vt_ld + key] with b = m / vt_rows,
+     * key = m % vt_rows, (h, c) = divmod(n - vt_col0, vt_d).  fp16 row-major out, epi BIAS only, vt_col0 % 64 == 0. */
+    void* vt;           int32_t vt_col0, vt_rows, vt_d, vt_ld, vt_H;
 } gl_gemm_args;
 
 /*
@@ -99,8 +103,8 @@ typedef struct gl_conv_args {
  * gl_attention: out[b, q, h*d : (h+1)*d] = softmax_k(scale * Q.K^T) . V   (flash-style, no S x S tensor).
  * Replaces SelfAttention.forward attention.py:164-176 and CrossAttention.forward :128-141 (mask=None).
  * Q [B, Nq, *] fp16 rows of stride ldq, head h at column offset h*d; K likewise (ldk).
- * V is passed TRANSPOSED per head: vt[((b*H + h)*d + c) * ldvt + key], ldvt % 8 == 0, keys >= Nk
- * zero-filled up to the next multiple of 64 (see gl_transpose_v).  d in {8..160}, d % 8 == 0.
+ * V is passed TRANSPOSED per head: vt[((b*H + h)*d + c) * ldvt + key], ldvt % 8 == 0 and >= Nk rounded up to 64 (the
+ * pad keys are never used: the kernel masks them, so their contents are arbitrary).  d in {8..160}, d % 8 == 0.
  * Batch strides are in elements.
  */
 typedef struct gl_attn_args {
@@ -288,7 +292,8 @@ int gl_sizeof_attn_args(void);
  * 3 always 8 waves, 4 always 4 waves); keys 4-7 = small-tile / split-K / 256-row-tile thresholds; key 8 = short-K GEGLU
  * GEMMs on the BK 32 / 4-blocks-per-CU variant (1 default, 0 off); key 10 = s_setprio around the attention MFMA
  * clusters (-1 auto, 0 off, 1 on); key 13 = intra-block K-split GEMM/conv variants (0 off, 1 auto = default, 2 always);
- * key 16 = GroupNorm apply pixels per block; key 20 = (tests) execute the gated-SA fuser even at fuser_scale 0. */
+ * key 16 = GroupNorm apply pixels per block; key 20 = (tests) execute the gated-SA fuser even at fuser_scale 0;
+ * key 21 = V^T written by the QKV GEMM epilogue (1, default) or by gl_transpose_v (0). */
 int gl_set_option(int key, int value);
 /* one-time per-process setup (raises dynamic-LDS limits of the tiled kernels); idempotent */
 int gl_init(void);

@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgligen_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # enum gl_epilogue / gl_out_mode
 EPI_BIAS, EPI_SILU, EPI_GEGLU, EPI_RES, EPI_GATE_RES, EPI_ROWBIAS = range(6)
@@ -41,6 +41,7 @@ class GemmArgs(C.Structure):
         ("workspace", vp), ("workspace_bytes", i64),
         ("res_f32", i32),
         ("out2", vp), ("ldc2", i32),
+        ("vt", vp), ("vt_col0", i32), ("vt_rows", i32), ("vt_d", i32), ("vt_ld", i32), ("vt_H", i32),
     ]
 
 

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(gl_attn_args p, int flags
     // tile-invariant staging coordinates (no per-tile divisions / 64-bit address rebuilds)
     const half_t* kptr[K_PER_T];
     const half_t* vptr[V_PER_T];
-    int krow[K_PER_T], klds[K_PER_T], vlds[V_PER_T];
+    int krow[K_PER_T], klds[K_PER_T], vlds[V_PER_T], vkey[V_PER_T];
     bool kok[K_PER_T], vok[V_PER_T], vone[V_PER_T];
 #pragma unroll
     for (int i = 0; i < K_PER_T; ++i) {
@@ -133,6 +133,7 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(gl_attn_args p, int flags
         const int idx = tid + NTHR * i;
         const int row = idx >> 3;      // head-dim column
         const int c = idx & 7;         // 8-key chunk
+        vkey[i] = c * 8;
         vok[i] = (idx < V_ITEMS) && (row < d);
         vone[i] = ONES && (idx < V_ITEMS) && (row == OC);
         // LDS image of a V^T row: per 16-key group [keys 0-3, 8-11 | keys 4-7, 12-15], i.e. the 8 keys a lane
@@ -154,7 +155,22 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(gl_attn_args p, int flags
         for (int i = 0; i < V_PER_T; ++i) {
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
             if (vone[i]) v = make_uint4(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u);   // fp16 1.0 x 8
-            if (vok[i]) v = ld16(vptr[i]);
+            if (vok[i]) {
+                v = ld16(vptr[i]);
+                // keys >= Nk of the last tile: P is 0 there, but 0 * (stale NaN / Inf) would poison O, so the V^T pad
+                // is masked here and its contents never matter (the producer does not have to zero-fill it)
+                const int kfirst = key0 + vkey[i];
+                if (kfirst + 8 > Nk) {
+                    const int keep = Nk - kfirst;            // valid keys in this 8-key chunk (<= 7, possibly <= 0)
+                    unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (2 * q >= keep) w[q] = 0u;
+                        else if (2 * q + 1 >= keep) w[q] &= 0xFFFFu;
+                    }
+                    v = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+            }
             vptr[i] += KT;
             rv[i] = v;
         }

@@ -21,11 +21,14 @@
 #include <unordered_map>
 #include <vector>
 
+extern int g_gl_option_epoch;      // misc.hip: bumped by every gl_set_option call
+
 namespace {
 
 constexpr int CIN_PAD = 64;              // the 4-channel latent is zero-padded to one 64-channel K block
 constexpr int64_t ALIGN = 256;
 constexpr int64_t WS_BYTES = 96ll << 20; // split-K fp32 partial tiles
+int g_fuse_vt = 1;                       // A/B knob (gl_set_option 21): V^T written by the QKV GEMM epilogue (1) or by gl_transpose_v (0)
 int g_force_fuser = 0;                   // test knob (gl_set_option 20): execute the fuser even at scale 0 (zero gates)
 
 enum Kind { CONV_IN = 0, RES = 1, ST = 2, DOWN = 3, UP = 4 };
@@ -126,6 +129,7 @@ struct gl_engine {
     float fuser_scale_cur = -1e30f;
     std::vector<float> gate_host;      // the [n_st][4] array last uploaded (kept alive for the async copy)
     int launches = 0;
+    int opt_epoch = 0;                 // gl_set_option generation the captured graphs were built under
     std::string err;
     hipStream_t cap_stream = nullptr;  // graphs are captured on an engine-owned stream (the caller's may be the legacy
                                        // default stream, which cannot be captured) and launched on the caller's
@@ -365,6 +369,19 @@ struct Run {
         ++launches;
         return gl_gemm(&g, st);
     }
+    int gemm_vt(const void* a, int lda, const std::string& w, int M, void* out, int ldc, void* vt, int vt_col0, int vt_rows, int vt_d, int vt_ld,
+                int vt_H) {
+        const WInfo* wi = e->wi(w);
+        if (!wi) return GL_ERR_BAD_ARG;
+        gl_gemm_args g{};
+        g.a = a; g.lda = lda; g.w = e->W(w);
+        g.M = M; g.N = (int)wi->shape[0]; g.K = (int)wi->shape[1];
+        g.epi = GL_EPI_BIAS; g.out_mode = GL_OUT_F16_ROWMAJOR; g.out = out; g.ldc = ldc;
+        g.vt = vt; g.vt_col0 = vt_col0; g.vt_rows = vt_rows; g.vt_d = vt_d; g.vt_ld = vt_ld; g.vt_H = vt_H;
+        g.workspace = ws; g.workspace_bytes = WS_BYTES;
+        ++launches;
+        return gl_gemm(&g, st);
+    }
     int conv(const void* in, const std::string& w, const std::string& bias, int B, int Hin, int Win, int Cin, int stride, int ups,
              void* out, int out_mode, int epi = GL_EPI_BIAS, const void* res = nullptr, int ldres = 0, int res_f32 = 0,
              const void* rowbias = nullptr, int ld_rowbias = 0, int rows_per_sample = 0, void* out2 = nullptr, int nchw_hw = 0) {
@@ -445,8 +462,15 @@ int self_attention(Run& r, const half_t* src, int rows_per_b, int Nq, int Nk, in
     half_t* vt = e->h16(tag + ".vt", (size_t)Bn * H * d * ldvt);
     half_t* att = e->h16(tag + ".att", (size_t)Bn * Nq * C);
     CKP(qkv); CKP(vt); CKP(att);
-    CK(r.gemm(src, C, wp + ".qkv.w", Bn * rows_per_b, qkv, 3 * C));
-    CK(r.transpose_v(qkv + 2 * C, (int64_t)rows_per_b * 3 * C, 3 * C, vt, ldvt, Bn, H, d, Nk));
+    // fused QKV projection; its V third is written directly as the attention kernel's V^T operand by the GEMM epilogue
+    // when the V columns start on an epilogue pass of every tile shape (true for all widths of this UNet), else by the
+    // separate transpose kernel
+    if (g_fuse_vt && (C % 32) == 0 && rows_per_b == Nk) {
+        CK(r.gemm_vt(src, C, wp + ".qkv.w", Bn * rows_per_b, qkv, 3 * C, vt, 2 * C, rows_per_b, d, ldvt, H));
+    } else {
+        CK(r.gemm(src, C, wp + ".qkv.w", Bn * rows_per_b, qkv, 3 * C));
+        CK(r.transpose_v(qkv + 2 * C, (int64_t)rows_per_b * 3 * C, 3 * C, vt, ldvt, Bn, H, d, Nk));
+    }
     CK(r.attn(qkv, (int64_t)rows_per_b * 3 * C, 3 * C, qkv + C, (int64_t)rows_per_b * 3 * C, 3 * C, vt, ldvt, att, (int64_t)Nq * C, C, Bn, H, d,
               Nq, Nk));
     *out = att;
@@ -862,6 +886,10 @@ extern "C" int gl_unet_forward(gl_engine* e, const float* x, const float* t_dev,
     }
     CK(set_fuser_scale(e, fuser_scale, st));
     const bool fuser_on = fuser_scale != 0.0f || g_force_fuser != 0;
+    if (e->opt_epoch != g_gl_option_epoch) {       // a tuning knob changed: the captured launch sequences may be stale
+        e->drop_graphs();
+        e->opt_epoch = g_gl_option_epoch;
+    }
     const auto key = std::make_tuple(Bn, side, e->R, e->Lc, (int)fuser_on, (int)(sd_conv != 0), (int)reps);
     auto it = e->graphs.find(key);
     if (use_graph && it == e->graphs.end()) {
@@ -923,6 +951,7 @@ extern "C" int gl_plms_step(gl_engine* e, const gl_plms_step_args* a, void* stre
 
 extern "C" int gl_set_option_engine(int key, int value) {
     if (key == 20) { g_force_fuser = value; return 0; }
+    if (key == 21) { g_fuse_vt = value; return 0; }
     return GL_ERR_BAD_ARG;
 }
 

@@ -471,6 +471,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
     // straight from the MFMA register layout.  For GEGLU a pass is exactly one [x(32) | gate(32)] pair.
     constexpr int EPS = 64 + 4;                            // padded fp32 row stride (conflict-free float4 writes)
     constexpr int NPASS = (TN + 1) / 2;
+    constexpr bool VT_OK = !(BM == 256 && BN == 160);      // that tile sits at the 256-register cap: no V^T tail there
     float* stage = reinterpret_cast<float*>(smem) + wave * (32 * EPS);
     half_t* outp = reinterpret_cast<half_t*>(p.out);
     const bool geglu = (epi == GL_EPI_GEGLU);
@@ -498,7 +499,43 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const int nbase = n0 + wn * (TN * 32) + np * 64;   // first (packed) column of this pass
-            if (geglu) {
+            if (VT_OK && p.vt != nullptr && nbase >= p.vt_col0) {
+                // V^T tail of a fused QKV projection: lane = one channel column of the pass, 8 consecutive tokens per store
+                // (read down the staged tile: consecutive lanes hit consecutive banks), so V never exists row-major
+                const int ncols = (np * 2 + 1 < TN) ? 64 : 32;
+                const int n = nbase + lane;
+                if (lane < ncols && n < N) {
+                    const int nv = n - p.vt_col0;
+                    const int hh = nv / p.vt_d;
+                    const int cc = nv - hh * p.vt_d;
+                    const float bv = bias ? bias[n] : 0.0f;
+                    half_t* vtp = reinterpret_cast<half_t*>(p.vt);
+#pragma unroll
+                    for (int tg = 0; tg < 4; ++tg) {
+                        const int m = mbase + tg * 8;
+                        if (m >= M) continue;
+                        half8_t o;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) o[k] = (half_t)(stage[(tg * 8 + k) * EPS + lane] + bv);
+                        if ((p.vt_rows & 7) == 0) {
+                            const int b = m / p.vt_rows;
+                            const int key = m - b * p.vt_rows;
+                            st16(vtp + ((size_t)(b * p.vt_H + hh) * p.vt_d + cc) * p.vt_ld + key, *reinterpret_cast<uint4*>(&o));
+                        } else {
+                            // ragged rows per sample (the fuser's N + 30 keys): 8 tokens may straddle two samples
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) {
+                                const int mm = m + k;
+                                if (mm < M) {
+                                    const int b = mm / p.vt_rows;
+                                    const int key = mm - b * p.vt_rows;
+                                    vtp[((size_t)(b * p.vt_H + hh) * p.vt_d + cc) * p.vt_ld + key] = o[k];
+                                }
+                            }
+                        }
+                    }
+                }
+            } else if (geglu) {
                 // 32 output columns per pass, 8 per lane: 4 lanes per row, 16 rows per sweep
 #pragma unroll
                 for (int ps = 0; ps < 2; ++ps) {
@@ -585,7 +622,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(gl_gemm_args p, int 
 // the fp32 partial round trip.
 inline int choose_splitk(const gl_gemm_args& g, int tiles, bool conv) {
     const int nk = g.K / 64;
-    if (!g.workspace || g.epi == GL_EPI_GEGLU || g.out_mode == GL_OUT_F32_NCHW) return 1;
+    if (!g.workspace || g.epi == GL_EPI_GEGLU || g.out_mode == GL_OUT_F32_NCHW || g.vt != nullptr) return 1;
     // convs (long K, weights streamed once per row tile) profit up to ~1.7 tiles per CU: the 32x32-level
     // convs launch exactly 256 tiles and went 604 -> 694 TF/s with 2 K-slices; plain GEMMs only below ~300
     if (tiles >= (conv ? g_opt_splitk_tiles_conv : g_opt_splitk_tiles) || nk < g_opt_splitk_nk) return 1;
@@ -599,6 +636,7 @@ inline int choose_splitk(const gl_gemm_args& g, int tiles, bool conv) {
 template <int BM, int BN, int WM, int WN, bool CONV, int BKT, int WK = 1>
 int launch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     if (g.a2 != nullptr && (g.ksplit % BKT) != 0) return GL_ERR_BAD_ARG;    // the two-source crossover happens on a K-tile edge
+    if (g.vt != nullptr && ((g.vt_col0 % BN) % 64) != 0) return GL_ERR_UNSUPPORTED;   // the V^T tail must start on an epilogue pass
     const int mt = gl_cdiv(g.M, BM), nt = gl_cdiv(g.N, BN);
     const int nk = g.K / BKT;
     int splitk = choose_splitk(g, mt * nt, CONV);
@@ -654,7 +692,7 @@ int dispatch_shape(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
             }
         }
         // 256-row tiles (4 waves x 64-row wave tiles, BK 32) once the problem has >= g_opt_big of them
-        if (g_opt_big && shape != 2 && shape != 3 && g.M >= 256) {
+        if (g_opt_big && shape != 2 && shape != 3 && g.M >= 256 && !(shape == 1 && g.vt != nullptr)) {
             const int bn = (shape == 1) ? 160 : 128;
             const long t256 = (long)gl_cdiv(g.M, 256) * gl_cdiv(g.N, bn);
             if (t256 >= g_opt_big) {
@@ -673,12 +711,9 @@ int dispatch_shape(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
         if (shape == 0) return launch<128, 128, 2, 2, CONV, 64>(g, cg, st);
         return launch<256, 64, 4, 1, CONV, 64>(g, cg, st);
     } else {
-        // BK 32 (plain GEMMs only): 128x128 / 64x128 at 4 blocks per CU, 256x128 once there are enough tiles
+        // BK 32 (short-K GEGLU projections only): 128x128 / 64x128 at 4 blocks per CU, so that one block's erf epilogue
+        // overlaps the other blocks' main loops (256-row tiles measured 13 % slower here: 181 vs 157 ms over the trace)
         static_assert(!CONV, "BK 32 dispatch is for plain GEMMs");
-        if (g_opt_big && shape == 0 && g.M >= 256) {
-            const long t256 = (long)gl_cdiv(g.M, 256) * gl_cdiv(g.N, 128);
-            if (t256 >= g_opt_big) return launch<256, 128, 4, 1, false, 32>(g, cg, st);
-        }
         if (shape == 3) return launch<64, 128, 2, 2, false, 32>(g, cg, st);
         return launch<128, 128, 2, 2, false, 32>(g, cg, st);
     }
@@ -698,6 +733,10 @@ int dispatch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     if ((g.epi == GL_EPI_RES || g.epi == GL_EPI_GATE_RES) && g.res == nullptr) return GL_ERR_BAD_ARG;
     if (g.epi == GL_EPI_GATE_RES && g.gate == nullptr) return GL_ERR_BAD_ARG;
     if (g.epi == GL_EPI_ROWBIAS && (g.rowbias == nullptr || g.rows_per_sample <= 0)) return GL_ERR_BAD_ARG;
+    if (g.vt != nullptr && (g.epi != GL_EPI_BIAS || g.out_mode != GL_OUT_F16_ROWMAJOR || (g.vt_col0 % 64) != 0 || g.vt_col0 <= 0 ||
+                            g.vt_col0 >= g.N || g.vt_rows <= 0 || g.vt_d <= 0 || ((g.N - g.vt_col0) % g.vt_d) != 0 || (g.vt_ld % 8) != 0 ||
+                            g.vt_ld < g.vt_rows || g.vt_H * g.vt_d != g.N - g.vt_col0))
+        return GL_ERR_BAD_ARG;
     // GEGLU with a short K (levels 0/1: K = 320/640, 5-10 k-tiles) spends a large share of each block in its
     // erf epilogue; BK 32 / 2-stage needs 35 KiB of LDS and 114 registers, so 4 blocks/CU are resident and
     // one block's epilogue overlaps the others' main loops (measured 150 -> 135 us and 109 -> 100 us; long-K

@@ -110,8 +110,11 @@ def _fill_epilogue(g: GemmArgs, epi, out, N_out, bias, res, gate, rowbias, rows_
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias=None, epi: int = EPI_BIAS, res=None, gate=None,
-         rowbias=None, rows_per_sample: int = 0, a2: Optional[torch.Tensor] = None, nchw_hw: int = 0, out16=None) -> torch.Tensor:
-    """out = [a | a2] @ w.T (+ epilogue).  a [M, K1], a2 [M, K2] (optional), w [N, K1+K2] fp16."""
+         rowbias=None, rows_per_sample: int = 0, a2: Optional[torch.Tensor] = None, nchw_hw: int = 0, out16=None,
+         vt: Optional[torch.Tensor] = None, vt_col0: int = 0, vt_rows: int = 0) -> torch.Tensor:
+    """out = [a | a2] @ w.T (+ epilogue).  a [M, K1], a2 [M, K2] (optional), w [N, K1+K2] fp16.
+    ``vt`` [B, H, d, ldvt] fp16: columns [vt_col0, N) are written there as gl_attention's V^T operand (row m = sample
+    m // vt_rows, key m % vt_rows) instead of to ``out`` (fused QKV projection)."""
     _req(a, F16, "a")
     _req(w, F16, "w")
     M, K1, lda = _rows(a, "a")
@@ -131,6 +134,12 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias=None, epi: in
     g.w = w.data_ptr()
     g.M, g.N, g.K = M, N, K
     _fill_epilogue(g, epi, out, N // 2 if epi == EPI_GEGLU else N, bias, res, gate, rowbias, rows_per_sample, nchw_hw, out16)
+    if vt is not None:
+        _req(vt, F16, "vt")
+        if vt.dim() != 4 or not vt.is_contiguous():
+            raise ValueError("vt must be a contiguous [B, H, d, ldvt] tensor")
+        g.vt, g.vt_col0, g.vt_rows = vt.data_ptr(), vt_col0, vt_rows
+        g.vt_H, g.vt_d, g.vt_ld = vt.shape[1], vt.shape[2], vt.shape[3]
     check(_lib.lib().gl_gemm(C.byref(g), _stream()), "gl_gemm")
     return out
 

@@ -155,8 +155,9 @@ class PyRefEngine:
             return
         for l in self.st_layers:
             f = l.prefix + ".transformer_blocks.0.fuser"
-            self._gates[f + ".tanh_attn"].fill_(scale * self.S[f + ".tanh_attn"])
-            self._gates[f + ".tanh_dense"].fill_(scale * self.S[f + ".tanh_dense"])
+            # fp32 product, like the reference's `scale * torch.tanh(alpha)` (python scalar x fp32 tensor) and like engine.hip
+            self._gates[f + ".tanh_attn"].fill_(float(np.float32(scale) * np.float32(self.S[f + ".tanh_attn"])))
+            self._gates[f + ".tanh_dense"].fill_(float(np.float32(scale) * np.float32(self.S[f + ".tanh_dense"])))
         self._fuser_scale = scale
 
     # ------------------------------------------------------------------ layers

@@ -208,6 +208,36 @@ def test_gemm_residual_stream_fp32(M, N, K):
     assert torch.equal(o16.cpu(), o32b.cpu().half())
 
 
+@pytest.mark.parametrize("B,rows,C,H", [(2, 256, 320, 8), (1, 1054, 640, 8), (2, 286, 64, 4), (3, 64, 1280, 8), (1, 4126, 320, 8)])
+def test_gemm_qkv_writes_v_transposed(B, rows, C, H):
+    """fused QKV projection whose V third goes straight to gl_attention's V^T layout from the GEMM epilogue: must be the
+    exact transpose of what the plain GEMM writes row-major (same fp16 values), for 8-aligned and ragged (N + 30) rows
+    per sample, every tile shape the dispatcher picks, and the attention on top must ignore the never-written pad keys."""
+    d = C // H
+    M = B * rows
+    a, ad = h16(rnd(f"vta{M}{C}", (M, C)))
+    w, wd = h16(rnd(f"vtw{C}", (3 * C, C), 1 / math.sqrt(C)))
+    plain = torch.empty(M, 3 * C, dtype=torch.float16, device=DEV)
+    ops.gemm(ad, wd, plain)
+    fused = torch.full((M, 3 * C), float("nan"), dtype=torch.float16, device=DEV)
+    vt = torch.full((B, H, d, ops.vt_ld(rows)), float("nan"), dtype=torch.float16, device=DEV)     # NaN pads on purpose
+    ops.gemm(ad, wd, fused, vt=vt, vt_col0=2 * C, vt_rows=rows)
+    assert torch.equal(fused[:, :2 * C], plain[:, :2 * C]), "Q and K columns are untouched"
+    assert torch.isnan(fused[:, 2 * C:]).all(), "the V columns must not be written row-major"
+    want = plain[:, 2 * C:].view(B, rows, H, d).permute(0, 2, 3, 1)
+    assert torch.equal(vt[..., :rows], want), float((vt[..., :rows].float() - want.float()).abs().max())
+    assert torch.isnan(vt[..., rows:]).all()
+    # attention over it: NaN pad keys must not leak (masked in the kernel), result == attention on a zero-padded transpose
+    Nq = min(rows, 300)
+    out = torch.empty(B * Nq, C, dtype=torch.float16, device=DEV)
+    ops.attention(fused, rows * 3 * C, 3 * C, fused[:, C:], rows * 3 * C, 3 * C, vt, out, Nq * C, C, B, H, d, Nq, rows, d ** -0.5)
+    vt0 = torch.zeros_like(vt)
+    ops.transpose_v(plain[:, 2 * C:], rows * 3 * C, 3 * C, vt0, B, H, d, rows)
+    out0 = torch.empty_like(out)
+    ops.attention(plain, rows * 3 * C, 3 * C, plain[:, C:], rows * 3 * C, 3 * C, vt0, out0, Nq * C, C, B, H, d, Nq, rows, d ** -0.5)
+    assert torch.isfinite(out).all() and torch.equal(out, out0)
+
+
 def test_gemm_two_source():
     M, K1, K2, N = 260, 128, 192, 256
     a1, a1d = h16(rnd("ta1", (M, K1)))
