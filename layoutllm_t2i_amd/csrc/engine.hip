@@ -458,14 +458,14 @@ int self_attention(Run& r, const half_t* src, int rows_per_b, int Nq, int Nk, in
     gl_engine* e = r.e;
     const int Bn = e->Bn, H = e->cfg.num_heads;
     half_t* qkv = e->h16(tag + ".qkv", (size_t)Bn * rows_per_b * 3 * C);
-    const int ldvt = vt_ld(Nk);
+    const int ldvt = vt_ld(Nk > rows_per_b ? Nk : rows_per_b);      // the fused V^T tail writes one column per ROW (pad rows included)
     half_t* vt = e->h16(tag + ".vt", (size_t)Bn * H * d * ldvt);
     half_t* att = e->h16(tag + ".att", (size_t)Bn * Nq * C);
     CKP(qkv); CKP(vt); CKP(att);
     // fused QKV projection; its V third is written directly as the attention kernel's V^T operand by the GEMM epilogue
     // when the V columns start on an epilogue pass of every tile shape (true for all widths of this UNet), else by the
     // separate transpose kernel
-    if (g_fuse_vt && (C % 32) == 0 && rows_per_b == Nk) {
+    if (g_fuse_vt && (C % 32) == 0) {
         CK(r.gemm_vt(src, C, wp + ".qkv.w", Bn * rows_per_b, qkv, 3 * C, vt, 2 * C, rows_per_b, d, ldvt, H));
     } else {
         CK(r.gemm(src, C, wp + ".qkv.w", Bn * rows_per_b, qkv, 3 * C));
@@ -548,11 +548,15 @@ int spatial_transformer(Run& r, const LayerD& l, int li, Stream2 xin, int side, 
     // --- gated self-attention fuser over [x ; objs] (attention.py:226-234); exact identity at scale 0
     if (fuser_on) {
         const std::string f = t + ".fuser";
-        half_t* cat = e->h16("st.cat", (size_t)Bn * (N + mo) * C);
+        // [x ; objs] rows per sample padded to a multiple of 8 so that the QKV epilogue can store V^T in 16-byte pieces; the
+        // pad rows are never normalised into (arbitrary finite-or-not contents): as keys they are masked by the attention
+        // kernel (Nk = N + mo), as queries they are not used (Nq = N)
+        const int rows = N + ((mo + 7) & ~7);
+        half_t* cat = e->h16("st.cat", (size_t)Bn * rows * C);
         CKP(cat);
-        CK(r.ln(x, C, 1, cat, C, f + ".norm1", Bn, N, N + mo, 0, C));
-        CK(r.ln(e->h16("hoist.objs." + sl, (size_t)Bn * mo * C), C, 0, cat, C, f + ".norm1", Bn, mo, N + mo, N, C));
-        CK(self_attention(r, cat, N + mo, N, N + mo, C, d, f + ".attn", "st.fa", &att));
+        CK(r.ln(x, C, 1, cat, C, f + ".norm1", Bn, N, rows, 0, C));
+        CK(r.ln(e->h16("hoist.objs." + sl, (size_t)Bn * mo * C), C, 0, cat, C, f + ".norm1", Bn, mo, rows, N, C));
+        CK(self_attention(r, cat, rows, N, N + mo, C, d, f + ".attn", "st.fa", &att));
         float* y = nxt(x);
         CK(r.gemm(att, C, f + ".attn.o.w", M, y, C, GL_OUT_F32_ROWMAJOR, f + ".attn.o.b", GL_EPI_GATE_RES, x, C, 1, gates + 0));
         x = y;

@@ -805,7 +805,7 @@ extern "C" int gl_set_option_gemm(int key, int value) {
     if (key == 7) { g_opt_big = value; return 0; }
     if (key == 8) { g_opt_geglu32 = value; return 0; }
     if (key == 13) { g_opt_ksplit = value; return 0; }
-    if (key == 5) { g_opt_splitk_tiles = value; g_opt_splitk_tiles_conv = value; return 0; }
+    if (key == 5) { g_opt_splitk_tiles = value < 0 ? 300 : value; g_opt_splitk_tiles_conv = value < 0 ? 450 : value; return 0; }   // < 0: defaults
     if (key == 6) { g_opt_splitk_nk = value; return 0; }
     return GL_ERR_BAD_ARG;
 }

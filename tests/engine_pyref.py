@@ -194,9 +194,12 @@ class PyRefEngine:
     def _self_attention(self, src, rows_per_b, Nq, Nk, C, d, wp, tagp):
         """src [Bn*rows_per_b, C] (already normalised) -> attention output [Bn*Nq, C] (before to_out)."""
         Bn, H = self.cond["Bn"], self.cfg.num_heads
-        qkv = ops.gemm(src, self.W[wp + ".qkv.w"], self.buf(tagp + ".qkv", (Bn * rows_per_b, 3 * C)))
-        vt = self.buf(tagp + ".vt", (Bn, H, d, ops.vt_ld(Nk)))
-        ops.transpose_v(qkv[:, 2 * C:], rows_per_b * 3 * C, 3 * C, vt, Bn, H, d, Nk)
+        vt = self.buf(tagp + ".vt", (Bn, H, d, ops.vt_ld(max(Nk, rows_per_b))))
+        if C % 32 == 0:      # same rule as engine.hip: V^T straight from the QKV GEMM epilogue (that form never splits K)
+            qkv = ops.gemm(src, self.W[wp + ".qkv.w"], self.buf(tagp + ".qkv", (Bn * rows_per_b, 3 * C)), vt=vt, vt_col0=2 * C, vt_rows=rows_per_b)
+        else:
+            qkv = ops.gemm(src, self.W[wp + ".qkv.w"], self.buf(tagp + ".qkv", (Bn * rows_per_b, 3 * C)))
+            ops.transpose_v(qkv[:, 2 * C:], rows_per_b * 3 * C, 3 * C, vt, Bn, H, d, Nk)
         att = self.buf(tagp + ".att", (Bn * Nq, C))
         ops.attention(qkv, rows_per_b * 3 * C, 3 * C, qkv[:, C:], rows_per_b * 3 * C, 3 * C, vt, att, Nq * C, C,
                       Bn, H, d, Nq, Nk, d ** -0.5)
@@ -230,10 +233,11 @@ class PyRefEngine:
         # --- gated self-attention fuser over [x ; objs] (attention.py:226-234); exact identity at scale 0
         if fuser_on:
             f = t + ".fuser"
-            cat = self.buf("st.cat", (Bn * (N + mo), C))
-            ops.layernorm(x, cat, W[f + ".norm1.g"], W[f + ".norm1.b"], Bn, N, N + mo, 0)
-            ops.layernorm(c[f"objs.{li}"], cat, W[f + ".norm1.g"], W[f + ".norm1.b"], Bn, mo, N + mo, N)
-            att = self._self_attention(cat, N + mo, N, N + mo, C, d, f + ".attn", "st.fa")
+            rows = N + ((mo + 7) & ~7)          # same padding as engine.hip (pad rows are masked keys / unused queries)
+            cat = self.buf("st.cat", (Bn * rows, C), zero=True)
+            ops.layernorm(x, cat, W[f + ".norm1.g"], W[f + ".norm1.b"], Bn, N, rows, 0)
+            ops.layernorm(c[f"objs.{li}"], cat, W[f + ".norm1.g"], W[f + ".norm1.b"], Bn, mo, rows, N)
+            att = self._self_attention(cat, rows, N, N + mo, C, d, f + ".attn", "st.fa")
             x = ops.gemm(att, W[f + ".attn.o.w"], nxt(x), W[f + ".attn.o.b"], EPI_GATE_RES, res=x,
                          gate=self._gates[f + ".tanh_attn"])
             n2 = ops.layernorm(x, self.buf("st.ln", (M, C)), W[f + ".norm2.g"], W[f + ".norm2.b"], Bn, N)

@@ -218,7 +218,11 @@ def test_gemm_qkv_writes_v_transposed(B, rows, C, H):
     a, ad = h16(rnd(f"vta{M}{C}", (M, C)))
     w, wd = h16(rnd(f"vtw{C}", (3 * C, C), 1 / math.sqrt(C)))
     plain = torch.empty(M, 3 * C, dtype=torch.float16, device=DEV)
-    ops.gemm(ad, wd, plain)
+    ops.set_option(5, 0)            # the fused form never splits K: compare with the unsplit plain GEMM (same fp32 summation order)
+    try:
+        ops.gemm(ad, wd, plain)
+    finally:
+        ops.set_option(5, -1)
     fused = torch.full((M, 3 * C), float("nan"), dtype=torch.float16, device=DEV)
     vt = torch.full((B, H, d, ops.vt_ld(rows)), float("nan"), dtype=torch.float16, device=DEV)     # NaN pads on purpose
     ops.gemm(ad, wd, fused, vt=vt, vt_col0=2 * C, vt_rows=rows)
