@@ -167,6 +167,21 @@ def main():
     eng.plms_step = timed_step
 
     vae_events = []
+    # configs[4] (train_rl rollout): the reward-scoring stage runs after the decode.  The CLIP towers that turn decoded
+    # images / captions into features are the caller's modules (HF CLIPModel), so the stage is fed synthetic CLIP features
+    # [B, 768] resident on the device; what is timed is this repo's part (similarities + AestheticMLP, gl_reward_score).
+    scorer, score_events, score_in = None, [], None
+    if cnum == 5 and not args.tiny:
+        from layoutllm_t2i_amd.reward import RewardScorer
+        gsc = torch.Generator(device=dev)
+        gsc.manual_seed(4242 + rank)
+        shp = {0: (1024, 768), 2: (128, 1024), 4: (64, 128), 6: (16, 64), 7: (1, 16)}
+        aes_sd = {}
+        for li, (n_, k_) in shp.items():
+            aes_sd[f"layers.{li}.weight"] = (torch.rand(n_, k_, device=dev, generator=gsc) * 2 - 1) * (3.0 / k_) ** 0.5
+            aes_sd[f"layers.{li}.bias"] = (torch.rand(n_, device=dev, generator=gsc) * 2 - 1) * 0.1
+        scorer = RewardScorer(aes_sd, dev)
+        score_in = tuple(torch.randn(B, 768, device=dev, generator=gsc) for _ in range(3))
 
     def one_step():
         model.first_conv_type = "GLIGEN"
@@ -179,6 +194,13 @@ def main():
         img = vae.decode(lat)                      # fp32 [B, 3, 512, 512], what interface.py:541 hands to the PIL loop
         e1.record()
         vae_events.append((e0, e1))
+        if scorer is not None:
+            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s0.record()
+            sc = scorer.score(*score_in)
+            s1.record()
+            score_events.append((s0, s1))
+            assert sc["reward"].shape == (B,)
         return img
 
     def sync():
@@ -191,6 +213,7 @@ def main():
         out = one_step()
     fwd_events.clear()
     vae_events.clear()
+    score_events.clear()
     sync()
     t1 = time.time()
     for _ in range(args.steps):
@@ -264,9 +287,12 @@ def main():
                    "parallelism": f"replicas x{world}, one weight broadcast, no per-step collectives"},
         "unet_step_ms": round(gpu_ms / max(n_fwd, 1), 3),
         "vae_decode_ms_per_batch": (round(sum(a.elapsed_time(b) for a, b in vae_events) / max(len(vae_events), 1), 2) if vae_events else None),
-        "step_includes": f"PLMS denoise ({args.plms_steps + 1} x gl_plms_step: 2B UNet forward + CFG + update)" + (" + VAE decode to fp32 images" if vae is not None else ""),
+        "step_includes": f"PLMS denoise ({args.plms_steps + 1} x gl_plms_step: 2B UNet forward + CFG + update)" + (" + VAE decode to fp32 images" if vae is not None else "") + (" + reward scoring (gl_reward_score)" if scorer is not None else ""),
         "launches_per_forward": eng.num_launches(),
         "images_per_sec_per_gpu": round(value / world, 4),
+        "reward_score_ms_per_batch": (round(sum(a.elapsed_time(b) for a, b in score_events) / max(len(score_events), 1), 4) if score_events else None),
+        "reward_score_note": ("similarities + AestheticMLP (gl_reward_score) on synthetic CLIP features [B, 768]; the CLIP towers and the CPU "
+                              "layout rewards (IoU / DocSim) are the caller's and not timed" if score_events else None),
         "roofline": roofline,
         "setup_s": round(setup_s, 1),
     }

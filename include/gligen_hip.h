@@ -278,6 +278,27 @@ int gl_sizeof_unet_config(void);
 int gl_sizeof_weight_info(void);
 int gl_sizeof_plms_step_args(void);
 
+/*
+ * gl_reward_score: the GPU part of Reward_Model.forward for the train_rl.py rollout (models/policy.py:106-135,
+ * tools/aesthetic.py:15-31,52-57), given CLIP features [B, D] fp32 (D = 768 for ViT-L/14) of the captions, the generated
+ * images and the ground-truth images:
+ *   sims_ti = <norm(txt), norm(pred)>, sims_ii = <norm(gt), norm(pred)>            (F.normalize, eps 1e-12)
+ *   aesthetic = AestheticMLP(normalized(norm(pred)))   five Linear layers D -> 1024 -> 128 -> 64 -> 16 -> 1, fp32 weights
+ *   partial_reward (optional) = sims_ti + sims_ii + 0.1 * aesthetic; the caller adds 10 * mIoU + 10 * DocSim (CPU python)
+ */
+typedef struct gl_reward_args {
+    const float* txt; const float* img_pred; const float* img_gt;   /* [B, D] */
+    int32_t B, D;
+    const float* w1; const float* b1;   /* [1024, D], [1024] */
+    const float* w2; const float* b2;   /* [128, 1024] */
+    const float* w3; const float* b3;   /* [64, 128]   */
+    const float* w4; const float* b4;   /* [16, 64]    */
+    const float* w5; const float* b5;   /* [1, 16], [1] */
+    float* sims_ti; float* sims_ii; float* aesthetic; float* partial_reward;   /* [B] each */
+} gl_reward_args;
+int gl_reward_score(const gl_reward_args* a, void* stream);
+int gl_sizeof_reward_args(void);
+
 int gl_gemm(const gl_gemm_args* a, void* stream);
 int gl_conv3x3(const gl_conv_args* a, void* stream);
 int gl_attention(const gl_attn_args* a, void* stream);

@@ -96,6 +96,13 @@ class PlmsStepArgs(C.Structure):
     ]
 
 
+class RewardArgs(C.Structure):
+    """gl_reward_args"""
+    _fields_ = [("txt", vp), ("img_pred", vp), ("img_gt", vp), ("B", i32), ("D", i32),
+                ("w1", vp), ("b1", vp), ("w2", vp), ("b2", vp), ("w3", vp), ("b3", vp), ("w4", vp), ("b4", vp), ("w5", vp), ("b5", vp),
+                ("sims_ti", vp), ("sims_ii", vp), ("aesthetic", vp), ("partial_reward", vp)]
+
+
 # name -> (restype, argtypes); every symbol include/gligen_hip.h declares
 PROTOTYPES = {
     "gl_gemm": (i32, [C.POINTER(GemmArgs), vp]),
@@ -134,6 +141,8 @@ PROTOTYPES = {
     "gl_sizeof_unet_config": (i32, []),
     "gl_sizeof_weight_info": (i32, []),
     "gl_sizeof_plms_step_args": (i32, []),
+    "gl_reward_score": (i32, [C.POINTER(RewardArgs), vp]),
+    "gl_sizeof_reward_args": (i32, []),
     "gl_set_option": (i32, [i32, i32]),
 }
 
@@ -169,7 +178,7 @@ def lib() -> C.CDLL:
         raise HipLibraryError(f"ABI version mismatch: lib {l.gl_abi_version()} vs host {ABI_VERSION}")
     for cls, fn in ((GemmArgs, l.gl_sizeof_gemm_args), (ConvArgs, l.gl_sizeof_conv_args), (AttnArgs, l.gl_sizeof_attn_args),
                     (UNetConfigC, l.gl_sizeof_unet_config), (WeightInfo, l.gl_sizeof_weight_info),
-                    (PlmsStepArgs, l.gl_sizeof_plms_step_args)):
+                    (PlmsStepArgs, l.gl_sizeof_plms_step_args), (RewardArgs, l.gl_sizeof_reward_args)):
         if C.sizeof(cls) != fn():
             raise HipLibraryError(f"struct size mismatch for {cls.__name__}: host {C.sizeof(cls)} vs lib {fn()}")
     _lib = l

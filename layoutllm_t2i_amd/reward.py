@@ -1,0 +1,68 @@
+"""Reward scoring stage of the train_rl.py rollout on the MI355X (BASELINE.json configs[4]).
+
+Mirrors the GPU part of ``Reward_Model.forward`` (models/policy.py:106-135): CLIP text-image / image-image cosine
+similarities and the AestheticMLP score (tools/aesthetic.py:15-31) run in ONE HIP kernel (``gl_reward_score``) on the
+CLIP features of the rollout batch; ``reward = clip + 0.1 * aes + 10 * mIoU + 10 * DocSim`` (policy.py:135) is finished
+on the host with the layout terms the reference computes in CPU python (``compute_maximum_iou`` / ``compute_docsim``),
+which are passed in.  The CLIP towers that produce the features are the caller's modules (HF ``CLIPModel``), exactly as
+``all_models``' text encoder is for the denoiser.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Mapping, Optional
+
+import torch
+
+from . import _lib
+from ._lib import RewardArgs, check
+
+F32 = torch.float32
+# nn.Sequential indices of the five Linear layers of AestheticMLP (tools/aesthetic.py:21-34; Dropouts sit in between)
+_LINEARS = (0, 2, 4, 6, 7)
+_SHAPES = ((1024, None), (128, 1024), (64, 128), (16, 64), (1, 16))
+
+
+class RewardScorer:
+    def __init__(self, aesthetic_state_dict: Mapping[str, torch.Tensor], device="cuda:0", input_size: int = 768):
+        """``aesthetic_state_dict``: the AestheticMLP checkpoint (keys ``layers.{0,2,4,6,7}.{weight,bias}``,
+        models/policy.py:44-46 loads ``sac+logos+ava1-l14-linearMSE.pth`` into it)."""
+        if not torch.cuda.is_available():
+            raise RuntimeError("RewardScorer needs a GPU: the scoring stage has no CPU fallback")
+        self.device = torch.device(device)
+        self.input_size = input_size
+        self.w = []
+        for li, (n, k) in zip(_LINEARS, _SHAPES):
+            k = input_size if k is None else k
+            w = torch.as_tensor(aesthetic_state_dict[f"layers.{li}.weight"], dtype=F32)
+            b = torch.as_tensor(aesthetic_state_dict[f"layers.{li}.bias"], dtype=F32)
+            if tuple(w.shape) != (n, k) or tuple(b.shape) != (n,):
+                raise ValueError(f"layers.{li}: weight {tuple(w.shape)} / bias {tuple(b.shape)}, expected ({n}, {k}) / ({n},)")
+            self.w.append((w.to(self.device).contiguous(), b.to(self.device).contiguous()))
+
+    @torch.no_grad()
+    def score(self, txt_features: torch.Tensor, img_pred_features: torch.Tensor, img_gt_features: torch.Tensor,
+              miou: Optional[torch.Tensor] = None, laysim: Optional[torch.Tensor] = None) -> dict:
+        """features: fp32 [B, D] CLIP embeddings (``get_text_features`` / ``get_image_features``, unnormalised).
+        Returns dict(sims_ti, sims_ii, clip_reward, aes_reward, reward) of fp32 [B] device tensors; ``reward`` includes
+        10 * miou + 10 * laysim when those (CPU-side layout terms, policy.py:126-133) are given."""
+        f = lambda t: torch.as_tensor(t, dtype=F32).to(self.device).contiguous()
+        t, p, g = f(txt_features), f(img_pred_features), f(img_gt_features)
+        if not (t.shape == p.shape == g.shape) or t.dim() != 2 or t.shape[1] != self.input_size:
+            raise ValueError(f"features must all be [B, {self.input_size}]")
+        B = t.shape[0]
+        out = torch.empty(4, B, dtype=F32, device=self.device)
+        a = RewardArgs()
+        a.txt, a.img_pred, a.img_gt, a.B, a.D = t.data_ptr(), p.data_ptr(), g.data_ptr(), B, self.input_size
+        for i, (w, b) in enumerate(self.w, start=1):
+            setattr(a, f"w{i}", w.data_ptr())
+            setattr(a, f"b{i}", b.data_ptr())
+        a.sims_ti, a.sims_ii, a.aesthetic, a.partial_reward = (out[i].data_ptr() for i in range(4))
+        with torch.cuda.device(self.device):
+            check(_lib.lib().gl_reward_score(C.byref(a), torch.cuda.current_stream(self.device).cuda_stream), "gl_reward_score")
+        reward = out[3]
+        if miou is not None:
+            reward = reward + f(miou) * 10
+        if laysim is not None:
+            reward = reward + f(laysim) * 10
+        return dict(sims_ti=out[0], sims_ii=out[1], clip_reward=out[0] + out[1], aes_reward=out[2], reward=reward)
