@@ -102,15 +102,10 @@ def collect():
 def main():
     which = set(sys.argv[1:]) or {"gemm", "conv", "attn", "norm"}
     init_device()
-    if "KB_PIPE" in os.environ:
-        ops.set_option(1, int(os.environ["KB_PIPE"]))
-    for k, env in ((4, "KB_SMALL"), (5, "KB_SKT"), (6, "KB_SKNK"), (7, "KB_BIG"), (8, "KB_GEGLU32"), (9, "KB_BIGKIND"), (10, "KB_ATTNPRIO"), (11, "KB_LNRPW"), (12, "KB_DBG"), (13, "KB_KSPLIT"), (14, "KB_HALO"), (15, "KB_HALOTILES"), (16, "KB_GNPPB")):
-        if env in os.environ:
-            ops.set_option(k, int(os.environ[env]))
-    if "KB_QT2" in os.environ:
-        ops.set_option(3, int(os.environ["KB_QT2"]))
-    if "KB_TILE" in os.environ:
-        ops.set_option(2, int(os.environ["KB_TILE"]))
+    # KB_OPTS="22=1,13=2": gl_set_option knobs for A/B runs (see include/gligen_hip.h)
+    for kv in filter(None, os.environ.get("KB_OPTS", "").split(",")):
+        k, v = kv.split("=")
+        ops.set_option(int(k), int(v))
     gemms, convs, attns, gns, lns = collect()
     h = lambda *s: torch.randn(*s, device=DEV).to(torch.float16)
     tot_on = tot_off = 0.0
