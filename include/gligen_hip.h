@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GL_ABI_VERSION 4
+#define GL_ABI_VERSION 5
 
 /* error codes (negative; positive values are hipError_t) */
 #define GL_ERR_BAD_ARG (-1)
@@ -114,6 +114,8 @@ typedef struct gl_attn_args {
     void* out;      int64_t o_bstride;  int32_t ldo;
     int32_t B, H, d, Nq, Nk;
     float scale;
+    int32_t q_prescaled;   /* != 0: scale * log2(e) is already folded into Q (the packer folds it into the q projection
+                              weights); `scale` is then ignored and the running max is subtracted inside the MFMA */
 } gl_attn_args;
 
 /* gl_transpose_v: V [B, Nk, *] (row stride ldv, head h at column h*d) -> vt [B, H, d, ldvt], zero-fills keys

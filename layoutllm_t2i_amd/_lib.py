@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgligen_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # enum gl_epilogue / gl_out_mode
 EPI_BIAS, EPI_SILU, EPI_GEGLU, EPI_RES, EPI_GATE_RES, EPI_ROWBIAS = range(6)
@@ -64,6 +64,7 @@ class AttnArgs(C.Structure):
         ("out", vp), ("o_bstride", i64), ("ldo", i32),
         ("B", i32), ("H", i32), ("d", i32), ("Nq", i32), ("Nk", i32),
         ("scale", f32),
+        ("q_prescaled", i32),
     ]
 
 

@@ -28,7 +28,12 @@ int g_attn_setprio = -1;     // s_setprio(1) around the MFMA clusters: -1 auto (
 constexpr int KT = 64;          // keys per tile
 constexpr int VSTR2 = KT + 8;   // main kernel: 144 B rows = 9 x 16 B, conflict-free 16-byte fragment reads
 
-template <int DQK, int QT, int NW>
+// PRE: the softmax scale AND log2(e) are already folded into Q (q_prescaled: the packer folds them into the q projection
+// weights), so the logits leave the MFMA in exp2 units.  The running max is then subtracted by the MFMA itself -- the
+// accumulator is initialised with -m instead of 0 -- and the common (no-rescale) path of the online softmax is ONE v_exp
+// per score instead of FMA + v_exp: the kernel is VALU-bound (PMC: VALU 68 % busy vs MFMA 43 % at d = 40), and this
+// removes 32 of its ~146 VALU instructions per 64-key tile.
+template <int DQK, int QT, int NW, bool PRE>
 __global__ __launch_bounds__(64 * NW) void attn_kernel(gl_attn_args p, int flags) {
     // NW = waves per block: 4 (128 queries share each staged K/V tile) or 8 (256 queries: half the L2 -> LDS
     // traffic per query at the same registers per wave)
@@ -101,10 +106,13 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(gl_attn_args p, int flags
 
     f32x16 o[QT][NDT];
     float m_run[QT], l_run[QT];
+    f32x16 negm[QT];                   // PRE: -m_run in all 16 accumulator slots = the C operand of the first QK^T MFMA
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-        m_run[qt] = -INFINITY;
+        m_run[qt] = PRE ? 0.0f : -INFINITY;
         l_run[qt] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[qt][r] = 0.0f;
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
@@ -211,7 +219,7 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(gl_attn_args p, int flags
             for (int ks = 0; ks < NKS; ++ks) {
                 const half8_t kf = *reinterpret_cast<const half8_t*>(Ks + (kh * 32 + ql) * KSTR + (2 * ks + hi) * 8);
 #pragma unroll
-                for (int qt = 0; qt < QT; ++qt) s[qt][kh] = mfma32(kf, qf[qt][ks], ks == 0 ? zero16 : s[qt][kh]);
+                for (int qt = 0; qt < QT; ++qt) s[qt][kh] = mfma32(kf, qf[qt][ks], ks == 0 ? (PRE ? negm[qt] : zero16) : s[qt][kh]);
             }
         if (SETPRIO) __builtin_amdgcn_s_setprio(0);
         // ---- online softmax (this lane: query ql of each sub-tile, keys kh*32 + (r&3) + 8*(r>>2) + 4*hi).
@@ -239,6 +247,44 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(gl_attn_args p, int flags
 #pragma unroll
             for (int i = 3; i < 31; i += 2) tmax = max3f(tmax, sv(i), sv(i + 1));
             tmax = fmaxf(tmax, sv(31));
+            float psum = 0.0f;
+            if constexpr (PRE) {
+                // scores are s' = logit - m_run (exp2 units).  Rescale when some row's tile max exceeds the running max
+                // by more than 2^DEFER -- and always on the first tile, which establishes the true row max (m_run = 0
+                // until then, so a row of very negative logits cannot underflow its whole first tile)
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                float inc = 0.0f;
+                if (t == 0 || __any(tmax > DEFER)) {
+                    inc = (t == 0) ? tmax : fmaxf(tmax, 0.0f);
+                    const float alpha = (t == 0) ? 1.0f : __builtin_amdgcn_exp2f(-inc);    // O and l are still 0 on the first tile
+                    m_run[qt] += inc;
+                    if constexpr (!ONES) l_run[qt] *= alpha;
+#pragma unroll
+                    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[qt][dt][r] *= alpha;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) negm[qt][r] = -m_run[qt];
+#pragma unroll
+                    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) s[qt][kh][r] -= inc;
+                }
+#pragma unroll
+                for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const float p0 = __builtin_amdgcn_exp2f(s[qt][kh][r]);
+                        const float p1 = __builtin_amdgcn_exp2f(s[qt][kh][r + 1]);
+                        if constexpr (!ONES) psum += p0 + p1;
+                        f32x2 pv = {p0, p1};
+                        const half2_t ph = __builtin_convertvector(pv, half2_t);
+                        const unsigned pw = *reinterpret_cast<const unsigned*>(&ph);
+                        const int j = kh * 2 + (r >> 3);
+                        const int e = (r & 7) >> 1;
+                        if (e == 0) pf[qt][j].x = pw; else if (e == 1) pf[qt][j].y = pw; else if (e == 2) pf[qt][j].z = pw; else pf[qt][j].w = pw;
+                    }
+            } else {
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * c_scale;
             if (__any(tmax > m_run[qt] + DEFER)) {
                 const float m_new = fmaxf(m_run[qt], tmax);
@@ -251,7 +297,6 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(gl_attn_args p, int flags
                     for (int r = 0; r < 16; ++r) o[qt][dt][r] *= alpha;
             }
             const float nm = -m_run[qt];
-            float psum = 0.0f;
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
@@ -266,6 +311,7 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(gl_attn_args p, int flags
                     const int e = (r & 7) >> 1;
                     if (e == 0) pf[qt][j].x = pw; else if (e == 1) pf[qt][j].y = pw; else if (e == 2) pf[qt][j].z = pw; else pf[qt][j].w = pw;
                 }
+            }
             if constexpr (!ONES) l_run[qt] += psum;
         }
         // ---- O^T += V^T . P^T : k-step j covers keys 16j..16j+15 in the order (e&3) + 8*(e>>2) + 4*hi
@@ -348,7 +394,9 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const half_t* __restri
 template <int DQK, int QT, int NW = 4>
 int launch_attn(const gl_attn_args& a, hipStream_t st) {
     dim3 grid(gl_cdiv(a.Nq, 32 * NW * QT) * a.H * a.B);
-    attn_kernel<DQK, QT, NW><<<grid, dim3(64 * NW), 0, st>>>(a, g_attn_setprio < 0 ? (DQK <= 48 ? 1 : 0) : g_attn_setprio);
+    const int flags = g_attn_setprio < 0 ? (DQK <= 48 ? 1 : 0) : g_attn_setprio;
+    if (a.q_prescaled) attn_kernel<DQK, QT, NW, true><<<grid, dim3(64 * NW), 0, st>>>(a, flags);
+    else attn_kernel<DQK, QT, NW, false><<<grid, dim3(64 * NW), 0, st>>>(a, flags);
     GL_CHECK_LAUNCH();
     return 0;
 }

@@ -420,6 +420,7 @@ struct Run {
         a.q = q; a.q_bstride = qb; a.ldq = ldq; a.k = k; a.k_bstride = kb; a.ldk = ldk; a.vt = vt; a.ldvt = ldvt;
         a.out = out; a.o_bstride = ob; a.ldo = ldo; a.B = B; a.H = H; a.d = d; a.Nq = Nq; a.Nk = Nk;
         a.scale = 1.0f / sqrtf((float)d);
+        a.q_prescaled = 1;      // weights.py folds d^-1/2 * log2(e) into every q projection
         ++launches;
         return gl_attention(&a, st);
     }

@@ -191,7 +191,9 @@ def transpose_v(v: torch.Tensor, v_bstride: int, ldv: int, vt: torch.Tensor, B: 
 
 
 def attention(q: torch.Tensor, q_bstride: int, ldq: int, k: torch.Tensor, k_bstride: int, ldk: int, vt: torch.Tensor,
-              out: torch.Tensor, o_bstride: int, ldo: int, B: int, H: int, d: int, Nq: int, Nk: int, scale: float):
+              out: torch.Tensor, o_bstride: int, ldo: int, B: int, H: int, d: int, Nq: int, Nk: int, scale: float,
+              q_prescaled: bool = False):
+    """``q_prescaled``: scale * log2(e) is already folded into q (weights.Q_FOLD does that to the packed q projections)."""
     _req(q, F16, "q")
     _req(k, F16, "k")
     _req(vt, F16, "vt")
@@ -203,6 +205,7 @@ def attention(q: torch.Tensor, q_bstride: int, ldq: int, k: torch.Tensor, k_bstr
     a.out, a.o_bstride, a.ldo = out.data_ptr(), o_bstride, ldo
     a.B, a.H, a.d, a.Nq, a.Nk = B, H, d, Nq, Nk
     a.scale = scale
+    a.q_prescaled = int(q_prescaled)
     check(_lib.lib().gl_attention(C.byref(a), _stream()), "gl_attention")
     return out
 

@@ -28,6 +28,13 @@ import torch
 from .arch import Plan, UNetConfig, build_plan, param_shapes
 
 CIN_PAD = 64
+LOG2E = 1.4426950408889634
+
+
+def q_fold(d_head: int) -> float:
+    """The softmax scale d^-1/2 (attention.py:136,172) times log2(e), folded into every q projection at pack time: the
+    attention kernel then gets logits in exp2 units straight out of the MFMA (gl_attn_args.q_prescaled)."""
+    return float(d_head) ** -0.5 * LOG2E
 
 
 def _t(v, device) -> torch.Tensor:
@@ -173,12 +180,12 @@ def pack_state_dict(sd: Mapping[str, object], cfg: UNetConfig, device, sd_first_
         W[p + ".ff1.b"] = geglu_interleave(g(p + ".net.0.proj.bias")).contiguous()
         lin(p + ".net.2", p + ".ff2")
 
-    def self_attn(p):
-        W[p + ".qkv.w"] = _h(torch.cat([g(p + ".to_q.weight"), g(p + ".to_k.weight"), g(p + ".to_v.weight")], 0))
+    def self_attn(p, d):
+        W[p + ".qkv.w"] = _h(torch.cat([g(p + ".to_q.weight") * q_fold(d), g(p + ".to_k.weight"), g(p + ".to_v.weight")], 0))
         lin(p + ".to_out.0", p + ".o")
 
-    def cross_attn(p):
-        W[p + ".q.w"] = _h(g(p + ".to_q.weight"))
+    def cross_attn(p, d):
+        W[p + ".q.w"] = _h(g(p + ".to_q.weight") * q_fold(d))
         W[p + ".kv.w"] = _h(torch.cat([g(p + ".to_k.weight"), g(p + ".to_v.weight")], 0))
         lin(p + ".to_out.0", p + ".o")
 
@@ -211,21 +218,21 @@ def pack_state_dict(sd: Mapping[str, object], cfg: UNetConfig, device, sd_first_
             lin(p + ".proj_in")
             lin(p + ".proj_out")
             t = p + ".transformer_blocks.0"
-            self_attn(t + ".attn1")
-            cross_attn(t + ".attn2")
+            self_attn(t + ".attn1", l.d_head)
+            cross_attn(t + ".attn2", l.d_head)
             ff(t + ".ff")
             for n in ("norm1", "norm2", "norm3"):
                 norm(f"{t}.{n}")
             f = t + ".fuser"
             lin(f + ".linear")
-            self_attn(f + ".attn")
+            self_attn(f + ".attn", l.d_head)
             ff(f + ".ff")
             norm(f + ".norm1")
             norm(f + ".norm2")
             S[f + ".tanh_attn"] = math.tanh(float(g(f + ".alpha_attn")))
             S[f + ".tanh_dense"] = math.tanh(float(g(f + ".alpha_dense")))
             r = t + ".rela_fuse"
-            cross_attn(r + ".attn")
+            cross_attn(r + ".attn", l.d_head)
             ff(r + ".ff")
             for n in ("norm1", "norm2", "norm3"):
                 norm(f"{r}.{n}")

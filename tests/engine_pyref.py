@@ -202,7 +202,7 @@ class PyRefEngine:
             ops.transpose_v(qkv[:, 2 * C:], rows_per_b * 3 * C, 3 * C, vt, Bn, H, d, Nk)
         att = self.buf(tagp + ".att", (Bn * Nq, C))
         ops.attention(qkv, rows_per_b * 3 * C, 3 * C, qkv[:, C:], rows_per_b * 3 * C, 3 * C, vt, att, Nq * C, C,
-                      Bn, H, d, Nq, Nk, d ** -0.5)
+                      Bn, H, d, Nq, Nk, d ** -0.5, q_prescaled=True)
         return att
 
     def _feed_forward(self, xn, res, p, M, C, out, gate=None):
@@ -253,7 +253,7 @@ class PyRefEngine:
         q = ops.gemm(fn, W[r + ".attn.q.w"], self.buf("rl.q", (Mo, C)))
         kv = c[f"kvrel.{li}"]
         ar = self.buf("rl.att", (Mo, C))
-        ops.attention(q, mo * C, C, kv, R * 2 * C, 2 * C, c[f"vtrel.{li}"], ar, mo * C, C, Bn, H, d, mo, R, d ** -0.5)
+        ops.attention(q, mo * C, C, kv, R * 2 * C, 2 * C, c[f"vtrel.{li}"], ar, mo * C, C, Bn, H, d, mo, R, d ** -0.5, q_prescaled=True)
         f1 = ops.gemm(ar, W[r + ".attn.o.w"], self.buf("rl.f1", (Mo, C)), W[r + ".attn.o.b"], EPI_GATE_RES, res=feat,
                       gate=self._gates[r + ".tanh_attn"])
         fn2 = ops.layernorm(f1, self.buf("rl.ln", (Mo, C)), W[r + ".norm2.g"], W[r + ".norm2.b"], Bn, mo)
@@ -267,7 +267,7 @@ class PyRefEngine:
         q2 = ops.gemm(n, W[t + ".attn2.q.w"], self.buf("st.q2", (M, C)))
         a2 = self.buf("st.att2", (M, C))
         ops.attention(q2, N * C, C, c[f"kvctx.{li}"], Lc * 2 * C, 2 * C, c[f"vtctx.{li}"], a2, N * C, C, Bn, H, d, N, Lc,
-                      d ** -0.5)
+                      d ** -0.5, q_prescaled=True)
         x = ops.gemm(a2, W[t + ".attn2.o.w"], nxt(x), W[t + ".attn2.o.b"], EPI_RES, res=x)
         # --- GEGLU feed-forward (attention.py:401): the sum is only consumed by proj_out's matrix product -> fp16
         n3 = ops.layernorm(x, self.buf("st.ln", (M, C)), W[t + ".norm3.g"], W[t + ".norm3.b"], Bn, N)

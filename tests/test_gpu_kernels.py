@@ -361,6 +361,31 @@ def test_attention(d, H, Nq, Nk, B):
     check(out, _attn_ref(q, k, v, H), f"attn_d{d}_q{Nq}_k{Nk}", rtol=2e-3, atol=2e-4)
 
 
+@pytest.mark.parametrize("d,H,Nq,Nk,B", [(16, 4, 64, 64, 2), (40, 8, 256, 286, 1), (64, 2, 130, 77, 2), (80, 8, 1024, 1054, 1),
+                                        (160, 8, 256, 286, 1), (40, 8, 30, 10, 2), (40, 8, 4096, 4126, 1)])
+def test_attention_prescaled_q(d, H, Nq, Nk, B):
+    """q_prescaled: d^-1/2 * log2(e) folded into Q beforehand (the packer folds it into the q projection weights), the running
+    max subtracted inside the MFMA.  Reference = softmax over the SAME fp16-rounded prescaled q; includes rows whose first
+    tile is far below / above zero (m starts at 0 and must lock onto the true row max on tile 0) and a late outlier key."""
+    from layoutllm_t2i_amd.weights import q_fold
+    C = H * d
+    c = q_fold(d)
+    q = rnd(f"pq{d}{Nq}", (B, Nq, C))
+    q[:, 0] *= 30.0                                  # one query with huge logits (|s| in the hundreds of exp2 units)
+    k = rnd(f"pk{d}{Nk}", (B, Nk, C))
+    if Nk > 100:
+        k[:, Nk - 3] = q[:, 1] * 4.0                 # a late key that jumps query 1's running max by >> 2^8
+    qs, qd = h16(q * c)                              # what the q projection GEMM would write
+    k, kd = h16(k)
+    v, vd = h16(rnd(f"pv{d}{Nk}", (B, Nk, C)))
+    vt = torch.full((B, H, d, ops.vt_ld(Nk)), float("nan"), dtype=torch.float16, device=DEV)
+    ops.transpose_v(vd, Nk * C, C, vt, B, H, d, Nk)
+    out = torch.empty(B, Nq, C, dtype=torch.float16, device=DEV)
+    ops.attention(qd, Nq * C, C, kd, Nk * C, C, vt, out, Nq * C, C, B, H, d, Nq, Nk, 123.0, q_prescaled=True)   # scale must be ignored
+    ref = _attn_ref(qs / c, k, v, H)                 # softmax(d^-1/2 (q'/c) k^T) == softmax over the prescaled logits
+    check(out, ref, f"attn_prescaled_d{d}_q{Nq}_k{Nk}", rtol=2e-3, atol=2e-4)
+
+
 @pytest.mark.parametrize("opt", [3, 4])
 def test_attention_block_size_variants(opt):
     """8-wave (256-query) and 4-wave blocks forced via gl_set_option(3, 3|4); includes a ragged last slab"""
@@ -368,6 +393,8 @@ def test_attention_block_size_variants(opt):
     try:
         test_attention(40, 8, 600, 1054, 1)
         test_attention(80, 8, 300, 1054, 1)
+        test_attention_prescaled_q(40, 8, 256, 286, 1)
+        test_attention_prescaled_q(80, 8, 1024, 1054, 1)
     finally:
         ops.set_option(3, 0)
 

@@ -158,7 +158,8 @@ def main():
             vt = torch.empty(B2, H, d, ldvt, dtype=torch.float16, device=DEV)
             ops.transpose_v(v, Nk * C, C, vt, B2, H, d, Nk)
             out = torch.empty(B2, Nq, C, dtype=torch.float16, device=DEV)
-            fn = lambda: ops.attention(q, Nq * C, C, k, Nk * C, C, vt, out, Nq * C, C, B2, H, d, Nq, Nk, d ** -0.5)
+            pre = bool(int(os.environ.get("KB_PRE", "1")))      # the engine's form: scale folded into q
+            fn = lambda: ops.attention(q, Nq * C, C, k, Nk * C, C, vt, out, Nq * C, C, B2, H, d, Nq, Nk, d ** -0.5, q_prescaled=pre)
             t = timeit(fn)
             tt = timeit(lambda: ops.transpose_v(v, Nk * C, C, vt, B2, H, d, Nk))
             fl = 4.0 * B2 * H * Nq * Nk * d
