@@ -118,7 +118,9 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(gl_attn_args p, int flags
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[qt][dt][r] = 0.0f;
     }
-    const float c_scale = p.scale * 1.4426950408889634f;
+    // q_prescaled input on the FMA path (small head dims, where the 16 extra registers of the C-init form would cost
+    // occupancy): the scale is already in the logits
+    const float c_scale = p.q_prescaled ? 1.0f : p.scale * 1.4426950408889634f;
 
     uint4 rk[K_PER_T], rv[V_PER_T];
     // tile-invariant staging coordinates (no per-tile divisions / 64-bit address rebuilds)
@@ -395,7 +397,9 @@ template <int DQK, int QT, int NW = 4>
 int launch_attn(const gl_attn_args& a, hipStream_t st) {
     dim3 grid(gl_cdiv(a.Nq, 32 * NW * QT) * a.H * a.B);
     const int flags = g_attn_setprio < 0 ? (DQK <= 48 ? 1 : 0) : g_attn_setprio;
-    if (a.q_prescaled) attn_kernel<DQK, QT, NW, true><<<grid, dim3(64 * NW), 0, st>>>(a, flags);
+    // the C-init form needs 16 more registers: measured +9 % at d = 80 (35.1 vs 38.4 us, N = 1024) but -12 % at d = 40, where
+    // the kernel lives on 8 waves per SIMD (60 -> 76 registers drops it to 6)
+    if (a.q_prescaled && DQK >= 80) attn_kernel<DQK, QT, NW, true><<<grid, dim3(64 * NW), 0, st>>>(a, flags);
     else attn_kernel<DQK, QT, NW, false><<<grid, dim3(64 * NW), 0, st>>>(a, flags);
     GL_CHECK_LAUNCH();
     return 0;
