@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GL_ABI_VERSION 5
+#define GL_ABI_VERSION 6
 
 /* error codes (negative; positive values are hipError_t) */
 #define GL_ERR_BAD_ARG (-1)
@@ -143,10 +143,12 @@ int gl_groupnorm_apply(const void* x1, int32_t C1, const void* x2, int32_t C2, i
  * Input row r = (b, i) with i < rows_in, fp32 when x_f32 != 0 (the residual stream) else fp16; output fp16, row index
  * = b * rows_out + row_off + i -- this writes straight into the [x ; objs] concatenation of GatedSelfAttentionDense
  * (attention.py:230).  stats (optional): (mean, rstd) per input row, fp32 [B * rows_in, 2].  C % 8 == 0, C <= 2048.
+ * x2 (optional, fp16, rows2 rows per sample, row stride ldx2): a second source whose rows follow the rows_in rows of x in
+ * every sample's output block -- [x ; objs] normalised in one launch.
  */
 int gl_layernorm(const void* x, int32_t ldx, int32_t x_f32, void* y, int32_t ldy, const float* gamma, const float* beta,
                  int32_t B, int32_t rows_in, int32_t rows_out, int32_t row_off, int32_t C, float eps, float* stats,
-                 void* stream);
+                 const void* x2, int32_t ldx2, int32_t rows2, void* stream);
 
 /*
  * RelationCrossAttention (attention.py:315-359) in closed form:
@@ -154,14 +156,16 @@ int gl_layernorm(const void* x, int32_t ldx, int32_t x_f32, void* y, int32_t ldy
  * rects[b][i] = {top, bottom, left, right} int32 pixel bounds (already python-slice-normalised on the
  * host, attention.py:325-346), nvalid[b] = boxes before the first padded/degenerate one, poison[b] != 0
  * reproduces the reference's NaN for an empty (right < left) slice.
- *   gl_rela_pool  : feat[b, i, :] = mean_{p in rect_i} hid[b, p, :]   (0 rows for i >= nvalid[b])
+ *   gl_rela_pool  : feat[b, i, :] = mean_{p in rect_i} hid[b, p, :]   (0 rows for i >= nvalid[b]); with ln_out != NULL also
+ *                   ln_out[b, i, :] = LayerNorm(feat[b, i, :]; ln_gamma, ln_beta, eps 1e-5)  (norm1, attention.py:348)
  *   gl_rela_merge : y = 0.5 * (x + hid + (1/max_objs) * sum_i 1[p in rect_i] f[b, i, :])
  *                   x / y fp32 when x_f32 != 0 (residual stream) else fp16.  hid = LayerNorm3(x) is either read (fp16,
  *                   ln_stats == NULL) or re-evaluated in fp32 from ln_stats = gl_layernorm's (mean, rstd) rows and
  *                   gamma / beta, so that it enters the stream unrounded.
  */
 int gl_rela_pool(const void* hid, int32_t B, int32_t H, int32_t W, int32_t C, const int32_t* rects,
-                 const int32_t* nvalid, const int32_t* poison, int32_t max_objs, void* feat, void* stream);
+                 const int32_t* nvalid, const int32_t* poison, int32_t max_objs, void* feat, const float* ln_gamma,
+                 const float* ln_beta, void* ln_out, void* stream);
 int gl_rela_merge(const void* x, int32_t x_f32, const void* hid, const float* ln_stats, const float* gamma,
                   const float* beta, const void* f, int32_t B, int32_t H, int32_t W, int32_t C,
                   const int32_t* rects, const int32_t* nvalid, const int32_t* poison, int32_t max_objs,

@@ -402,9 +402,10 @@ struct Run {
         return gl_conv3x3(&a, st);
     }
     int ln(const void* x, int ldx, int x_f32, half_t* y, int ldy, const std::string& p, int B, int rows_in, int rows_out, int row_off,
-           int C, float* stats = nullptr) {
+           int C, float* stats = nullptr, const half_t* x2 = nullptr, int rows2 = 0) {
         ++launches;
-        return gl_layernorm(x, ldx, x_f32, y, ldy, e->Wf(p + ".g"), e->Wf(p + ".b"), B, rows_in, rows_out, row_off, C, 1e-5f, stats, st);
+        return gl_layernorm(x, ldx, x_f32, y, ldy, e->Wf(p + ".g"), e->Wf(p + ".b"), B, rows_in, rows_out, row_off, C, 1e-5f, stats, x2, C, rows2,
+                            st);
     }
     int gn(const half_t* x1, int C1, const half_t* x2, int C2, int B, int HW, const std::string& p, float eps, int silu, half_t* out) {
         const int nchunk = gn_nchunk(HW);
@@ -555,8 +556,7 @@ int spatial_transformer(Run& r, const LayerD& l, int li, Stream2 xin, int side, 
         const int rows = N + ((mo + 7) & ~7);
         half_t* cat = e->h16("st.cat", (size_t)Bn * rows * C);
         CKP(cat);
-        CK(r.ln(x, C, 1, cat, C, f + ".norm1", Bn, N, rows, 0, C));
-        CK(r.ln(e->h16("hoist.objs." + sl, (size_t)Bn * mo * C), C, 0, cat, C, f + ".norm1", Bn, mo, rows, N, C));
+        CK(r.ln(x, C, 1, cat, C, f + ".norm1", Bn, N, rows, 0, C, nullptr, e->h16("hoist.objs." + sl, (size_t)Bn * mo * C), mo));
         CK(self_attention(r, cat, rows, N, N + mo, C, d, f + ".attn", "st.fa", &att));
         float* y = nxt(x);
         CK(r.gemm(att, C, f + ".attn.o.w", M, y, C, GL_OUT_F32_ROWMAJOR, f + ".attn.o.b", GL_EPI_GATE_RES, x, C, 1, gates + 0));
@@ -586,8 +586,7 @@ int spatial_transformer(Run& r, const LayerD& l, int li, Stream2 xin, int side, 
         CKP(rects); CKP(nvalid); CKP(poison); CKP(stats); CKP(hid); CKP(feat); CKP(fn); CKP(q); CKP(ar); CKP(f1); CKP(hg); CKP(f2);
         CK(r.ln(x, C, 1, hid, C, rf + ".norm3", Bn, N, N, 0, C, stats));
         ++r.launches;
-        CK(gl_rela_pool(hid, Bn, side, side, C, rects, nvalid, poison, mo, feat, r.st));
-        CK(r.ln(feat, C, 0, fn, C, rf + ".norm1", Bn, mo, mo, 0, C));
+        CK(gl_rela_pool(hid, Bn, side, side, C, rects, nvalid, poison, mo, feat, e->Wf(rf + ".norm1.g"), e->Wf(rf + ".norm1.b"), fn, r.st));
         CK(r.gemm(fn, C, rf + ".attn.q.w", Mo, q, C));
         const half_t* kv = e->h16("hoist.kvrel." + sl, (size_t)Bn * R * 2 * C);
         const int ldvt = vt_ld(R);

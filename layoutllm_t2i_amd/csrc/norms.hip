@@ -243,15 +243,22 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
 // One wave per row; up to NV x 64 8-channel vectors per row.  XF32: the input row is fp32 (the residual stream), else
 // fp16.  Two-pass statistics in registers (mean, then sum of squared deviations).  Optionally stores (mean, rstd) per
 // input row so that a consumer can re-evaluate the normalisation in fp32 (rela_merge).
+// Optional second source (fp16 rows x2, rows2 per sample): sample b's output rows are [rows_in rows of x | rows2 rows of x2],
+// i.e. the [x ; objs] concatenation of GatedSelfAttentionDense (attention.py:230) is normalised in ONE launch.
 template <bool XF32, int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__ xv, int ldx, half_t* __restrict__ y,
                                                         int ldy, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int nrows, int rows_in,
                                                         int rows_out, int row_off, int C, float eps,
-                                                        float* __restrict__ stats) {
+                                                        float* __restrict__ stats, const half_t* __restrict__ x2, int ldx2, int rows2) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= nrows) return;
+    const int orow = blockIdx.x * 4 + (threadIdx.x >> 6);        // index over B * (rows_in + rows2)
+    if (orow >= nrows) return;
+    const int rtot = rows_in + rows2;
+    const int bidx = orow / rtot;
+    const int i_in = orow - bidx * rtot;
+    const bool second = i_in >= rows_in;                           // wave-uniform
+    const int row = second ? bidx * rows2 + (i_in - rows_in) : bidx * rows_in + i_in;   // row within its source
     const int nvec = C / 8;
     float v[NV][8];
 #pragma unroll
@@ -260,7 +267,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[i][j] = 0.0f;
         if (vec < nvec) {
-            if constexpr (XF32) {
+            if (second) {
+                uint4 raw = ld16(x2 + (size_t)row * ldx2 + vec * 8);
+                const half8_t hv = *reinterpret_cast<half8_t*>(&raw);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[i][j] = (float)hv[j];
+            } else if constexpr (XF32) {
                 const float* xr = reinterpret_cast<const float*>(xv) + (size_t)row * ldx + vec * 8;
                 const float4 a = *reinterpret_cast<const float4*>(xr);
                 const float4 c = *reinterpret_cast<const float4*>(xr + 4);
@@ -292,12 +304,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
         }
     }
     const float rstd = rsqrtf(wave_sum(ss) / (float)C + eps);
-    if (stats != nullptr && lane == 0) {
+    if (stats != nullptr && lane == 0 && !second) {
         stats[(size_t)row * 2] = mean;
         stats[(size_t)row * 2 + 1] = rstd;
     }
-    const int bidx = row / rows_in;
-    const int i_in = row - bidx * rows_in;
     half_t* yr = y + ((size_t)bidx * rows_out + row_off + i_in) * ldy;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -359,15 +369,18 @@ extern "C" int gl_groupnorm_apply(const void* x1, int32_t C1, const void* x2, in
 
 extern "C" int gl_layernorm(const void* x, int32_t ldx, int32_t x_f32, void* y, int32_t ldy, const float* gamma,
                             const float* beta, int32_t B, int32_t rows_in, int32_t rows_out, int32_t row_off, int32_t C,
-                            float eps, float* stats, void* stream) {
+                            float eps, float* stats, const void* x2, int32_t ldx2, int32_t rows2, void* stream) {
     if (!x || !y || !gamma || !beta || C <= 0 || (C % 8) || C > 2048 || (ldx % 8) || (ldy % 8)) return GL_ERR_BAD_ARG;
-    const int nrows = B * rows_in;
+    if (x2 == nullptr) rows2 = 0;
+    if (rows2 < 0 || (x2 != nullptr && (ldx2 % 8))) return GL_ERR_BAD_ARG;
+    const half_t* x2p = reinterpret_cast<const half_t*>(x2);
+    const int nrows = B * (rows_in + rows2);
     if (nrows <= 0) return GL_ERR_BAD_ARG;
     half_t* yp = reinterpret_cast<half_t*>(y);
     hipStream_t st = (hipStream_t)stream;
     const int nv = gl_cdiv(C / 8, 64);
     const dim3 grid(gl_cdiv(nrows, 4)), blk(256);
-#define GL_LN(F, V) layernorm_kernel<F, V><<<grid, blk, 0, st>>>(x, ldx, yp, ldy, gamma, beta, nrows, rows_in, rows_out, row_off, C, eps, stats)
+#define GL_LN(F, V) layernorm_kernel<F, V><<<grid, blk, 0, st>>>(x, ldx, yp, ldy, gamma, beta, nrows, rows_in, rows_out, row_off, C, eps, stats, x2p, ldx2, rows2)
     if (x_f32) {
         if (nv == 1) GL_LN(true, 1); else if (nv == 2) GL_LN(true, 2); else if (nv == 3) GL_LN(true, 3); else GL_LN(true, 4);
     } else {

@@ -20,71 +20,108 @@ constexpr int RELA_MAX_C = 2048;
 __global__ __launch_bounds__(256) void rela_pool_kernel(const half_t* __restrict__ hid, int H, int W, int C,
                                                         const int* __restrict__ rects, const int* __restrict__ nvalid,
                                                         const int* __restrict__ poison, int max_objs,
-                                                        half_t* __restrict__ feat) {
+                                                        half_t* __restrict__ feat, const float* __restrict__ ln_g,
+                                                        const float* __restrict__ ln_b, half_t* __restrict__ ln_out) {
     __shared__ float lacc[RELA_MAX_C];   // [plane][C] partial sums, nplanes * C <= 2048
+    __shared__ float red[4];
     const int i = blockIdx.x;
     const int b = blockIdx.y;
     const int nvec = C / 8;
     half_t* frow = feat + ((size_t)b * max_objs + i) * C;
+    // mode: 0 = pooled mean, 1 = unused slot (zero row), 2 = NaN row (empty python slice: torch.mean of nothing,
+    // attention.py:343, or a poisoned sample)
+    int mode = 0;
+    int top = 0, left = 0, rw = 1, npix = 1;
     if (i >= nvalid[b]) {
-        for (int c = threadIdx.x; c < C; c += 256) frow[c] = (half_t)0.0f;
-        return;
-    }
-    const int* r = rects + ((size_t)b * max_objs + i) * 4;
-    const int top = r[0], bottom = r[1], left = r[2], right = r[3];
-    const int rw = right - left;
-    const int npix = (bottom - top) * rw;
-    if (npix <= 0) {   // empty python slice: torch.mean of nothing = NaN (attention.py:343)
-        for (int c = threadIdx.x; c < C; c += 256) frow[c] = (half_t)__builtin_nanf("");
-        return;
+        mode = 1;
+    } else {
+        const int* r = rects + ((size_t)b * max_objs + i) * 4;
+        top = r[0]; left = r[2];
+        rw = r[3] - r[2];
+        npix = (r[1] - r[0]) * rw;
+        if (npix <= 0 || poison[b] != 0) mode = 2;
     }
     const int vlanes = min(nvec, 256);
     const int nplanes = 256 / vlanes;
-    const int plane = threadIdx.x / vlanes;
-    const int v0 = threadIdx.x - plane * vlanes;
-    if (plane < nplanes) {
-        for (int vec = v0; vec < nvec; vec += vlanes) {
-            float s[8];
+    if (mode == 0) {
+        const int plane = threadIdx.x / vlanes;
+        const int v0 = threadIdx.x - plane * vlanes;
+        if (plane < nplanes) {
+            for (int vec = v0; vec < nvec; vec += vlanes) {
+                float s[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s[j] = 0.0f;
-            int q = plane;
-            // 4 independent 16-byte loads in flight per thread (rectangles can span 2k+ pixels)
-            for (; q + 3 * nplanes < npix; q += 4 * nplanes) {
-                uint4 raw[4];
+                for (int j = 0; j < 8; ++j) s[j] = 0.0f;
+                int q = plane;
+                // 4 independent 16-byte loads in flight per thread (rectangles can span 2k+ pixels)
+                for (; q + 3 * nplanes < npix; q += 4 * nplanes) {
+                    uint4 raw[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int qq = q + u * nplanes;
-                    const int py = top + qq / rw;
-                    const int px = left + qq % rw;
-                    raw[u] = ld16(hid + (((size_t)b * H + py) * W + px) * C + vec * 8);
+                    for (int u = 0; u < 4; ++u) {
+                        const int qq = q + u * nplanes;
+                        const int py = top + qq / rw;
+                        const int px = left + qq % rw;
+                        raw[u] = ld16(hid + (((size_t)b * H + py) * W + px) * C + vec * 8);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const half8_t hv = *reinterpret_cast<half8_t*>(&raw[u]);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) s[j] += (float)hv[j];
+                    }
                 }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const half8_t hv = *reinterpret_cast<half8_t*>(&raw[u]);
+                for (; q < npix; q += nplanes) {
+                    const int py = top + q / rw;
+                    const int px = left + q % rw;
+                    uint4 raw = ld16(hid + (((size_t)b * H + py) * W + px) * C + vec * 8);
+                    const half8_t hv = *reinterpret_cast<half8_t*>(&raw);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) s[j] += (float)hv[j];
                 }
-            }
-            for (; q < npix; q += nplanes) {
-                const int py = top + q / rw;
-                const int px = left + q % rw;
-                uint4 raw = ld16(hid + (((size_t)b * H + py) * W + px) * C + vec * 8);
-                const half8_t hv = *reinterpret_cast<half8_t*>(&raw);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) s[j] += (float)hv[j];
+                for (int j = 0; j < 8; ++j) lacc[plane * C + vec * 8 + j] = s[j];
             }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) lacc[plane * C + vec * 8 + j] = s[j];
         }
     }
     __syncthreads();
     const float inv = 1.0f / (float)npix;
-    const bool bad = poison[b] != 0;
+    // the row as the next kernels see it: rounded to fp16 (kept in lacc[0 .. C) as floats for the fused LayerNorm)
+    float lsum = 0.0f;
     for (int c = threadIdx.x; c < C; c += 256) {
-        float s = 0.0f;
-        for (int pl = 0; pl < nplanes; ++pl) s += lacc[pl * C + c];
-        frow[c] = bad ? (half_t)__builtin_nanf("") : (half_t)(s * inv);
+        float v = 0.0f;
+        if (mode == 0) {
+            float s = 0.0f;
+            for (int pl = 0; pl < nplanes; ++pl) s += lacc[pl * C + c];
+            v = s * inv;
+        } else if (mode == 2) {
+            v = __builtin_nanf("");
+        }
+        const half_t hvv = (half_t)v;
+        frow[c] = hvv;
+        v = (float)hvv;
+        lsum += v;
+        if (ln_out != nullptr) {
+            // plane 0 of lacc is also a SOURCE above: every thread re-reads only its own channels c, written by itself
+            lacc[c] = v;
+        }
     }
+    if (ln_out == nullptr) return;
+    // fused LayerNorm1 of the pooled row (attention.py:348: attn(norm1(obj_features), ...)), two-pass, fp32
+    auto bsum = [&](float v) {
+        v = wave_sum(v);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        return red[0] + red[1] + red[2] + red[3];
+    };
+    const float mean = bsum(lsum) / (float)C;
+    float lss = 0.0f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float d = lacc[c] - mean;
+        lss = fmaf(d, d, lss);
+    }
+    const float rstd = rsqrtf(bsum(lss) / (float)C + 1e-5f);
+    half_t* lrow = ln_out + ((size_t)b * max_objs + i) * C;
+    for (int c = threadIdx.x; c < C; c += 256) lrow[c] = (half_t)((lacc[c] - mean) * rstd * ln_g[c] + ln_b[c]);
 }
 
 // elementwise over [B, H*W, C]: 8 channels per thread.  XF32: x and y are the fp32 residual stream and hid = LN3(x) is
@@ -165,10 +202,13 @@ __global__ __launch_bounds__(256) void rela_merge_kernel(const void* __restrict_
 }  // namespace
 
 extern "C" int gl_rela_pool(const void* hid, int32_t B, int32_t H, int32_t W, int32_t C, const int32_t* rects,
-                            const int32_t* nvalid, const int32_t* poison, int32_t max_objs, void* feat, void* stream) {
+                            const int32_t* nvalid, const int32_t* poison, int32_t max_objs, void* feat, const float* ln_gamma,
+                            const float* ln_beta, void* ln_out, void* stream) {
     if (!hid || !rects || !nvalid || !poison || !feat || C <= 0 || (C % 8) || C > RELA_MAX_C) return GL_ERR_BAD_ARG;
+    if (ln_out != nullptr && (!ln_gamma || !ln_beta)) return GL_ERR_BAD_ARG;
     rela_pool_kernel<<<dim3(max_objs, B), dim3(256), 0, (hipStream_t)stream>>>(
-        reinterpret_cast<const half_t*>(hid), H, W, C, rects, nvalid, poison, max_objs, reinterpret_cast<half_t*>(feat));
+        reinterpret_cast<const half_t*>(hid), H, W, C, rects, nvalid, poison, max_objs, reinterpret_cast<half_t*>(feat), ln_gamma,
+        ln_beta, reinterpret_cast<half_t*>(ln_out));
     GL_CHECK_LAUNCH();
     return 0;
 }

@@ -243,9 +243,11 @@ def groupnorm(x1: torch.Tensor, x2: Optional[torch.Tensor], B: int, HW: int, gam
 
 
 def layernorm(x: torch.Tensor, y: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, B: int, rows_in: int,
-              rows_out: Optional[int] = None, row_off: int = 0, eps: float = 1e-5, stats: Optional[torch.Tensor] = None) -> torch.Tensor:
+              rows_out: Optional[int] = None, row_off: int = 0, eps: float = 1e-5, stats: Optional[torch.Tensor] = None,
+              x2: Optional[torch.Tensor] = None, rows2: int = 0) -> torch.Tensor:
     """x [B*rows_in, C] fp16 or fp32 (residual stream) -> y fp16 rows b*rows_out + row_off + i (y is [B*rows_out, C]);
-    ``stats`` (optional fp32 [B*rows_in, 2]) receives (mean, rstd) per row."""
+    ``stats`` (optional fp32 [B*rows_in, 2]) receives (mean, rstd) per row.  ``x2`` (fp16 [B*rows2, C]): a second source
+    whose rows follow x's rows inside every sample's block of y ([x ; objs] in one launch)."""
     xf32 = x.dtype == F32
     _req(x, F32 if xf32 else F16, "x")
     _req(y, F16, "y")
@@ -258,18 +260,27 @@ def layernorm(x: torch.Tensor, y: torch.Tensor, gamma: torch.Tensor, beta: torch
         _req(stats, F32, "stats", 8)
         if stats.numel() < 2 * B * rows_in:
             raise ValueError("stats buffer too small")
+    ldx2 = 0
+    if x2 is not None:
+        _req(x2, F16, "x2")
+        ldx2 = _rows(x2, "x2")[2]
     check(_lib.lib().gl_layernorm(x.data_ptr(), ldx, int(xf32), y.data_ptr(), ldy, gamma.data_ptr(), beta.data_ptr(), B, rows_in,
-                                  rows_out, row_off, Cc, eps, _ptr(stats), _stream()), "gl_layernorm")
+                                  rows_out, row_off, Cc, eps, _ptr(stats), _ptr(x2), ldx2, rows2, _stream()), "gl_layernorm")
     return y
 
 
-def rela_pool(hid, B, H, W, Cc, rects, nvalid, poison, max_objs, feat):
+def rela_pool(hid, B, H, W, Cc, rects, nvalid, poison, max_objs, feat, ln_gamma=None, ln_beta=None, ln_out=None):
+    """feat[b, i] = mean of hid over box i; with ``ln_out`` also LayerNorm(feat) (fused norm1 of rela_fuse)."""
     _req(hid, F16, "hid")
     _req(feat, F16, "feat")
     for t, n in ((rects, "rects"), (nvalid, "nvalid"), (poison, "poison")):
         _req(t, torch.int32, n, 4)
+    if ln_out is not None:
+        _req(ln_out, F16, "ln_out")
+        _req(ln_gamma, F32, "ln_gamma")
+        _req(ln_beta, F32, "ln_beta")
     check(_lib.lib().gl_rela_pool(hid.data_ptr(), B, H, W, Cc, rects.data_ptr(), nvalid.data_ptr(), poison.data_ptr(),
-                                  max_objs, feat.data_ptr(), _stream()), "gl_rela_pool")
+                                  max_objs, feat.data_ptr(), _ptr(ln_gamma), _ptr(ln_beta), _ptr(ln_out), _stream()), "gl_rela_pool")
     return feat
 
 

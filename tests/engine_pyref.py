@@ -235,8 +235,7 @@ class PyRefEngine:
             f = t + ".fuser"
             rows = N + ((mo + 7) & ~7)          # same padding as engine.hip (pad rows are masked keys / unused queries)
             cat = self.buf("st.cat", (Bn * rows, C), zero=True)
-            ops.layernorm(x, cat, W[f + ".norm1.g"], W[f + ".norm1.b"], Bn, N, rows, 0)
-            ops.layernorm(c[f"objs.{li}"], cat, W[f + ".norm1.g"], W[f + ".norm1.b"], Bn, mo, rows, N)
+            ops.layernorm(x, cat, W[f + ".norm1.g"], W[f + ".norm1.b"], Bn, N, rows, 0, x2=c[f"objs.{li}"], rows2=mo)
             att = self._self_attention(cat, rows, N, N + mo, C, d, f + ".attn", "st.fa")
             x = ops.gemm(att, W[f + ".attn.o.w"], nxt(x), W[f + ".attn.o.b"], EPI_GATE_RES, res=x,
                          gate=self._gates[f + ".tanh_attn"])
@@ -248,8 +247,9 @@ class PyRefEngine:
         stats = self.buf("st.lnstats", (M, 2), F32)
         hid = ops.layernorm(x, self.buf("st.hid", (M, C)), W[r + ".norm3.g"], W[r + ".norm3.b"], Bn, N, stats=stats)
         Mo = Bn * mo
-        feat = ops.rela_pool(hid, Bn, side, side, C, rects, nvalid, poison, mo, self.buf("rl.feat", (Mo, C)))
-        fn = ops.layernorm(feat, self.buf("rl.ln", (Mo, C)), W[r + ".norm1.g"], W[r + ".norm1.b"], Bn, mo)
+        fn = self.buf("rl.ln", (Mo, C))
+        feat = ops.rela_pool(hid, Bn, side, side, C, rects, nvalid, poison, mo, self.buf("rl.feat", (Mo, C)),
+                             ln_gamma=W[r + ".norm1.g"], ln_beta=W[r + ".norm1.b"], ln_out=fn)
         q = ops.gemm(fn, W[r + ".attn.q.w"], self.buf("rl.q", (Mo, C)))
         kv = c[f"kvrel.{li}"]
         ar = self.buf("rl.att", (Mo, C))

@@ -482,6 +482,25 @@ def test_layernorm_fp32_stream_and_stats():
         assert torch.allclose(st[:, 0].cpu(), mean, rtol=1e-5, atol=1e-6) and torch.allclose(st[:, 1].cpu(), rstd, rtol=1e-5, atol=1e-6)
 
 
+def test_layernorm_two_sources_one_launch():
+    """[x (fp32 stream) ; objs (fp16)] normalised into the fuser's concat buffer by ONE launch == the two separate launches"""
+    B, N, mo, C = 2, 144, 30, 320
+    rows = N + 32
+    x = rnd("l2x", (B * N, C)) * 2 + 0.3
+    o, od = h16(rnd("l2o", (B * mo, C)))
+    gam, bet = (1 + 0.1 * rnd("l2g", (C,))).to(DEV), (0.1 * rnd("l2b", (C,))).to(DEV)
+    a = torch.zeros(B * rows, C, dtype=torch.float16, device=DEV)
+    b = torch.zeros(B * rows, C, dtype=torch.float16, device=DEV)
+    ops.layernorm(x.to(DEV), a, gam, bet, B, N, rows, 0)
+    ops.layernorm(od, a, gam, bet, B, mo, rows, N)
+    ops.layernorm(x.to(DEV), b, gam, bet, B, N, rows, 0, x2=od, rows2=mo)
+    assert torch.equal(a, b)
+    ref = torch.zeros(B, rows, C)
+    ref[:, :N] = F.layer_norm(x, (C,), gam.cpu(), bet.cpu(), 1e-5).view(B, N, C)
+    ref[:, N:N + mo] = F.layer_norm(o, (C,), gam.cpu(), bet.cpu(), 1e-5).view(B, mo, C)
+    check(b, ref.view(-1, C), "layernorm_two_sources")
+
+
 @pytest.mark.parametrize("C", [64, 320, 640, 1280])
 def test_layernorm(C):
     B, rows = 2, 100
@@ -536,6 +555,14 @@ def test_rela_pool_merge(C, hw):
             t, bo, l, r = [int(v) for v in rects[b, i]]
             ref[b, i] = hv[b, t:bo, l:r].reshape(-1, C).mean(0)
     check(feat, ref.view(B * mo, C), f"rela_pool_{C}_{hw}")
+    # fused norm1: LayerNorm of the fp16-rounded pooled row, bitwise equal to pool followed by gl_layernorm
+    gam, bet = (1 + 0.1 * rnd(f"rpg{C}", (C,))).to(DEV), (0.1 * rnd(f"rpb{C}", (C,))).to(DEV)
+    feat2, fn_fused = torch.empty_like(feat), torch.empty_like(feat)
+    ops.rela_pool(hidd, B, hw, hw, C, dr, dn, dp, mo, feat2, ln_gamma=gam, ln_beta=bet, ln_out=fn_fused)
+    fn_sep = ops.layernorm(feat, torch.empty_like(feat), gam, bet, B, mo)
+    assert torch.equal(feat2, feat)
+    check(fn_fused, F.layer_norm(feat.float().cpu(), (C,), gam.cpu(), bet.cpu(), 1e-5), f"rela_pool_ln_{C}_{hw}")
+    print("fused vs separate LN max diff", float((fn_fused.float() - fn_sep.float()).abs().max()))
     f, fd = h16(rnd(f"rf{C}", (B * mo, C)))
     y = torch.empty(B * hw * hw, C, dtype=torch.float16, device=DEV)
     ops.rela_merge(xd, hidd, fd, B, hw, hw, C, dr, dn, dp, mo, y)
@@ -596,8 +623,8 @@ def test_rela_fuse_reference_goldens_through_hip(name, hw):
     e16 = lambda *shape: torch.empty(*shape, dtype=torch.float16, device=DEV)
     st = torch.empty(B * N, 2, dtype=torch.float32, device=DEV)
     hid = ops.layernorm(xd, e16(B * N, C), dv(sd["norm3.weight"]), dv(sd["norm3.bias"]), B, N, stats=st)
-    feat = ops.rela_pool(hid, B, hw, hw, C, dr, dn, dp, mo, e16(B * mo, C))
-    fn = ops.layernorm(feat, e16(B * mo, C), dv(sd["norm1.weight"]), dv(sd["norm1.bias"]), B, mo)
+    fn = e16(B * mo, C)
+    feat = ops.rela_pool(hid, B, hw, hw, C, dr, dn, dp, mo, e16(B * mo, C), ln_gamma=dv(sd["norm1.weight"]), ln_beta=dv(sd["norm1.bias"]), ln_out=fn)
     q = ops.gemm(fn, hd(sd["attn.to_q.weight"]), e16(B * mo, C))
     kv = ops.gemm(hd(inp["relations"].reshape(B * R, -1)), hd(torch.cat([sd["attn.to_k.weight"], sd["attn.to_v.weight"]], 0)), e16(B * R, 2 * C))
     vt = torch.zeros(B, heads, d, ops.vt_ld(R), dtype=torch.float16, device=DEV)

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(l, name), f"{name} declared in gligen_hip.h but not exported"
     assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
-    assert l.gl_abi_version() == _lib.ABI_VERSION == 5
+    assert l.gl_abi_version() == _lib.ABI_VERSION == 6
     assert l.gl_sizeof_gemm_args() == ctypes.sizeof(_lib.GemmArgs)
     assert l.gl_sizeof_conv_args() == ctypes.sizeof(_lib.ConvArgs)
     assert l.gl_sizeof_attn_args() == ctypes.sizeof(_lib.AttnArgs)
@@ -91,7 +91,7 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert l.gl_gemm(ctypes.byref(g), None) == -1          # null pointers -> GL_ERR_BAD_ARG, no launch
     a = _lib.AttnArgs()
     assert l.gl_attention(ctypes.byref(a), None) == -1
-    assert l.gl_layernorm(None, 0, 0, None, 0, None, None, 1, 1, 1, 0, 64, 1e-5, None, None) == -1
+    assert l.gl_layernorm(None, 0, 0, None, 0, None, None, 1, 1, 1, 0, 64, 1e-5, None, None, 0, 0, None) == -1
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
