@@ -137,6 +137,12 @@ int gl_groupnorm_stats(const void* x1, int32_t C1, const void* x2, int32_t C2, i
 int gl_groupnorm_apply(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t B, int32_t HW,
                        const float* partial, int32_t nchunk, const float* gamma, const float* beta,
                        float eps, int32_t silu, void* out, void* stream);
+/* gl_groupnorm: the whole operator.  Small maps with C % 256 == 0 (the 16x16 / 8x8 levels) run as ONE launch that keeps a
+ * group's slab in registers (two-pass statistics); everything else as gl_groupnorm_stats + gl_groupnorm_apply (partial /
+ * nchunk are only used then).  gl_groupnorm_launches tells which (1 or 2). */
+int gl_groupnorm(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t B, int32_t HW, const float* gamma,
+                 const float* beta, float eps, int32_t silu, void* out, float* partial, int32_t nchunk, void* stream);
+int gl_groupnorm_launches(int32_t C, int32_t HW);
 
 /*
  * gl_layernorm: row LayerNorm eps 1e-5 over C (attention.py:216-217,292-294,369-371), fp32 statistics (two-pass).
@@ -319,7 +325,7 @@ int gl_sizeof_attn_args(void);
  * 3 always 8 waves, 4 always 4 waves); keys 4-7 = small-tile / split-K / 256-row-tile thresholds; key 8 = short-K GEGLU
  * GEMMs on the BK 32 / 4-blocks-per-CU variant (1 default, 0 off); key 10 = s_setprio around the attention MFMA
  * clusters (-1 auto, 0 off, 1 on); key 13 = intra-block K-split GEMM/conv variants (0 off, 1 auto = default, 2 always);
- * key 16 = GroupNorm apply pixels per block; key 20 = (tests) execute the gated-SA fuser even at fuser_scale 0;
+ * key 16 = GroupNorm apply pixels per block; key 17 = single-launch small-map GroupNorm (1 default, 0 off); key 20 = (tests) execute the gated-SA fuser even at fuser_scale 0;
  * key 21 = V^T written by the QKV GEMM epilogue (1, default) or by gl_transpose_v (0). */
 int gl_set_option(int key, int value);
 /* one-time per-process setup (raises dynamic-LDS limits of the tiled kernels); idempotent */

@@ -112,6 +112,8 @@ PROTOTYPES = {
     "gl_transpose_v": (i32, [vp, i64, i32, vp, i32, i32, i32, i32, i32, vp]),
     "gl_groupnorm_stats": (i32, [vp, i32, vp, i32, i32, i32, fp, i32, vp]),
     "gl_groupnorm_apply": (i32, [vp, i32, vp, i32, i32, i32, fp, i32, fp, fp, f32, i32, vp, vp]),
+    "gl_groupnorm": (i32, [vp, i32, vp, i32, i32, i32, fp, fp, f32, i32, vp, fp, i32, vp]),
+    "gl_groupnorm_launches": (i32, [i32, i32]),
     "gl_layernorm": (i32, [vp, i32, i32, vp, i32, fp, fp, i32, i32, i32, i32, i32, f32, fp, vp, i32, i32, vp]),
     "gl_rela_pool": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, fp, fp, vp, vp]),
     "gl_rela_merge": (i32, [vp, i32, vp, fp, fp, fp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp]),

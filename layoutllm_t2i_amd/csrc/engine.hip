@@ -411,9 +411,8 @@ struct Run {
         const int nchunk = gn_nchunk(HW);
         float* partial = e->f32("gn.partial", (size_t)B * nchunk * 64);
         CKP(partial);
-        launches += 2;
-        CK(gl_groupnorm_stats(x1, C1, x2, C2, B, HW, partial, nchunk, st));
-        return gl_groupnorm_apply(x1, C1, x2, C2, B, HW, partial, nchunk, e->Wf(p + ".g"), e->Wf(p + ".b"), eps, silu, out, st);
+        launches += gl_groupnorm_launches(C1 + C2, HW);
+        return gl_groupnorm(x1, C1, x2, C2, B, HW, e->Wf(p + ".g"), e->Wf(p + ".b"), eps, silu, out, partial, nchunk, st);
     }
     int attn(const half_t* q, int64_t qb, int ldq, const half_t* k, int64_t kb, int ldk, const half_t* vt, int ldvt, half_t* out,
              int64_t ob, int ldo, int B, int H, int d, int Nq, int Nk) {

@@ -240,6 +240,85 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
     }
 }
 
+// Small maps (the 16x16 / 8x8 levels: 1280- / 2560-channel tensors of 64..256 pixels): ONE launch, one block per (sample,
+// group).  The group's HW x (C/32) slab (<= 20 K elements) is loaded once into registers, reduced two-pass (mean, then
+// squared deviations: exact, no E[x^2] - mean^2 cancellation) and normalised from the registers -- instead of
+// gn_stats + gn_apply, which at these sizes are two latency-bound launches that each re-read the tensor.
+// Needs whole 8-channel vectors per group (C % 256 == 0) and HW * C / 256 <= 256 * NV vectors.
+template <int NV>
+__global__ __launch_bounds__(256) void gn_fused_kernel(const half_t* __restrict__ x1, int C1, const half_t* __restrict__ x2, int C2,
+                                                       int HW, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float eps, int silu, half_t* __restrict__ out) {
+    __shared__ float red[4];
+    const int C = C1 + C2;
+    const int cpg = C / 32;
+    const int nv = cpg / 8;
+    const int total = HW * nv;
+    const int g = blockIdx.x, b = blockIdx.y;
+    auto bsum = [&](float v) {
+        v = wave_sum(v);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        return red[0] + red[1] + red[2] + red[3];
+    };
+    uint4 raw[NV];
+    int chan[NV], pix[NV];
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int idx = threadIdx.x + 256 * k;
+        raw[k] = make_uint4(0u, 0u, 0u, 0u);
+        chan[k] = -1;
+        pix[k] = 0;
+        if (idx < total) {
+            const int p = idx / nv;
+            const int c = g * cpg + (idx - p * nv) * 8;
+            chan[k] = c;
+            pix[k] = p;
+            const half_t* src = (c < C1) ? x1 + ((size_t)b * HW + p) * C1 + c : x2 + ((size_t)b * HW + p) * C2 + (c - C1);
+            raw[k] = ld16(src);
+            const half8_t hv = *reinterpret_cast<half8_t*>(&raw[k]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += (float)hv[j];
+        }
+    }
+    const float n = (float)cpg * (float)HW;
+    const float mean = bsum(s) / n;
+    float ss = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        if (chan[k] >= 0) {
+            const half8_t hv = *reinterpret_cast<half8_t*>(&raw[k]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = (float)hv[j] - mean;
+                ss = fmaf(d, d, ss);
+            }
+        }
+    }
+    const float rstd = rsqrtf(bsum(ss) / n + eps);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        if (chan[k] >= 0) {
+            const int c = chan[k];
+            const float4 g0 = *reinterpret_cast<const float4*>(gamma + c), g1 = *reinterpret_cast<const float4*>(gamma + c + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(beta + c), b1 = *reinterpret_cast<const float4*>(beta + c + 4);
+            const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            const float bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            const half8_t hv = *reinterpret_cast<half8_t*>(&raw[k]);
+            half8_t ov;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = ((float)hv[j] - mean) * rstd * gm[j] + bt[j];
+                if (silu) v = silu_f(v);
+                ov[j] = (half_t)v;
+            }
+            st16(out + ((size_t)b * HW + pix[k]) * C + c, *reinterpret_cast<uint4*>(&ov));
+        }
+    }
+}
+
 // One wave per row; up to NV x 64 8-channel vectors per row.  XF32: the input row is fp32 (the residual stream), else
 // fp16.  Two-pass statistics in registers (mean, then sum of squared deviations).  Optionally stores (mean, rstd) per
 // input row so that a consumer can re-evaluate the normalisation in fp32 (rela_merge).
@@ -328,11 +407,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
 }
 
 int g_gn_ppb = 16;  // GroupNorm apply: pixels per pixel-lane per block (A/B knob 16)
+int g_gn_fused = 1; // A/B knob 17: single-launch GroupNorm for small maps
 
 }  // namespace
 
 extern "C" int gl_set_option_norm(int key, int value) {
     if (key == 16) { g_gn_ppb = value > 0 ? value : 16; return 0; }
+    if (key == 17) { g_gn_fused = value; return 0; }
     return GL_ERR_BAD_ARG;
 }
 
@@ -365,6 +446,36 @@ extern "C" int gl_groupnorm_apply(const void* x1, int32_t C1, const void* x2, in
         gamma, beta, eps, silu, reinterpret_cast<half_t*>(out), ppb);
     GL_CHECK_LAUNCH();
     return 0;
+}
+
+// how many launches gl_groupnorm issues for this shape: 1 (fused small-map kernel) or 2 (statistics + apply)
+extern "C" int gl_groupnorm_launches(int32_t C, int32_t HW) {
+    if (!g_gn_fused || (C % 256) != 0) return 2;
+    const int64_t vecs = (int64_t)HW * (C / 256);
+    return vecs <= 256 * 10 ? 1 : 2;
+}
+
+extern "C" int gl_groupnorm(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t B, int32_t HW, const float* gamma,
+                            const float* beta, float eps, int32_t silu, void* out, float* partial, int32_t nchunk, void* stream) {
+    const int C = C1 + (x2 ? C2 : 0);
+    if (!x1 || !gamma || !beta || !out || C <= 0 || (C % 32) || (C1 % 8) || (x2 && (C2 % 8))) return GL_ERR_BAD_ARG;
+    if (gl_groupnorm_launches(C, HW) == 1) {
+        const int64_t vecs = (int64_t)HW * (C / 256);
+        const dim3 grid(32, B), blk(256);
+        const half_t* a = reinterpret_cast<const half_t*>(x1);
+        const half_t* b2 = reinterpret_cast<const half_t*>(x2);
+        half_t* o = reinterpret_cast<half_t*>(out);
+        hipStream_t st = (hipStream_t)stream;
+        if (vecs <= 256 * 3) gn_fused_kernel<3><<<grid, blk, 0, st>>>(a, C1, b2, x2 ? C2 : 0, HW, gamma, beta, eps, silu, o);
+        else if (vecs <= 256 * 5) gn_fused_kernel<5><<<grid, blk, 0, st>>>(a, C1, b2, x2 ? C2 : 0, HW, gamma, beta, eps, silu, o);
+        else gn_fused_kernel<10><<<grid, blk, 0, st>>>(a, C1, b2, x2 ? C2 : 0, HW, gamma, beta, eps, silu, o);
+        GL_CHECK_LAUNCH();
+        return 0;
+    }
+    if (!partial || nchunk <= 0) return GL_ERR_BAD_ARG;
+    const int rc = gl_groupnorm_stats(x1, C1, x2, C2, B, HW, partial, nchunk, stream);
+    if (rc != 0) return rc;
+    return gl_groupnorm_apply(x1, C1, x2, C2, B, HW, partial, nchunk, gamma, beta, eps, silu, out, stream);
 }
 
 extern "C" int gl_layernorm(const void* x, int32_t ldx, int32_t x_f32, void* y, int32_t ldy, const float* gamma,

@@ -234,11 +234,8 @@ def groupnorm(x1: torch.Tensor, x2: Optional[torch.Tensor], B: int, HW: int, gam
     nchunk = gn_nchunk(HW)
     if partial.numel() < B * nchunk * 64:
         raise ValueError("partial buffer too small")
-    l = _lib.lib()
-    check(l.gl_groupnorm_stats(x1.data_ptr(), C1, _ptr(x2), C2, B, HW, partial.data_ptr(), nchunk, _stream()),
-          "gl_groupnorm_stats")
-    check(l.gl_groupnorm_apply(x1.data_ptr(), C1, _ptr(x2), C2, B, HW, partial.data_ptr(), nchunk, gamma.data_ptr(),
-                               beta.data_ptr(), eps, int(silu), out.data_ptr(), _stream()), "gl_groupnorm_apply")
+    check(_lib.lib().gl_groupnorm(x1.data_ptr(), C1, _ptr(x2), C2, B, HW, gamma.data_ptr(), beta.data_ptr(), eps, int(silu),
+                                  out.data_ptr(), partial.data_ptr(), nchunk, _stream()), "gl_groupnorm")
     return out
 
 

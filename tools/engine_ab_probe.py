@@ -1,6 +1,8 @@
-"""Same-box A/B on the GPU box: forward time of the C++ engine (gl_unet_forward, engine-owned hipGraph) vs the Python
-launch sequence of tests/engine_pyref.py (torch-captured graph) on the full model, interleaved rounds.
-    python tools/engine_ab_probe.py [B]"""
+"""Same-box, same-process A/B on the GPU box: forward time of the C++ engine (gl_unet_forward, hipGraph replay) on the full
+model under different gl_set_option settings, interleaved rounds; optionally also the Python launch sequence of
+tests/engine_pyref.py (torch-captured graph) as a cross-check of the orchestration cost.
+    python tools/engine_ab_probe.py [B] [variant ...]      variant = name:key=value[,key=value...]   e.g.  nofusedgn:17=0
+"""
 import os
 import sys
 
@@ -9,31 +11,46 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from engine_pyref import PyRefEngine
-from layoutllm_t2i_amd import recipe
+from layoutllm_t2i_amd import ops, recipe
 from layoutllm_t2i_amd.arch import UNetConfig
 from layoutllm_t2i_amd.engine import UNetEngine
 from layoutllm_t2i_amd.weights import pack_state_dict, random_state_dict
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+args = sys.argv[1:]
+B = int(args[0]) if args and args[0].isdigit() else 4
+variants = [("default", [])]
+for v in args[1:] if args and args[0].isdigit() else args:
+    if v == "pyref":
+        variants.append(("pyref", None))
+        continue
+    name, kv = v.split(":")
+    variants.append((name, [tuple(int(t) for t in p.split("=")) for p in kv.split(",")]))
 dev = torch.device("cuda:0")
 cfg = UNetConfig()
 P = pack_state_dict(random_state_dict(cfg, dev, seed=0), cfg, dev, recipe.sd_first_conv(cfg, 0))
 inp = {k: torch.from_numpy(v) for k, v in recipe.synth_inputs(cfg, B, 64, n_boxes=8, n_rel=3, seed=1).items()}
 z = torch.zeros_like
 cat = lambda a, b: torch.cat([a, b], 0)
-engines = {"cpp": UNetEngine(P), "pyref": PyRefEngine(P)}
+eng = UNetEngine(P)
+engines = {"cpp": eng}
+if any(o is None for _, o in variants):
+    from engine_pyref import PyRefEngine
+    engines["pyref"] = PyRefEngine(P)
 x = inp["x"].to(dev)
 for e in engines.values():
     e.set_conditioning(cat(inp["context"], inp["uc"]), cat(inp["relations"], inp["relations"]), cat(inp["boxes"], z(inp["boxes"])),
                        cat(inp["masks"], z(inp["masks"])), cat(inp["positive_embeddings"], z(inp["positive_embeddings"])), 64)
-    for fs in (1.0, 0.0):
-        e.forward(x, 481.0, fs, False, 2)
-torch.cuda.synchronize()
-res = {k: {1.0: [], 0.0: []} for k in engines}
-for rnd in range(6):
-    for name, e in engines.items():
+DEFAULTS = {17: 1, 21: 1, 13: 1, 7: 300, 8: 1, 5: -1, 3: 0, 10: -1, 2: 0, 4: 400}
+res = {n: {1.0: [], 0.0: []} for n, _ in variants}
+launches = {}
+for rnd in range(5):
+    for name, opts in variants:
+        e = engines["pyref"] if opts is None else eng
+        for k, v in (opts or []):
+            ops.set_option(k, v)
         for fs in (1.0, 0.0):
+            e.forward(x, 481.0, fs, False, 2)          # (re-)capture under these options
+            torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(10):
@@ -41,8 +58,12 @@ for rnd in range(6):
             e1.record()
             torch.cuda.synchronize()
             res[name][fs].append(e0.elapsed_time(e1) / 10)
-for name in engines:
+        if opts is not None:
+            launches[name] = eng.num_launches()
+        for k, _ in (opts or []):
+            ops.set_option(k, DEFAULTS[k])
+for name, _ in variants:
     for fs in (1.0, 0.0):
         v = sorted(res[name][fs])
-        print(f"{name:6s} fuser={'on ' if fs else 'off'} 2B={2 * B}: median {v[len(v) // 2]:.3f} ms  min {v[0]:.3f}  all {[round(t, 2) for t in res[name][fs]]}")
-print("launches per forward (cpp, last variant run):", engines["cpp"].num_launches())
+        print(f"{name:12s} fuser={'on ' if fs else 'off'} 2B={2 * B}: median {v[len(v) // 2]:.3f} ms  min {v[0]:.3f}  all {[round(t, 2) for t in res[name][fs]]}")
+print("launches per fuser-off forward:", launches)
