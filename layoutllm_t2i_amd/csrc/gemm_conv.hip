@@ -33,7 +33,8 @@ __device__ uint4 g_zero16[4];
 
 namespace {
 
-int g_opt_ksplit = 1;        // intra-block K-split variants (64-row wave tiles): 0 off, 1 auto (long K), 2 always
+int g_opt_ksplit = 3;        // intra-block K-split variants (64-row wave tiles): 0 off, 1 convs + long-K GEMMs, 2 always, 3 convs only
+                             // (default: same-box full-forward A/B, profiles/r2_ab_dispatch_knobs.txt: the plain-GEMM use costs 0.1 ms), 4 GEMMs only
 int g_opt_geglu32 = 1;       // 1 = short-K GEGLU GEMMs use the 4-blocks/CU BK 32 variant
 int g_opt_big = 300;         // problems with >= this many 256-row tiles use the 256-row variant (B=4: neutral; B=16: +5-7 %); 0 = off
 int g_opt_small = 400;       // use 64x128 tiles when the 128-row grid has fewer tiles than this (0 = never)
@@ -685,7 +686,9 @@ int dispatch_shape(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
             const int nk = g.K / 64;
             bool use = (g_opt_ksplit == 2);
             // (128-wide conv tiles only occur in the VAE decoder, M = 0.26-1 M pixels x 128/256 channels: measured 2 % slower)
-            if (g_opt_ksplit == 1) use = CONV ? (shape == 1 && nk >= 20) : (nk >= 16);
+            if (g_opt_ksplit == 1 || g_opt_ksplit == 3 || g_opt_ksplit == 4) use = CONV ? (shape == 1 && nk >= 20) : (nk >= 16);
+            if (g_opt_ksplit == 3 && !CONV) use = false;      // A/B: convs only
+            if (g_opt_ksplit == 4 && CONV) use = false;       // A/B: plain GEMMs only
             if (use) {
                 if (shape == 1) return launch<128, 160, 2, 1, CONV, 64, 2>(g, cg, st);
                 return launch<128, 128, 2, 1, CONV, 64, 2>(g, cg, st);
@@ -703,7 +706,7 @@ int dispatch_shape(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
         if constexpr (!CONV) {
             // K-split for the small-tile shape too (64x64 instead of 32x64 wave tiles): 22.4 -> 20.4 us at
             // M = 2048, N = K = 1280; neutral at K = 640, which stays on the plain kernel
-            if (shape == 3 && (g_opt_ksplit == 2 || (g_opt_ksplit == 1 && g.K >= 1024)))
+            if (shape == 3 && (g_opt_ksplit == 2 || ((g_opt_ksplit == 1 || g_opt_ksplit == 4 || g_opt_ksplit == 5) && g.K >= 1024)))
                 return launch<64, 128, 1, 2, false, 64, 2>(g, cg, st);
         }
         if (shape == 3) return launch<64, 128, 2, 2, CONV, 64>(g, cg, st);

@@ -170,7 +170,7 @@ def test_gemm_conv_ksplit_variant():
         test_conv3x3("s1", 1280, 1280, 8)
         test_conv3x3_epilogues()
     finally:
-        ops.set_option(13, 1)
+        ops.set_option(13, 3)
 
 
 @pytest.mark.parametrize("M,N,K", [(700, 320, 640), (512, 1280, 5120), (130, 640, 2048), (8192, 640, 640)])
