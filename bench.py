@@ -57,6 +57,7 @@ def parse():
                     help="also run BASELINE configs[0] end to end on the CPU oracle (S=10, 22 forwards, ~2 min)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tiny", action="store_true", help="debug: tiny UNet (not a valid benchmark)")
+    ap.add_argument("--no-hot-kernel", action="store_true", help="skip the standalone timing of the hottest kernel shape (PMC passes)")
     ap.add_argument("--no-vae", action="store_true", help="stop at the final latent (exclude the VAE decode stage from the step)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
                     help="gl_set_option tuning knob for same-box A/B runs (see include/gligen_hip.h), repeatable")
@@ -247,9 +248,9 @@ def main():
                 "flops_per_launch": round(flops / max(n_fwd, 1)), "flop_model": "SURVEY 8d minimal (32 F_full + 70 F_off per image at S=50; F_full=%.4f, F_off=%.4f TFLOP/sample-forward at this latent)" % (F_FULL / 1e12, F_OFF / 1e12)}
 
     # ---- the single hottest kernel shape, timed standalone with HIP events on the launch stream: the implicit-GEMM
-    # 3x3 conv 320 -> 320 at the 64x64 level of the 2B batch (gemm_kernel<128,160,2,1,true,64,2,2>, 7 launches per forward;
-    # that instantiation is the top line of profiles/r1_kernel_stats.csv, where its average covers all conv shapes)
-    if rank == 0 and side == 64 and not args.tiny:
+    # 3x3 conv 320 -> 320 at the 64x64 level of the 2B batch (gemm_kernel<128,160,2,1,true,64,2>, 7 launches per forward;
+    # that instantiation is the top line of profiles/r2_kernel_stats.csv, where its average covers all conv shapes)
+    if rank == 0 and side == 64 and not args.tiny and not args.no_hot_kernel:
         from layoutllm_t2i_amd import ops as _o
         Bn = 2 * B
         xa = torch.randn(Bn * side * side, 320, device=dev).to(torch.float16)
@@ -268,7 +269,7 @@ def main():
         k_us = k0.elapsed_time(k1) / nrep * 1e3
         k_flops = 2.0 * Bn * side * side * 320 * 9 * 320
         k_tf = k_flops / (k_us * 1e-6) / 1e12
-        roofline["hot_kernel"] = {"kernel": "gemm_kernel<128,160,2,1,true,64,2,2> as 3x3 conv 320->320 @64x64, 2B=%d" % Bn,
+        roofline["hot_kernel"] = {"kernel": "gemm_kernel<128,160,2,1,true,64,2> as 3x3 conv 320->320 @64x64, 2B=%d" % Bn,
                                   "avg_us": round(k_us, 1), "flops": k_flops, "achieved": round(k_tf, 1), "unit": "TFLOP/s",
                                   "frac": round(k_tf / MFMA_PEAK_TFLOPS, 4), "launches_per_forward": 7}
         del xa, wa, oa
