@@ -41,6 +41,7 @@ int g_opt_small = 400;       // use 64x128 tiles when the 128-row grid has fewer
 int g_opt_splitk_tiles = 300; // split K only below this many tiles (plain GEMM) ...
 int g_opt_splitk_tiles_conv = 450; // ... (conv)
 int g_opt_splitk_nk = 16;    // ... and at least this many 64-wide K tiles
+int g_opt_order = 1;         // tile order: 0 = N-tiles fastest, 1 = M-tiles fastest when the weights are the larger operand, 2 = always M
 int g_opt_tile = 0;          // 0 = auto; 1 = force 128x128 (N >= 256); 2 = prefer 128x160 whenever N % 160 == 0
 
 struct ConvGeom {
@@ -135,7 +136,7 @@ __device__ __forceinline__ void finish8(const gl_gemm_args& p, float gate, int m
 // the LDS-DMA writes and the fragment reads, is what bounds the main loop (loop ablation).  The two
 // partial accumulators are exchanged through LDS in the epilogue: each wave ends up finalising 32 rows.
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, int BKT, int WK = 1>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT, WK>())) void gemm_kernel(gl_gemm_args p, ConvGeom cg, int splitk, int kt_per_split) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT, WK>())) void gemm_kernel(gl_gemm_args p, ConvGeom cg, int splitk, int kt_per_split, int order_m) {
     constexpr int NTHR = 64 * WAVES_M * WAVES_N * WK;
     constexpr int TM = BM / WAVES_M / 32;
     constexpr int TN = BN / WAVES_N / 32;
@@ -175,9 +176,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
         const int xcd = bid & 7, local = bid >> 3;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
     }
-    const int tm = tile / nt;
+    // N-tiles fastest by default: the tiles sharing an A panel run on one XCD.  When the WEIGHTS are the larger operand (the
+    // 16x16 / 8x8 levels: 30-59 MB of conv weights against a few MB of activations) M-tiles go fastest instead, so that an
+    // XCD owns a contiguous range of N and streams only ITS slice of the weights into its L2 (order_m).
+    const int mt_ = (M + BM - 1) / BM;
+    const int tm = order_m ? tile % mt_ : tile / nt;
     const int m0 = tm * BM;
-    const int n0 = (tile - tm * nt) * BN;
+    const int n0 = (order_m ? tile / mt_ : tile - tm * nt) * BN;
     const int kt_begin = blockIdx.z * kt_per_split;
     const int kt_end = min(K / BKT, kt_begin + kt_per_split);
     const int nkt = kt_end - kt_begin;
@@ -645,7 +650,9 @@ int launch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     const int zs = gl_cdiv(nk, kper);          // slices that actually have work
     dim3 grid(mt * nt, 1, zs);
     constexpr int lds = lds_bytes<BM, BN, BKT, WM * WN * WK>();
-    gemm_kernel<BM, BN, WM, WN, CONV, BKT, WK><<<grid, dim3(64 * WM * WN * WK), lds, st>>>(g, cg, zs, kper);
+    // weights (N x K) larger than the activations they meet (M x K, or M x K / 9 distinct bytes for a conv)?
+    const int order_m = g_opt_order == 1 ? ((CONV ? 9L : 1L) * g.N > (long)g.M) : (g_opt_order == 2);
+    gemm_kernel<BM, BN, WM, WN, CONV, BKT, WK><<<grid, dim3(64 * WM * WN * WK), lds, st>>>(g, cg, zs, kper, order_m);
     GL_CHECK_LAUNCH();
     if (zs > 1) {
         const size_t total = (size_t)g.M * (g.N / 8);
@@ -808,6 +815,7 @@ extern "C" int gl_set_option_gemm(int key, int value) {
     if (key == 7) { g_opt_big = value; return 0; }
     if (key == 8) { g_opt_geglu32 = value; return 0; }
     if (key == 13) { g_opt_ksplit = value; return 0; }
+    if (key == 23) { g_opt_order = value; return 0; }
     if (key == 5) { g_opt_splitk_tiles = value < 0 ? 300 : value; g_opt_splitk_tiles_conv = value < 0 ? 450 : value; return 0; }   // < 0: defaults
     if (key == 6) { g_opt_splitk_nk = value; return 0; }
     return GL_ERR_BAD_ARG;
