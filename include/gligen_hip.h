@@ -328,7 +328,8 @@ int gl_sizeof_attn_args(void);
  * key 16 = GroupNorm apply pixels per block; key 17 = single-launch small-map GroupNorm (1 default, 0 off); key 20 = (tests) execute the gated-SA fuser even at fuser_scale 0;
  * key 21 = V^T written by the QKV GEMM epilogue (1, default) or by gl_transpose_v (0); key 23 = output-tile order (0 N-tiles
  * fastest, 1 = default: M-tiles fastest when the weight matrix is the larger operand, so each XCD's L2 streams only its
- * slice of the weights, 2 always M-fastest). */
+ * slice of the weights, 2 always M-fastest); key 24 = skinny-GEMM kernel (M <= 1024 rows, register operands, four waves split
+ * K) while its operand re-reads stay below this many MiB (64 default, 0 = LDS-staged kernels only). */
 int gl_set_option(int key, int value);
 /* one-time per-process setup (raises dynamic-LDS limits of the tiled kernels); idempotent */
 int gl_init(void);

@@ -41,6 +41,7 @@ int g_opt_small = 400;       // use 64x128 tiles when the 128-row grid has fewer
 int g_opt_splitk_tiles = 300; // split K only below this many tiles (plain GEMM) ...
 int g_opt_splitk_tiles_conv = 450; // ... (conv)
 int g_opt_splitk_nk = 16;    // ... and at least this many 64-wide K tiles
+int g_opt_skinny = 64;       // skinny-GEMM kernel while its operand re-reads stay below this many MiB (0 = off)
 int g_opt_order = 1;         // tile order: 0 = N-tiles fastest, 1 = M-tiles fastest when the weights are the larger operand, 2 = always M
 int g_opt_tile = 0;          // 0 = auto; 1 = force 128x128 (N >= 256); 2 = prefer 128x160 whenever N % 160 == 0
 
@@ -624,6 +625,76 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(gl_gemm_args p, int 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Skinny GEMM (M <= ~1000 rows: the 30-slot relation / grounding-token chains, the timestep MLP).  With 4-20 tiles
+// of the LDS-staged kernel these problems are pure latency: every K-step of its 2-stage ring exposes one cold
+// HBM / cross-XCD round trip (12-18 us for a 240 x 320 x 320 product).  Here a block owns one 32 x 32 output tile,
+// its four waves split K, and each wave loads its MFMA operand fragments straight from global memory into registers
+// -- up to 20 k-steps (K = 1280 per block) in flight at once, no LDS staging, no barrier in the loop: one round trip.
+// The four partial tiles are added in wave order through LDS (deterministic), then the shared finish8 epilogue.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int SK_BATCH = 20;            // k-steps of 16 whose operand loads are issued back to back (160 VGPRs)
+constexpr int SK_RS = 36;               // fp32 row stride of a staged partial tile
+
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(gl_gemm_args p) {
+    __shared__ __attribute__((aligned(16))) float part[4][32 * SK_RS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+    const int M = p.M, K = p.K;
+    const int steps = K / 64;                                   // k-steps of 16 per wave (K % 64 == 0)
+    const int kw = wave * steps * 16;                           // this wave's K slice
+    int mr = m0 + (lane & 31);
+    if (mr >= M) mr = M - 1;                                    // ragged last tile: clamp (rows discarded below)
+    const half_t* ap = reinterpret_cast<const half_t*>(p.a) + (size_t)mr * p.lda + kw + 8 * (lane >> 5);
+    const half_t* wp = reinterpret_cast<const half_t*>(p.w) + (size_t)(n0 + (lane & 31)) * K + kw + 8 * (lane >> 5);
+    f32x16 acc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+    for (int s0 = 0; s0 < steps; s0 += SK_BATCH) {
+        uint4 af[SK_BATCH], wf[SK_BATCH];
+#pragma unroll
+        for (int j = 0; j < SK_BATCH; ++j)
+            if (s0 + j < steps) {
+                af[j] = ld16(ap + (s0 + j) * 16);
+                wf[j] = ld16(wp + (s0 + j) * 16);
+            }
+#pragma unroll
+        for (int j = 0; j < SK_BATCH; ++j)
+            if (s0 + j < steps)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8_t*>(&wf[j]), *reinterpret_cast<half8_t*>(&af[j]), acc, 0, 0, 0);
+    }
+    // lane holds row m = lane & 31, columns 8 * rg + 4 * (lane >> 5) + {0..3}
+    float* mine = part[wave] + (lane & 31) * SK_RS + 4 * (lane >> 5);
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg)
+        *reinterpret_cast<float4*>(mine + 8 * rg) = make_float4(acc[rg * 4], acc[rg * 4 + 1], acc[rg * 4 + 2], acc[rg * 4 + 3]);
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int r = threadIdx.x >> 2, c = (threadIdx.x & 3) * 8;
+        const int m = m0 + r;
+        if (m < M) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = part[0][r * SK_RS + c + j];
+#pragma unroll
+            for (int w = 1; w < 4; ++w)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += part[w][r * SK_RS + c + j];
+            float gate = 1.0f;
+            if (p.epi == GL_EPI_GATE_RES) gate = p.gate[0];
+            finish8(p, gate, m, n0 + c, v);
+        }
+    }
+}
+
+// rows x (N / 32) tiles, every tile streams (32 + 32) x K operand halves: worth it while that stays cache-sized
+inline bool skinny_ok(const gl_gemm_args& g) {
+    if (!g_opt_skinny || g.M > 1024 || (g.N % 32) != 0 || g.epi == GL_EPI_GEGLU || g.vt != nullptr || g.a2 != nullptr) return false;
+    if (g.out_mode == GL_OUT_F32_NCHW || (g.lda % 8) != 0) return false;
+    const long tiles = (long)gl_cdiv(g.M, 32) * (g.N / 32);
+    return tiles * 64L * g.K * 2L <= (long)g_opt_skinny << 20;
+}
+
 // How many K slices: only when the tile grid underfills the chip and K is long enough to amortise
 // the fp32 partial round trip.
 inline int choose_splitk(const gl_gemm_args& g, int tiles, bool conv) {
@@ -752,6 +823,11 @@ int dispatch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     // one block's epilogue overlaps the others' main loops (measured 150 -> 135 us and 109 -> 100 us; long-K
     // GEMMs and convs lose 10-20 % to the doubled barrier count, so they stay on BK 64)
     if constexpr (!CONV) {
+        if (skinny_ok(g)) {
+            gemm_skinny_kernel<<<dim3(g.N / 32, gl_cdiv(g.M, 32)), dim3(256), 0, st>>>(g);
+            GL_CHECK_LAUNCH();
+            return 0;
+        }
         if (g_opt_geglu32 && g.epi == GL_EPI_GEGLU && g.K <= 640 && g.a2 == nullptr) return dispatch_shape<false, 32>(g, cg, st);
     }
     return dispatch_shape<CONV, 64>(g, cg, st);
@@ -816,6 +892,7 @@ extern "C" int gl_set_option_gemm(int key, int value) {
     if (key == 8) { g_opt_geglu32 = value; return 0; }
     if (key == 13) { g_opt_ksplit = value; return 0; }
     if (key == 23) { g_opt_order = value; return 0; }
+    if (key == 24) { g_opt_skinny = value; return 0; }
     if (key == 5) { g_opt_splitk_tiles = value < 0 ? 300 : value; g_opt_splitk_tiles_conv = value < 0 ? 450 : value; return 0; }   // < 0: defaults
     if (key == 6) { g_opt_splitk_nk = value; return 0; }
     return GL_ERR_BAD_ARG;

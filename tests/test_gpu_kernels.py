@@ -102,6 +102,52 @@ def test_gemm_geglu(C):
     check(out, x * F.gelu(g), f"gemm_geglu_{C}")
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(240, 320, 320, "bias"), (240, 320, 320, "gate"), (240, 1280, 1280, "gate"), (240, 640, 2560, "gate"),
+                                       (8, 1280, 320, "silu"), (8, 1280, 1280, "bias"), (120, 320, 1280, "res32"), (960, 320, 320, "res"),
+                                       (33, 64, 64, "bias")])
+def test_gemm_skinny(M, N, K, epi):
+    """M <= ~1000 rows (the 30-slot relation chain: 240 rows at B = 4; the timestep MLP: 8 rows): register-operand kernel,
+    32 x 32 tile per block, four waves split K (gl_set_option(24, MiB) bounds its use; 0 = LDS-staged kernels only).
+    Checked against torch fp32 AND against the LDS-staged kernel on the same inputs; rows past M stay untouched."""
+    a, ad = h16(rnd(f"sa{M}{K}", (M, K)))
+    w, wd = h16(rnd(f"sw{N}{K}", (N, K), 1 / math.sqrt(K)))
+    b = rnd(f"sb{N}", (N,), 0.1)
+    r, rd = h16(rnd(f"sr{M}{N}", (M, N)))
+    base = F.linear(a, w, b)
+    gate = torch.tensor([0.61], dtype=torch.float32, device=DEV)
+
+    def run(out):
+        if epi == "bias":
+            ops.gemm(ad, wd, out[:M], b.to(DEV))
+            return base
+        if epi == "silu":
+            ops.gemm(ad, wd, out[:M], b.to(DEV), EPI_SILU)
+            return F.silu(base)
+        if epi == "res":
+            ops.gemm(ad, wd, out[:M], b.to(DEV), EPI_RES, res=rd)
+            return base + r
+        if epi == "gate":
+            ops.gemm(ad, wd, out[:M], b.to(DEV), EPI_GATE_RES, res=rd, gate=gate)
+            return r + 0.61 * base
+        r32 = rnd(f"sr32{M}{N}", (M, N)) * 3.0 + 1.7
+        ops.gemm(ad, wd, out[:M], b.to(DEV), EPI_RES, res=r32.to(DEV))
+        return base + r32
+
+    dt = torch.float32 if epi == "res32" else torch.float16
+    out = torch.full((M + 40, N), 7.0, dtype=dt, device=DEV)
+    ref = run(out)
+    check(out[:M], ref, f"gemm_skinny_{M}x{N}x{K}_{epi}")
+    assert float((out[M:] - 7.0).abs().max()) == 0.0, "rows past M were written"
+    ops.set_option(24, 0)
+    try:
+        out2 = torch.full((M + 40, N), 7.0, dtype=dt, device=DEV)
+        run(out2)
+    finally:
+        ops.set_option(24, 64)
+    d = float((out[:M].float() - out2[:M].float()).norm() / out2[:M].float().norm())
+    assert d < 5e-4, d          # same fp16 operands, fp32 accumulation in another order
+
+
 @pytest.mark.parametrize("M,N,K,epi", [(512, 1280, 5120, "res"), (512, 1280, 2560, "bias"), (2048, 1280, 5120, "gate"), (100, 640, 2048, "rowbias")])
 def test_gemm_split_k(M, N, K, epi):
     """few output tiles + long K -> the launcher cuts K into slices (fp32 partials + reduce/epilogue kernel)."""
@@ -111,6 +157,7 @@ def test_gemm_split_k(M, N, K, epi):
     r, rd = h16(rnd(f"skr{M}{N}", (M, N)))
     out = torch.empty(M, N, dtype=torch.float16, device=DEV)
     base = F.linear(a, w, b)
+    ops.set_option(24, 0)               # keep the small-M case on the LDS-staged kernel this test is about
     if epi == "res":
         ops.gemm(ad, wd, out, b.to(DEV), EPI_RES, res=rd)
         ref = base + r
@@ -125,6 +172,7 @@ def test_gemm_split_k(M, N, K, epi):
     else:
         ops.gemm(ad, wd, out, b.to(DEV))
         ref = base
+    ops.set_option(24, 64)
     check(out, ref, f"gemm_splitk_{M}x{N}x{K}_{epi}")
 
 
@@ -132,6 +180,7 @@ def test_gemm_conv_256row_variant():
     """the 256-row kernels (4 waves x 64-row wave tiles, BK 32) forced everywhere via gl_set_option(7, 1); by default they
     serve problems with >= 300 such tiles (the 2B = 32 batch of configs[4])"""
     ops.set_option(7, 1)
+    ops.set_option(24, 0)
     try:
         test_gemm_bias(512, 1280, 640)
         test_gemm_bias(1024, 960, 320)
@@ -146,12 +195,14 @@ def test_gemm_conv_256row_variant():
         test_conv3x3_epilogues()
     finally:
         ops.set_option(7, 300)      # library default
+        ops.set_option(24, 64)
 
 
 def test_gemm_conv_ksplit_variant():
     """intra-block K-split kernels (gl_set_option(13, 2) forces them everywhere; 1 = the default per-shape rule): 64-row wave tiles, partial accumulators exchanged in the
     epilogue; includes split-K + K-split (extra workspace slices) and ragged M / N edges"""
     ops.set_option(13, 2)
+    ops.set_option(24, 0)
     try:
         test_gemm_bias(512, 1280, 640)
         test_gemm_bias(300, 320, 320)
@@ -171,6 +222,7 @@ def test_gemm_conv_ksplit_variant():
         test_conv3x3_epilogues()
     finally:
         ops.set_option(13, 3)
+        ops.set_option(24, 64)
 
 
 @pytest.mark.parametrize("M,N,K", [(700, 320, 640), (512, 1280, 5120), (130, 640, 2048), (8192, 640, 640)])
@@ -219,10 +271,12 @@ def test_gemm_qkv_writes_v_transposed(B, rows, C, H):
     w, wd = h16(rnd(f"vtw{C}", (3 * C, C), 1 / math.sqrt(C)))
     plain = torch.empty(M, 3 * C, dtype=torch.float16, device=DEV)
     ops.set_option(5, 0)            # the fused form never splits K: compare with the unsplit plain GEMM (same fp32 summation order)
+    ops.set_option(24, 0)           # ... on the LDS-staged kernel (the skinny kernel splits K over its four waves)
     try:
         ops.gemm(ad, wd, plain)
     finally:
         ops.set_option(5, -1)
+        ops.set_option(24, 64)
     fused = torch.full((M, 3 * C), float("nan"), dtype=torch.float16, device=DEV)
     vt = torch.full((B, H, d, ops.vt_ld(rows)), float("nan"), dtype=torch.float16, device=DEV)     # NaN pads on purpose
     ops.gemm(ad, wd, fused, vt=vt, vt_col0=2 * C, vt_rows=rows)
