@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GL_ABI_VERSION 6
+#define GL_ABI_VERSION 7
 
 /* error codes (negative; positive values are hipError_t) */
 #define GL_ERR_BAD_ARG (-1)
@@ -167,7 +167,9 @@ int gl_layernorm(const void* x, int32_t ldx, int32_t x_f32, void* y, int32_t ldy
  *   gl_rela_merge : y = 0.5 * (x + hid + (1/max_objs) * sum_i 1[p in rect_i] f[b, i, :])
  *                   x / y fp32 when x_f32 != 0 (residual stream) else fp16.  hid = LayerNorm3(x) is either read (fp16,
  *                   ln_stats == NULL) or re-evaluated in fp32 from ln_stats = gl_layernorm's (mean, rstd) rows and
- *                   gamma / beta, so that it enters the stream unrounded.
+ *                   gamma / beta, so that it enters the stream unrounded.  With ln2_out != NULL (fp32 stream + ln_stats
+ *                   form only, max_objs <= 32) the same launch also writes ln2_out = LayerNorm(y; ln2_gamma, ln2_beta,
+ *                   eps 1e-5) in fp16 -- the norm2 in front of attn2 (attention.py:400) -- bit-identical to gl_layernorm(y).
  */
 int gl_rela_pool(const void* hid, int32_t B, int32_t H, int32_t W, int32_t C, const int32_t* rects,
                  const int32_t* nvalid, const int32_t* poison, int32_t max_objs, void* feat, const float* ln_gamma,
@@ -175,7 +177,7 @@ int gl_rela_pool(const void* hid, int32_t B, int32_t H, int32_t W, int32_t C, co
 int gl_rela_merge(const void* x, int32_t x_f32, const void* hid, const float* ln_stats, const float* gamma,
                   const float* beta, const void* f, int32_t B, int32_t H, int32_t W, int32_t C,
                   const int32_t* rects, const int32_t* nvalid, const int32_t* poison, int32_t max_objs,
-                  void* y, void* stream);
+                  void* y, const float* ln2_gamma, const float* ln2_beta, void* ln2_out, void* stream);
 
 /*
  * gl_posnet_input: builds the PositionNet MLP input (text_grounding_net.py:30-41, util.py:12-26):
@@ -329,7 +331,8 @@ int gl_sizeof_attn_args(void);
  * key 21 = V^T written by the QKV GEMM epilogue (1, default) or by gl_transpose_v (0); key 23 = output-tile order (0 N-tiles
  * fastest, 1 = default: M-tiles fastest when the weight matrix is the larger operand, so each XCD's L2 streams only its
  * slice of the weights, 2 always M-fastest); key 24 = skinny-GEMM kernel (M <= 1024 rows, register operands, four waves split
- * K) while its operand re-reads stay below this many MiB (64 default, 0 = LDS-staged kernels only). */
+ * K) while its operand re-reads stay below this many MiB (64 default, 0 = LDS-staged kernels only); key 25 = gl_rela_merge
+ * also writes the following LayerNorm (1, default) or a separate gl_layernorm launch does (0). */
 int gl_set_option(int key, int value);
 /* one-time per-process setup (raises dynamic-LDS limits of the tiled kernels); idempotent */
 int gl_init(void);

@@ -28,6 +28,7 @@ namespace {
 constexpr int CIN_PAD = 64;              // the 4-channel latent is zero-padded to one 64-channel K block
 constexpr int64_t ALIGN = 256;
 constexpr int64_t WS_BYTES = 96ll << 20; // split-K fp32 partial tiles
+int g_fuse_merge_ln = 1;                 // A/B knob (gl_set_option 25): rela_merge also writes LayerNorm(norm2) of its rows
 int g_fuse_vt = 1;                       // A/B knob (gl_set_option 21): V^T written by the QKV GEMM epilogue (1) or by gl_transpose_v (0)
 int g_force_fuser = 0;                   // test knob (gl_set_option 20): execute the fuser even at scale 0 (zero gates)
 
@@ -566,6 +567,7 @@ int spatial_transformer(Run& r, const LayerD& l, int li, Stream2 xin, int side, 
         x = y;
     }
     // --- relation injection (attention.py:315-359, :398), closed form
+    bool ln2_done = false;
     {
         const std::string rf = t + ".rela_fuse";
         const std::string ss = std::to_string(side);
@@ -598,9 +600,12 @@ int spatial_transformer(Run& r, const LayerD& l, int li, Stream2 xin, int side, 
         CK(r.gemm(hg, 4 * C, rf + ".ff.ff2.w", Mo, f2, C, GL_OUT_F16_ROWMAJOR, rf + ".ff.ff2.b", GL_EPI_GATE_RES, f1, C, 0, gates + 3));
         float* y = nxt(x);
         ++r.launches;
+        // ... and LayerNorm(norm2) of the merged rows in the same launch (the rows attn2's q projection reads)
+        const bool fuse_ln2 = g_fuse_merge_ln && mo <= 32;
         CK(gl_rela_merge(x, 1, nullptr, stats, e->Wf(rf + ".norm3.g"), e->Wf(rf + ".norm3.b"), f2, Bn, side, side, C, rects, nvalid, poison, mo, y,
-                         r.st));
+                         fuse_ln2 ? e->Wf(t + ".norm2.g") : nullptr, fuse_ln2 ? e->Wf(t + ".norm2.b") : nullptr, fuse_ln2 ? lnb : nullptr, r.st));
         x = y;
+        ln2_done = fuse_ln2;
     }
     // --- attn2: text cross-attention with hoisted K/V (attention.py:400)
     {
@@ -610,7 +615,7 @@ int spatial_transformer(Run& r, const LayerD& l, int li, Stream2 xin, int side, 
         const int ldvt = vt_ld(Lc);
         const half_t* vtc = e->h16("hoist.vtctx." + sl, (size_t)Bn * H * d * ldvt);
         CKP(q2); CKP(a2); CKP(kv); CKP(vtc);
-        CK(r.ln(x, C, 1, lnb, C, t + ".norm2", Bn, N, N, 0, C));
+        if (!ln2_done) CK(r.ln(x, C, 1, lnb, C, t + ".norm2", Bn, N, N, 0, C));
         CK(r.gemm(lnb, C, t + ".attn2.q.w", M, q2, C));
         CK(r.attn(q2, (int64_t)N * C, C, kv, (int64_t)Lc * 2 * C, 2 * C, vtc, ldvt, a2, (int64_t)N * C, C, Bn, H, d, N, Lc));
         float* y = nxt(x);
@@ -955,6 +960,7 @@ extern "C" int gl_plms_step(gl_engine* e, const gl_plms_step_args* a, void* stre
 extern "C" int gl_set_option_engine(int key, int value) {
     if (key == 20) { g_force_fuser = value; return 0; }
     if (key == 21) { g_fuse_vt = value; return 0; }
+    if (key == 25) { g_fuse_merge_ln = value; return 0; }
     return GL_ERR_BAD_ARG;
 }
 

@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
             const float bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
             half8_t ov;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) ov[j] = (half_t)((v[i][j] - mean) * rstd * g[j] + bt[j]);
+            for (int j = 0; j < 8; ++j) ov[j] = (half_t)fmaf((v[i][j] - mean) * rstd, g[j], bt[j]);   // explicit: rela_merge_ln_kernel rounds identically
             st16(yr + vec * 8, *reinterpret_cast<uint4*>(&ov));
         }
     }

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void rela_merge_kernel(const void* __restrict_
         if (ln_stats != nullptr) {
             const float mean = ln_stats[tok * 2], rstd = ln_stats[tok * 2 + 1];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) hf[j] = (xf[j] - mean) * rstd * gamma[vec * 8 + j] + beta[vec * 8 + j];
+            for (int j = 0; j < 8; ++j) hf[j] = fmaf((xf[j] - mean) * rstd, gamma[vec * 8 + j], beta[vec * 8 + j]);   // explicit FMAs: the row form below must round identically
         } else {
             uint4 rh = ld16(hid + tok * C + vec * 8);
             const half8_t hv = *reinterpret_cast<half8_t*>(&rh);
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void rela_merge_kernel(const void* __restrict_
         float o[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            o[j] = 0.5f * ((hf[j] + acc[j] * inv_mo) + xf[j]);
+            o[j] = 0.5f * (fmaf(acc[j], inv_mo, hf[j]) + xf[j]);
             if (bad) o[j] = __builtin_nanf("");
         }
         if constexpr (XF32) {
@@ -201,6 +201,98 @@ __global__ __launch_bounds__(256) void rela_merge_kernel(const void* __restrict_
 #pragma unroll
             for (int j = 0; j < 8; ++j) ov[j] = (half_t)o[j];
             st16(reinterpret_cast<half_t*>(yv) + tok * C + vec * 8, *reinterpret_cast<uint4*>(&ov));
+        }
+    }
+}
+
+// Row form of rela_merge for the fp32 stream, one wave per token: besides y it writes LayerNorm(y) (fp16) -- the norm2
+// that feeds attn2's q projection (attention.py:400) -- so the freshly written rows are not read back by a LayerNorm launch.
+template <int NV>
+__global__ __launch_bounds__(256) void rela_merge_ln_kernel(const float* __restrict__ x, const float* __restrict__ ln_stats,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const half_t* __restrict__ f, int H, int W, int C,
+                                                            const int* __restrict__ rects, const int* __restrict__ nvalid,
+                                                            const int* __restrict__ poison, int max_objs, float* __restrict__ y,
+                                                            const float* __restrict__ g2, const float* __restrict__ b2,
+                                                            half_t* __restrict__ ln_out, int ntok) {
+    const int lane = threadIdx.x & 63;
+    const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= ntok) return;
+    const int nvec = C / 8;
+    const int HW = H * W;
+    const int b = tok / HW;
+    const int p = tok - b * HW;
+    const int py = p / W, px = p - py * W;
+    const float inv_mo = 1.0f / (float)max_objs;
+    const float mean3 = ln_stats[(size_t)tok * 2], rstd3 = ln_stats[(size_t)tok * 2 + 1];
+    const int nv = nvalid[b];
+    const int* rb = rects + (size_t)b * max_objs * 4;
+    const bool bad = poison[b] != 0;
+    // which boxes cover this pixel: wave-uniform bit mask (max_objs <= 32 checked by the launcher)
+    unsigned cover = 0;
+    for (int i = 0; i < nv; ++i) {
+        const int top = rb[4 * i], bottom = rb[4 * i + 1], left = rb[4 * i + 2], right = rb[4 * i + 3];
+        if (py >= top && py < bottom && px >= left && px < right) cover |= 1u << i;
+    }
+    float o[NV][8];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int vec = lane + 64 * i;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[i][j] = 0.0f;
+        if (vec < nvec) {
+            const float* xr = x + (size_t)tok * C + vec * 8;
+            const float4 a = *reinterpret_cast<const float4*>(xr);
+            const float4 c = *reinterpret_cast<const float4*>(xr + 4);
+            const float xf[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+            float acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+            for (unsigned m = cover; m != 0; m &= m - 1) {
+                const int bi = __builtin_ctz(m);
+                uint4 rf = ld16(f + ((size_t)b * max_objs + bi) * C + vec * 8);
+                const half8_t fv = *reinterpret_cast<half8_t*>(&rf);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += (float)fv[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float hf = fmaf((xf[j] - mean3) * rstd3, gamma[vec * 8 + j], beta[vec * 8 + j]);
+                o[i][j] = 0.5f * (fmaf(acc[j], inv_mo, hf) + xf[j]);
+                if (bad) o[i][j] = __builtin_nanf("");
+            }
+            float* yr = y + (size_t)tok * C + vec * 8;
+            *reinterpret_cast<float4*>(yr) = make_float4(o[i][0], o[i][1], o[i][2], o[i][3]);
+            *reinterpret_cast<float4*>(yr + 4) = make_float4(o[i][4], o[i][5], o[i][6], o[i][7]);
+        }
+    }
+    // LayerNorm of the row just formed: same two-pass arithmetic as layernorm_kernel (norms.hip)
+    float a = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a += o[i][j];
+    const float mean = wave_sum(a) / (float)C;
+    float ss = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if (lane + 64 * i < nvec) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float dlt = o[i][j] - mean;
+                ss = fmaf(dlt, dlt, ss);
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)C + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int vec = lane + 64 * i;
+        if (vec < nvec) {
+            half8_t ov;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ov[j] = (half_t)fmaf((o[i][j] - mean) * rstd, g2[vec * 8 + j], b2[vec * 8 + j]);
+            st16(ln_out + (size_t)tok * C + vec * 8, *reinterpret_cast<uint4*>(&ov));
         }
     }
 }
@@ -222,9 +314,25 @@ extern "C" int gl_rela_pool(const void* hid, int32_t B, int32_t H, int32_t W, in
 extern "C" int gl_rela_merge(const void* x, int32_t x_f32, const void* hid, const float* ln_stats, const float* gamma,
                              const float* beta, const void* f, int32_t B, int32_t H, int32_t W, int32_t C,
                              const int32_t* rects, const int32_t* nvalid, const int32_t* poison, int32_t max_objs, void* y,
-                             void* stream) {
+                             const float* ln2_gamma, const float* ln2_beta, void* ln2_out, void* stream) {
     if (!x || !f || !rects || !nvalid || !poison || !y || C <= 0 || (C % 8)) return GL_ERR_BAD_ARG;
     if (ln_stats ? (!gamma || !beta) : !hid) return GL_ERR_BAD_ARG;
+    if (ln2_out != nullptr) {
+        // fused form: fp32 stream + recomputed LN3 only, one wave per token
+        if (!x_f32 || !ln_stats || !ln2_gamma || !ln2_beta || max_objs > 32 || C > 2048) return GL_ERR_UNSUPPORTED;
+        const int ntok = B * H * W;
+        const int nv = gl_cdiv(C / 8, 64);
+        const dim3 grid(gl_cdiv(ntok, 4)), blk(256);
+#define GL_RM(V)                                                                                                                         \
+    rela_merge_ln_kernel<V><<<grid, blk, 0, (hipStream_t)stream>>>(reinterpret_cast<const float*>(x), ln_stats, gamma, beta,              \
+                                                                   reinterpret_cast<const half_t*>(f), H, W, C, rects, nvalid, poison,    \
+                                                                   max_objs, reinterpret_cast<float*>(y), ln2_gamma, ln2_beta,             \
+                                                                   reinterpret_cast<half_t*>(ln2_out), ntok)
+        if (nv == 1) GL_RM(1); else if (nv == 2) GL_RM(2); else if (nv == 3) GL_RM(3); else GL_RM(4);
+#undef GL_RM
+        GL_CHECK_LAUNCH();
+        return 0;
+    }
     const size_t total = (size_t)B * H * W * (C / 8);
     int nblk = (int)((total + 255) / 256);
     if (nblk > 2048) nblk = 2048;

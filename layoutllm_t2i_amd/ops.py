@@ -281,9 +281,11 @@ def rela_pool(hid, B, H, W, Cc, rects, nvalid, poison, max_objs, feat, ln_gamma=
     return feat
 
 
-def rela_merge(x, hid, f, B, H, W, Cc, rects, nvalid, poison, max_objs, y, ln_stats=None, gamma=None, beta=None):
+def rela_merge(x, hid, f, B, H, W, Cc, rects, nvalid, poison, max_objs, y, ln_stats=None, gamma=None, beta=None,
+               ln2_gamma=None, ln2_beta=None, ln2_out=None):
     """y = 0.5 * (x + hid + (1/max_objs) sum_i 1[p in rect_i] f_i); x / y fp16 or fp32 (same dtype).  With ``ln_stats``
-    (+ gamma, beta) hid = LayerNorm(x) is re-evaluated in fp32 from the stored (mean, rstd) instead of read from ``hid``."""
+    (+ gamma, beta) hid = LayerNorm(x) is re-evaluated in fp32 from the stored (mean, rstd) instead of read from ``hid``.
+    With ``ln2_out`` (fp32 stream + ln_stats form) the launch also writes LayerNorm(y; ln2_gamma, ln2_beta) in fp16."""
     xf32 = x.dtype == F32
     for t, n in ((x, "x"), (y, "y")):
         _req(t, F32 if xf32 else F16, n)
@@ -293,8 +295,13 @@ def rela_merge(x, hid, f, B, H, W, Cc, rects, nvalid, poison, max_objs, y, ln_st
     else:
         for t, n in ((ln_stats, "ln_stats"), (gamma, "gamma"), (beta, "beta")):
             _req(t, F32, n, 8)
+    if ln2_out is not None:
+        _req(ln2_out, F16, "ln2_out")
+        for t, n in ((ln2_gamma, "ln2_gamma"), (ln2_beta, "ln2_beta")):
+            _req(t, F32, n, 8)
     check(_lib.lib().gl_rela_merge(x.data_ptr(), int(xf32), _ptr(hid), _ptr(ln_stats), _ptr(gamma), _ptr(beta), f.data_ptr(), B, H, W,
-                                   Cc, rects.data_ptr(), nvalid.data_ptr(), poison.data_ptr(), max_objs, y.data_ptr(), _stream()),
+                                   Cc, rects.data_ptr(), nvalid.data_ptr(), poison.data_ptr(), max_objs, y.data_ptr(), _ptr(ln2_gamma),
+                                   _ptr(ln2_beta), _ptr(ln2_out), _stream()),
           "gl_rela_merge")
     return y
 

@@ -674,6 +674,41 @@ def test_rela_merge_fp32_stream_recomputes_ln():
     assert torch.allclose(y.cpu(), ref, rtol=1e-5, atol=1e-5), float((y.cpu() - ref).abs().max())
 
 
+@pytest.mark.parametrize("C,hw,poisoned", [(320, 16, False), (640, 8, False), (1280, 8, False), (2048, 4, False), (320, 8, True)])
+def test_rela_merge_with_fused_layernorm(C, hw, poisoned):
+    """ln2_out form (one wave per token): y and LayerNorm(y) from one launch must equal, bit for bit, the elementwise
+    gl_rela_merge followed by gl_layernorm -- for every channel width's register layout (1..4 vectors per lane), overlapping
+    boxes, an empty sample and a NaN-poisoned sample."""
+    B, mo = 3, 30
+    boxes = np.zeros((B, mo, 4), np.float32)
+    masks = np.zeros((B, mo), np.float32)
+    boxes[0, :4] = [(0.0, 0.0, 0.5, 0.5), (0.25, 0.25, 1.0, 1.0), (0.6, 0.1, 0.9, 0.45), (0.3, 0.3, 0.7, 0.7)]
+    masks[0, :4] = 1
+    boxes[2, :2] = [(0.1, 0.2, 0.8, 0.9), (0.5, 0.5, 0.1, 0.1) if poisoned else (0.0, 0.5, 1.0, 1.0)]
+    masks[2, :2] = 1
+    rects, nvalid, poison = host.box_rects(boxes, masks, hw, hw)
+    assert bool(poison[2]) == poisoned
+    x = (rnd(f"rml{C}x", (B * hw * hw, C)) * 1.3 + 0.2).to(DEV)
+    g3, b3, g2, b2 = ((1 + 0.1 * rnd(f"rml{C}{k}", (C,))).to(DEV) if k in "ac" else (0.1 * rnd(f"rml{C}{k}", (C,))).to(DEV) for k in "abcd")
+    _, fd = h16(rnd(f"rml{C}f", (B * mo, C)))
+    dr, dn, dp = (torch.from_numpy(a).to(DEV) for a in (rects, nvalid, poison))
+    M = B * hw * hw
+    hid16 = torch.empty(M, C, dtype=torch.float16, device=DEV)
+    st = torch.empty(M, 2, dtype=torch.float32, device=DEV)
+    ops.layernorm(x, hid16, g3, b3, B, hw * hw, stats=st)
+    y0 = torch.empty(M, C, dtype=torch.float32, device=DEV)
+    ops.rela_merge(x, None, fd, B, hw, hw, C, dr, dn, dp, mo, y0, ln_stats=st, gamma=g3, beta=b3)
+    n0 = torch.empty(M, C, dtype=torch.float16, device=DEV)
+    ops.layernorm(y0, n0, g2, b2, B, hw * hw)
+    y1 = torch.full((M, C), 7.0, dtype=torch.float32, device=DEV)
+    n1 = torch.full((M, C), 7.0, dtype=torch.float16, device=DEV)
+    ops.rela_merge(x, None, fd, B, hw, hw, C, dr, dn, dp, mo, y1, ln_stats=st, gamma=g3, beta=b3, ln2_gamma=g2, ln2_beta=b2, ln2_out=n1)
+    eq = lambda a, b: torch.equal(torch.nan_to_num(a.float(), nan=123.0), torch.nan_to_num(b.float(), nan=123.0))
+    assert eq(y1, y0), float(torch.nan_to_num(y1 - y0).abs().max())
+    assert eq(n1, n0), float(torch.nan_to_num(n1.float() - n0.float()).abs().max())
+    assert torch.isnan(y1.view(B, -1)[2]).all() == poisoned and torch.isfinite(y1.view(B, -1)[:2]).all()
+
+
 RELA_GOLDENS = [("rela_normal", 8), ("rela_degenerate", 8), ("rela_null", 8), ("rela_clamp", 8), ("rela_maskgap", 16), ("rela_empty_slice", 8)]
 
 
