@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GL_ABI_VERSION 7
+#define GL_ABI_VERSION 8
 
 /* error codes (negative; positive values are hipError_t) */
 #define GL_ERR_BAD_ARG (-1)
@@ -81,6 +81,31 @@ typedef struct gl_gemm_args {
      * key = m % vt_rows, (h, c) = divmod(n - vt_col0, vt_d).  fp16 row-major out, epi BIAS only, vt_col0 % 64 == 0. */
     void* vt;           int32_t vt_col0, vt_rows, vt_d, vt_ld, vt_H;
 } gl_gemm_args;
+
+/*
+ * gl_ff_fused: the whole FeedForward of a BasicTransformerBlock / GatedSelfAttentionDense in ONE launch (attention.py:38-62,
+ * called at :231-232 and :401):   out = res (+|gate *) ( GEGLU(x . W1^T + b1) . W2^T + b2 )
+ * for narrow channel widths (C in {64, 128, 192, 256, 320}; gl_ff_fused_supported(C)) -- the level whose [M, 4C]
+ * GEGLU intermediate (84 MB at 64x64x320) would otherwise make a round trip through HBM between two gl_gemm launches.
+ * w1 / b1 are gl_gemm's GL_EPI_GEGLU operands (rows interleaved in blocks of 32: x rows, gate rows), w2 is [C, 4C].
+ * gate == NULL: out = y + res (GL_EPI_RES);  gate != NULL: out = res + gate[0] * y (GL_EPI_GATE_RES).
+ * Agrees with the two-launch form to fp32 accumulation rounding (same fp16 intermediate, other summation order).
+ */
+typedef struct gl_ff_args {
+    const void* x;      int32_t ldx;    /* fp16 [M, C] (already normalised rows) */
+    const void* w1;     const float* b1;/* fp16 [8C, C] packed, fp32 [8C] packed   */
+    const void* w2;     const float* b2;/* fp16 [C, 4C], fp32 [C]                  */
+    const void* res;    int32_t ldres;  int32_t res_f32;   /* residual rows: fp32 stream (res_f32 != 0) or fp16 */
+    const float* gate;                  /* device scalar or NULL */
+    void* out;          int32_t ldc;    int32_t out_mode;  /* GL_OUT_F16_ROWMAJOR or GL_OUT_F32_ROWMAJOR */
+    int32_t M, C;
+} gl_ff_args;
+int gl_ff_fused(const gl_ff_args* args, void* stream);
+int gl_ff_fused_supported(int32_t C);
+/* 1 when the fused form is the faster choice for [M, C] on the current device (enough 128-row blocks to fill whole rounds
+ * of CUs); the engine uses it, and so must anything that wants to reproduce the engine's results bit for bit */
+int gl_ff_fused_applicable(int32_t C, int32_t M);
+int gl_sizeof_ff_args(void);
 
 /*
  * gl_conv3x3: 3x3, pad 1 convolution as implicit GEMM over NHWC fp16 input [B, Hin, Win, Cin]
@@ -332,7 +357,8 @@ int gl_sizeof_attn_args(void);
  * fastest, 1 = default: M-tiles fastest when the weight matrix is the larger operand, so each XCD's L2 streams only its
  * slice of the weights, 2 always M-fastest); key 24 = skinny-GEMM kernel (M <= 1024 rows, register operands, four waves split
  * K) while its operand re-reads stay below this many MiB (64 default, 0 = LDS-staged kernels only); key 25 = gl_rela_merge
- * also writes the following LayerNorm (1, default) or a separate gl_layernorm launch does (0). */
+ * also writes the following LayerNorm (1, default) or a separate gl_layernorm launch does (0); key 26 = gl_ff_fused timing
+ * ablations (results wrong when != 0); key 27 = fused FeedForward where applicable (1, default) or never (0). */
 int gl_set_option(int key, int value);
 /* one-time per-process setup (raises dynamic-LDS limits of the tiled kernels); idempotent */
 int gl_init(void);

@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgligen_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # enum gl_epilogue / gl_out_mode
 EPI_BIAS, EPI_SILU, EPI_GEGLU, EPI_RES, EPI_GATE_RES, EPI_ROWBIAS = range(6)
@@ -104,6 +104,12 @@ class RewardArgs(C.Structure):
                 ("sims_ti", vp), ("sims_ii", vp), ("aesthetic", vp), ("partial_reward", vp)]
 
 
+class FFArgs(C.Structure):
+    """gl_ff_args"""
+    _fields_ = [("x", vp), ("ldx", i32), ("w1", vp), ("b1", vp), ("w2", vp), ("b2", vp), ("res", vp), ("ldres", i32), ("res_f32", i32),
+                ("gate", vp), ("out", vp), ("ldc", i32), ("out_mode", i32), ("M", i32), ("C", i32)]
+
+
 # name -> (restype, argtypes); every symbol include/gligen_hip.h declares
 PROTOTYPES = {
     "gl_gemm": (i32, [C.POINTER(GemmArgs), vp]),
@@ -146,6 +152,10 @@ PROTOTYPES = {
     "gl_sizeof_plms_step_args": (i32, []),
     "gl_reward_score": (i32, [C.POINTER(RewardArgs), vp]),
     "gl_sizeof_reward_args": (i32, []),
+    "gl_ff_fused": (i32, [C.POINTER(FFArgs), vp]),
+    "gl_ff_fused_supported": (i32, [i32]),
+    "gl_ff_fused_applicable": (i32, [i32, i32]),
+    "gl_sizeof_ff_args": (i32, []),
     "gl_set_option": (i32, [i32, i32]),
 }
 
@@ -181,7 +191,7 @@ def lib() -> C.CDLL:
         raise HipLibraryError(f"ABI version mismatch: lib {l.gl_abi_version()} vs host {ABI_VERSION}")
     for cls, fn in ((GemmArgs, l.gl_sizeof_gemm_args), (ConvArgs, l.gl_sizeof_conv_args), (AttnArgs, l.gl_sizeof_attn_args),
                     (UNetConfigC, l.gl_sizeof_unet_config), (WeightInfo, l.gl_sizeof_weight_info),
-                    (PlmsStepArgs, l.gl_sizeof_plms_step_args), (RewardArgs, l.gl_sizeof_reward_args)):
+                    (PlmsStepArgs, l.gl_sizeof_plms_step_args), (RewardArgs, l.gl_sizeof_reward_args), (FFArgs, l.gl_sizeof_ff_args)):
         if C.sizeof(cls) != fn():
             raise HipLibraryError(f"struct size mismatch for {cls.__name__}: host {C.sizeof(cls)} vs lib {fn()}")
     _lib = l

@@ -16,7 +16,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 REPO = os.path.dirname(PKG)
-SOURCES = ["gemm_conv.hip", "attention.hip", "norms.hip", "rela.hip", "misc.hip", "engine.hip", "reward.hip"]
+SOURCES = ["gemm_conv.hip", "attention.hip", "norms.hip", "rela.hip", "misc.hip", "engine.hip", "reward.hip", "ff_fused.hip"]
 LIB = os.path.join(PKG, "libgligen_hip.so")
 OBJDIR = os.path.join(HERE, "build")
 
@@ -52,7 +52,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             subprocess.run(cmd, check=True)
         return o
 
-    with ThreadPoolExecutor(max_workers=min(7, len(SOURCES))) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     if force or any(_newer(o, LIB) for o in objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]

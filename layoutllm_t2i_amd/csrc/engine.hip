@@ -480,6 +480,20 @@ int self_attention(Run& r, const half_t* src, int rows_per_b, int Nq, int Nk, in
 }
 
 int feed_forward(Run& r, const half_t* xn, const float* res, const std::string& p, int M, int C, void* out, int out_mode, const float* gate) {
+    if (gl_ff_fused_applicable(C, M)) {
+        // narrow / long level: the whole FeedForward in one launch, the [M, 4C] GEGLU intermediate never leaves the CU
+        gl_ff_args a{};
+        a.x = xn; a.ldx = C;
+        a.w1 = r.e->W(p + ".ff1.w"); a.b1 = r.e->Wf(p + ".ff1.b");
+        a.w2 = r.e->W(p + ".ff2.w"); a.b2 = r.e->Wf(p + ".ff2.b");
+        if (!a.w1 || !a.b1 || !a.w2 || !a.b2) return GL_ERR_BAD_ARG;
+        a.res = res; a.ldres = C; a.res_f32 = 1;
+        a.gate = gate;
+        a.out = out; a.ldc = C; a.out_mode = out_mode;
+        a.M = M; a.C = C;
+        ++r.launches;
+        return gl_ff_fused(&a, r.st);
+    }
     half_t* hg = r.e->h16("ff.h", (size_t)M * 4 * C);
     CKP(hg);
     CK(r.gemm(xn, C, p + ".ff1.w", M, hg, 4 * C, GL_OUT_F16_ROWMAJOR, p + ".ff1.b", GL_EPI_GEGLU));

@@ -234,14 +234,17 @@ extern "C" int gl_latent_affine_pack(const float* z, const float* w, const float
 }
 
 extern "C" int gl_init_gemm(void);
+extern "C" int gl_init_ff(void);
 extern "C" int gl_set_option_gemm(int key, int value);
 extern "C" int gl_set_option_attn(int key, int value);
 extern "C" int gl_set_option_norm(int key, int value);
 extern "C" int gl_set_option_engine(int key, int value);
+extern "C" int gl_set_option_ff(int key, int value);
 int g_gl_option_epoch = 0;
 extern "C" int gl_set_option(int key, int value) {
     ++g_gl_option_epoch;
     if (key == 16 || key == 17) return gl_set_option_norm(key, value);
+    if (key == 26 || key == 27) return gl_set_option_ff(key, value);
     if (key == 20 || key == 21 || key == 25) return gl_set_option_engine(key, value);
     return (key == 3 || key == 10) ? gl_set_option_attn(key, value) : gl_set_option_gemm(key, value);   // 1,2,4-9: GEMM knobs
 }
@@ -250,4 +253,7 @@ extern "C" int gl_abi_version(void) { return GL_ABI_VERSION; }
 extern "C" int gl_sizeof_gemm_args(void) { return (int)sizeof(gl_gemm_args); }
 extern "C" int gl_sizeof_conv_args(void) { return (int)sizeof(gl_conv_args); }
 extern "C" int gl_sizeof_attn_args(void) { return (int)sizeof(gl_attn_args); }
-extern "C" int gl_init(void) { return gl_init_gemm(); }
+extern "C" int gl_init(void) {
+    const int e = gl_init_gemm();
+    return e ? e : gl_init_ff();
+}

@@ -306,6 +306,39 @@ def rela_merge(x, hid, f, B, H, W, Cc, rects, nvalid, poison, max_objs, y, ln_st
     return y
 
 
+def ff_fused_supported(Cc: int) -> bool:
+    return bool(_lib.lib().gl_ff_fused_supported(int(Cc)))
+
+
+def ff_fused_applicable(Cc: int, M: int) -> bool:
+    """the engine's own rule for taking the fused FeedForward (gl_ff_fused_applicable)"""
+    return bool(_lib.lib().gl_ff_fused_applicable(int(Cc), int(M)))
+
+
+def ff_fused(x, w1, b1, w2, b2, res, out, gate=None):
+    """out = res (+ | gate *) (GEGLU(x . w1^T + b1) . w2^T + b2) in one launch (gl_ff_fused; attention.py:38-62).
+    x fp16 [M, C]; w1 / b1 the packed GEGLU operands [8C, C] / [8C]; w2 [C, 4C]; res fp32 or fp16 [M, C]; out fp16 or fp32."""
+    _req(x, F16, "x")
+    _req(w1, F16, "w1")
+    _req(w2, F16, "w2")
+    _req(b1, F32, "b1")
+    _req(b2, F32, "b2")
+    M, Cc = x.shape
+    if w1.shape != (8 * Cc, Cc) or w2.shape != (Cc, 4 * Cc) or not w1.is_contiguous() or not w2.is_contiguous():
+        raise ValueError("w1 must be [8C, C] (packed GEGLU layout) and w2 [C, 4C], contiguous")
+    if res.dtype not in (F16, F32) or out.dtype not in (F16, F32) or not res.is_cuda or not out.is_cuda:
+        raise _lib.HipLibraryError("res / out: fp16 or fp32 GPU tensors")
+    a = _lib.FFArgs()
+    a.x, a.ldx = x.data_ptr(), x.stride(0)
+    a.w1, a.b1, a.w2, a.b2 = w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr()
+    a.res, a.ldres, a.res_f32 = res.data_ptr(), res.stride(0), int(res.dtype == F32)
+    a.gate = _ptr(gate)
+    a.out, a.ldc, a.out_mode = out.data_ptr(), out.stride(0), (OUT_F32_ROWMAJOR if out.dtype == F32 else OUT_F16_ROWMAJOR)
+    a.M, a.C = M, Cc
+    check(_lib.lib().gl_ff_fused(C.byref(a), _stream()), "gl_ff_fused")
+    return out
+
+
 def posnet_input(boxes, masks, emb, null_pos, null_xyxy, num_freqs, out):
     for t, n in ((boxes, "boxes"), (masks, "masks"), (emb, "emb"), (null_pos, "null_pos"), (null_xyxy, "null_xyxy")):
         _req(t, F32, n, 4)

@@ -207,6 +207,8 @@ class PyRefEngine:
 
     def _feed_forward(self, xn, res, p, M, C, out, gate=None):
         W = self.W
+        if ops.ff_fused_applicable(C, M):
+            return ops.ff_fused(xn, W[p + ".ff1.w"], W[p + ".ff1.b"], W[p + ".ff2.w"], W[p + ".ff2.b"], res, out, gate=gate)
         hg = ops.gemm(xn, W[p + ".ff1.w"], self.buf("ff.h", (M, 4 * C)), W[p + ".ff1.b"], EPI_GEGLU)
         if gate is None:
             return ops.gemm(hg, W[p + ".ff2.w"], out, W[p + ".ff2.b"], EPI_RES, res=res)

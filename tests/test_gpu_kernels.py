@@ -102,6 +102,44 @@ def test_gemm_geglu(C):
     check(out, x * F.gelu(g), f"gemm_geglu_{C}")
 
 
+@pytest.mark.parametrize("M,C,mode", [(4096, 320, "res32_f16"), (1000, 320, "gate_f32"), (300, 64, "res32_f16"), (257, 128, "res16_f16"),
+                                      (512, 192, "gate_f32"), (640, 256, "res32_f32")])
+def test_ff_fused(M, C, mode):
+    """gl_ff_fused: GEGLU projection -> erf-GELU gate -> output projection -> (gated) residual in ONE launch, the [M, 4C]
+    intermediate never stored.  Checked against torch fp32 on the fp16-rounded operands (with the intermediate rounded to
+    fp16 like both HIP forms do) and against the two-launch gl_gemm form; ragged last block; rows past M untouched."""
+    x, xd = h16(rnd(f"ffx{M}{C}", (M, C)))
+    w1, _ = h16(rnd(f"ffw1{C}", (8 * C, C), 1 / math.sqrt(C)))
+    b1 = rnd(f"ffb1{C}", (8 * C,), 0.1)
+    w2, w2d = h16(rnd(f"ffw2{C}", (C, 4 * C), 1 / math.sqrt(4 * C)))
+    b2 = rnd(f"ffb2{C}", (C,), 0.1)
+    w1d = geglu_interleave(w1).to(torch.float16).to(DEV).contiguous()
+    b1d = geglu_interleave(b1).contiguous().to(DEV)
+    res32 = mode.startswith("res32") or mode.startswith("gate")
+    r = rnd(f"ffr{M}{C}", (M, C)) * 2.0 + 0.3
+    if not res32:
+        r = r.half().float()
+    rd = r.to(DEV) if res32 else r.half().to(DEV)
+    gate = torch.tensor([0.61], dtype=torch.float32, device=DEV) if mode.startswith("gate") else None
+    odt = torch.float32 if mode.endswith("f32") else torch.float16
+    out = torch.full((M + 9, C), 7.0, dtype=odt, device=DEV)
+    ops.ff_fused(xd, w1d, b1d, w2d, b2.to(DEV), rd, out[:M], gate=gate)
+    xg, gg = F.linear(x, w1, b1).chunk(2, dim=-1)
+    hmid = (xg * F.gelu(gg)).half().float()
+    yv = F.linear(hmid, w2, b2)
+    ref = r + 0.61 * yv if gate is not None else yv + r
+    check(out[:M], ref, f"ff_fused_{M}_{C}_{mode}")
+    assert float((out[M:].float() - 7.0).abs().max()) == 0.0, "rows past M were written"
+    # the two-launch form on the same operands
+    hbuf = torch.empty(M, 4 * C, dtype=torch.float16, device=DEV)
+    ops.gemm(xd, w1d, hbuf, b1d, EPI_GEGLU)
+    out2 = torch.empty(M, C, dtype=odt, device=DEV)
+    ops.gemm(hbuf, w2d, out2, b2.to(DEV), EPI_GATE_RES if gate is not None else EPI_RES, res=rd, gate=gate)
+    d = float((out[:M].float() - out2.float()).norm() / out2.float().norm())
+    print(f"[ff_fused {M}x{C} {mode}] rel-L2 vs two-launch form = {d:.2e}")
+    assert d < (4e-4 if odt == torch.float16 else 2e-5), d
+
+
 @pytest.mark.parametrize("M,N,K,epi", [(240, 320, 320, "bias"), (240, 320, 320, "gate"), (240, 1280, 1280, "gate"), (240, 640, 2560, "gate"),
                                        (8, 1280, 320, "silu"), (8, 1280, 1280, "bias"), (120, 320, 1280, "res32"), (960, 320, 320, "res"),
                                        (33, 64, 64, "bias")])
