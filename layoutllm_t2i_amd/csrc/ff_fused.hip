@@ -66,29 +66,42 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(gl_ff_args p) {
 
     // ---- weight stream: chunk j -> ring slot j & 1 (LDS-DMA: lane i of a wave instruction lands at dst + 16 i, so the
     // LDS layout is produced by choosing each lane's SOURCE address)
+    // per-lane source offsets of this wave's DMA instructions are the same for every chunk: computed once
+    constexpr int NI1 = (G::W1_INSTR + 3) / 4, NI2 = (G::W2_INSTR + 3) / 4;
+    unsigned off1[NI1], off2[NI2];
+#pragma unroll
+    for (int ii = 0; ii < NI1; ++ii) {
+        const int i = ii * 4 + wave;
+        const int pos = i * 64 + lane;                                // chunk position in the padded [64][ROWCH] tile
+        const int row = pos / G::ROWCH;
+        int c = pos - row * G::ROWCH;
+        if (c >= C / 8) c = C / 8 - 1;                                // pad chunk: any valid address
+        off1[ii] = (unsigned)(row * C + c * 8);
+    }
+#pragma unroll
+    for (int ii = 0; ii < NI2; ++ii) {
+        const int i = ii * 4 + wave;
+        const int pos = i * 64 + lane;
+        const int n = pos >> 2;
+        const int ch = (pos & 3) ^ ((n >> 2) & 3);                    // the chunk stored at this position
+        off2[ii] = (unsigned)(n * (4 * C) + ch * 8);
+    }
     auto issue = [&](int j) {
         unsigned char* st = smem + (j & 1) * G::W1_BYTES;
         const half_t* w1c = w1 + (size_t)j * 64 * C;                  // 64 packed rows [x 32 | gate 32] of this chunk
 #pragma unroll
-        for (int ii = 0; ii < (G::W1_INSTR + 3) / 4; ++ii) {
+        for (int ii = 0; ii < NI1; ++ii) {
             const int i = ii * 4 + wave;
             if (i >= G::W1_INSTR) break;
-            const int pos = i * 64 + lane;                            // chunk position in the padded [64][ROWCH] tile
-            const int row = pos / G::ROWCH;
-            int c = pos - row * G::ROWCH;
-            if (c >= C / 8) c = C / 8 - 1;                            // pad chunk: any valid address
-            ff_glds16(w1c + (size_t)row * C + c * 8, st + i * 1024);
+            ff_glds16(w1c + off1[ii], st + i * 1024);
         }
         unsigned char* st2 = smem + G::W2_BASE + (j % 3) * G::W2_BYTES;
         const half_t* w2c = w2 + (size_t)j * 32;                      // columns [32 j, 32 j + 32) of every W2 row
 #pragma unroll
-        for (int ii = 0; ii < (G::W2_INSTR + 3) / 4; ++ii) {
+        for (int ii = 0; ii < NI2; ++ii) {
             const int i = ii * 4 + wave;
             if (i >= G::W2_INSTR) break;
-            const int pos = i * 64 + lane;
-            const int n = pos >> 2;
-            const int ch = (pos & 3) ^ ((n >> 2) & 3);                // the chunk stored at this position
-            ff_glds16(w2c + (size_t)n * (4 * C) + ch * 8, st2 + i * 1024);
+            ff_glds16(w2c + off2[ii], st2 + i * 1024);
         }
     };
     issue(0);
