@@ -24,6 +24,7 @@
 namespace {
 
 int g_attn_qt2 = 0;          // block shape: 0 auto, 3 always 8 waves, 4 always 4 waves
+int g_attn_padmax = 1;       // running max carried in the operands' padding column where the head dim has one (gl_set_option 29; 0 = FMA path)
 int g_attn_setprio = -1;     // s_setprio(1) around the MFMA clusters: -1 auto (head dim <= 48: +6 %; d = 80: -4 %), 0 off, 1 on
 constexpr int KT = 64;          // keys per tile
 constexpr int VSTR2 = KT + 8;   // main kernel: 144 B rows = 9 x 16 B, conflict-free 16-byte fragment reads
@@ -33,7 +34,12 @@ constexpr int VSTR2 = KT + 8;   // main kernel: 144 B rows = 9 x 16 B, conflict-
 // accumulator is initialised with -m instead of 0 -- and the common (no-rescale) path of the online softmax is ONE v_exp
 // per score instead of FMA + v_exp: the kernel is VALU-bound (PMC: VALU 68 % busy vs MFMA 43 % at d = 40), and this
 // removes 32 of its ~146 VALU instructions per 64-key tile.
-template <int DQK, int QT, int NW, bool PRE>
+// PRE == 2 (head dims with a spare padded column, d % 16 == 8: d = 40 in this UNet): the running max rides in the PADDING of
+// the operands instead of the accumulator init -- K's pad column d holds 1.0 for every key, Q's pad column d holds -m_run, so
+// the QK^T MFMA that is issued anyway delivers logit - m_run; no extra registers (the C-init form costs 16 and an occupancy
+// step at d = 40).  -m_run sits in an fp16 operand, so m_run is kept fp16-representable; softmax is invariant to WHICH
+// reference value is subtracted as long as P, the row sum and the rescale factors all use the same one.
+template <int DQK, int QT, int NW, int PRE>
 __global__ __launch_bounds__(64 * NW) void attn_kernel(gl_attn_args p, int flags) {
     // NW = waves per block: 4 (128 queries share each staged K/V tile) or 8 (256 queries: half the L2 -> LDS
     // traffic per query at the same registers per wave)
@@ -127,7 +133,7 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(gl_attn_args p, int flags
     const half_t* kptr[K_PER_T];
     const half_t* vptr[V_PER_T];
     int krow[K_PER_T], klds[K_PER_T], vlds[V_PER_T], vkey[V_PER_T];
-    bool kok[K_PER_T], vok[V_PER_T], vone[V_PER_T];
+    bool kok[K_PER_T], kone[K_PER_T], vok[V_PER_T], vone[V_PER_T];
 #pragma unroll
     for (int i = 0; i < K_PER_T; ++i) {
         const int idx = tid + NTHR * i;
@@ -135,6 +141,7 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(gl_attn_args p, int flags
         const int c = idx - row * KCH;
         krow[i] = row;
         kok[i] = (idx < K_ITEMS) && (c * 8 < d);
+        kone[i] = (PRE == 2) && (idx < K_ITEMS) && (c * 8 == d);      // the pad chunk whose first column carries 1.0
         klds[i] = row * KSTR + c * 8;
         kptr[i] = Kg + (size_t)row * p.ldk + c * 8;
     }
@@ -157,6 +164,7 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(gl_attn_args p, int flags
 #pragma unroll
         for (int i = 0; i < K_PER_T; ++i) {
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (kone[i]) v.x = 0x00003C00u;                          // fp16 1.0 in column d
             if (kok[i] && key0 + krow[i] < Nk) v = ld16(kptr[i]);
             kptr[i] += kstep;
             rk[i] = v;
@@ -221,7 +229,7 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(gl_attn_args p, int flags
             for (int ks = 0; ks < NKS; ++ks) {
                 const half8_t kf = *reinterpret_cast<const half8_t*>(Ks + (kh * 32 + ql) * KSTR + (2 * ks + hi) * 8);
 #pragma unroll
-                for (int qt = 0; qt < QT; ++qt) s[qt][kh] = mfma32(kf, qf[qt][ks], ks == 0 ? (PRE ? negm[qt] : zero16) : s[qt][kh]);
+                for (int qt = 0; qt < QT; ++qt) s[qt][kh] = mfma32(kf, qf[qt][ks], ks == 0 ? (PRE == 1 ? negm[qt] : zero16) : s[qt][kh]);
             }
         if (SETPRIO) __builtin_amdgcn_s_setprio(0);
         // ---- online softmax (this lane: query ql of each sub-tile, keys kh*32 + (r&3) + 8*(r>>2) + 4*hi).
@@ -250,7 +258,7 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(gl_attn_args p, int flags
             for (int i = 3; i < 31; i += 2) tmax = max3f(tmax, sv(i), sv(i + 1));
             tmax = fmaxf(tmax, sv(31));
             float psum = 0.0f;
-            if constexpr (PRE) {
+            if constexpr (PRE != 0) {
                 // scores are s' = logit - m_run (exp2 units).  Rescale when some row's tile max exceeds the running max
                 // by more than 2^DEFER -- and always on the first tile, which establishes the true row max (m_run = 0
                 // until then, so a row of very negative logits cannot underflow its whole first tile)
@@ -258,6 +266,7 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(gl_attn_args p, int flags
                 float inc = 0.0f;
                 if (t == 0 || __any(tmax > DEFER)) {
                     inc = (t == 0) ? tmax : fmaxf(tmax, 0.0f);
+                    if constexpr (PRE == 2) inc = (float)(half_t)(m_run[qt] + inc) - m_run[qt];   // m_run stays fp16-representable
                     const float alpha = (t == 0) ? 1.0f : __builtin_amdgcn_exp2f(-inc);    // O and l are still 0 on the first tile
                     m_run[qt] += inc;
                     if constexpr (!ONES) l_run[qt] *= alpha;
@@ -265,8 +274,13 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(gl_attn_args p, int flags
                     for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) o[qt][dt][r] *= alpha;
+                    if constexpr (PRE == 1) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) negm[qt][r] = -m_run[qt];
+                        for (int r = 0; r < 16; ++r) negm[qt][r] = -m_run[qt];
+                    } else {
+                        // pad column d = DQK - 8 of this query's Q row: last k-step, upper lane half, first element
+                        if (hi == 1) qf[qt][NKS - 1][0] = (half_t)(-m_run[qt]);
+                    }
 #pragma unroll
                     for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
@@ -399,8 +413,9 @@ int launch_attn(const gl_attn_args& a, hipStream_t st) {
     const int flags = g_attn_setprio < 0 ? (DQK <= 48 ? 1 : 0) : g_attn_setprio;
     // the C-init form needs 16 more registers: measured +9 % at d = 80 (35.1 vs 38.4 us, N = 1024) but -12 % at d = 40, where
     // the kernel lives on 8 waves per SIMD (60 -> 76 registers drops it to 6)
-    if (a.q_prescaled && DQK >= 80) attn_kernel<DQK, QT, NW, true><<<grid, dim3(64 * NW), 0, st>>>(a, flags);
-    else attn_kernel<DQK, QT, NW, false><<<grid, dim3(64 * NW), 0, st>>>(a, flags);
+    if (a.q_prescaled && DQK >= 80) attn_kernel<DQK, QT, NW, 1><<<grid, dim3(64 * NW), 0, st>>>(a, flags);
+    else if (a.q_prescaled && g_attn_padmax && a.d + 8 == DQK) attn_kernel<DQK, QT, NW, 2><<<grid, dim3(64 * NW), 0, st>>>(a, flags);
+    else attn_kernel<DQK, QT, NW, 0><<<grid, dim3(64 * NW), 0, st>>>(a, flags);
     GL_CHECK_LAUNCH();
     return 0;
 }
@@ -440,6 +455,7 @@ extern "C" int gl_attention(const gl_attn_args* a, void* stream) {
 extern "C" int gl_set_option_attn(int key, int value) {
     if (key == 3) { g_attn_qt2 = value; return 0; }
     if (key == 10) { g_attn_setprio = value; return 0; }
+    if (key == 29) { g_attn_padmax = value; return 0; }
     return GL_ERR_BAD_ARG;
 }
 

@@ -246,7 +246,7 @@ extern "C" int gl_set_option(int key, int value) {
     if (key == 16 || key == 17) return gl_set_option_norm(key, value);
     if (key == 26 || key == 27) return gl_set_option_ff(key, value);
     if (key == 20 || key == 21 || key == 25) return gl_set_option_engine(key, value);
-    return (key == 3 || key == 10) ? gl_set_option_attn(key, value) : gl_set_option_gemm(key, value);   // 1,2,4-9: GEMM knobs
+    return (key == 3 || key == 10 || key == 29) ? gl_set_option_attn(key, value) : gl_set_option_gemm(key, value);   // 1,2,4-9: GEMM knobs
 }
 
 extern "C" int gl_abi_version(void) { return GL_ABI_VERSION; }

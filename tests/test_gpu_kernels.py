@@ -478,6 +478,38 @@ def test_attention_prescaled_q(d, H, Nq, Nk, B):
     check(out, ref, f"attn_prescaled_d{d}_q{Nq}_k{Nk}", rtol=2e-3, atol=2e-4)
 
 
+def test_attention_padding_column_max_vs_fma_path():
+    """d = 40 (padded to 48): with q_prescaled the running max travels in the operands' padding column (K pad column = 1.0,
+    Q pad column = -m, fp16) so the QK^T MFMA delivers logit - m; gl_set_option(29, 0) restores the FMA path.  Both must match
+    the reference and each other on logits of every size (rows whose max is tiny, huge, negative; a late outlier; ragged Nq / Nk;
+    the 8 head-dim padded d = 24 case as well)."""
+    for (d, H, Nq, Nk, B) in [(40, 8, 300, 1054, 1), (40, 8, 4096, 4126, 1), (24, 4, 130, 200, 2), (8, 2, 64, 70, 1)]:
+        test_attention_prescaled_q(d, H, Nq, Nk, B)
+        from layoutllm_t2i_amd.weights import q_fold
+        C = H * d
+        q = rnd(f"pmq{d}{Nq}", (B, Nq, C))
+        q[:, 0] *= 60.0
+        q[:, 2] *= 1e-3
+        k = rnd(f"pmk{d}{Nk}", (B, Nk, C))
+        k[:, Nk - 2] = -q[:, 3] * 5.0                      # a late key far BELOW query 3's max, and (by symmetry) far above others'
+        _, qd = h16(q * q_fold(d))
+        _, kd = h16(k)
+        _, vd = h16(rnd(f"pmv{d}{Nk}", (B, Nk, C)))
+        vt = torch.full((B, H, d, ops.vt_ld(Nk)), float("nan"), dtype=torch.float16, device=DEV)
+        ops.transpose_v(vd, Nk * C, C, vt, B, H, d, Nk)
+        o1 = torch.empty(B, Nq, C, dtype=torch.float16, device=DEV)
+        o0 = torch.empty_like(o1)
+        ops.attention(qd, Nq * C, C, kd, Nk * C, C, vt, o1, Nq * C, C, B, H, d, Nq, Nk, 1.0, q_prescaled=True)
+        ops.set_option(29, 0)
+        try:
+            ops.attention(qd, Nq * C, C, kd, Nk * C, C, vt, o0, Nq * C, C, B, H, d, Nq, Nk, 1.0, q_prescaled=True)
+        finally:
+            ops.set_option(29, 1)
+        assert torch.isfinite(o1).all()
+        dl = float((o1.float() - o0.float()).norm() / o0.float().norm())
+        assert dl < 6e-4, (d, Nq, Nk, dl)                  # two roundings of P to fp16 about different reference maxima
+
+
 @pytest.mark.parametrize("opt", [3, 4])
 def test_attention_block_size_variants(opt):
     """8-wave (256-query) and 4-wave blocks forced via gl_set_option(3, 3|4); includes a ragged last slab"""
