@@ -352,7 +352,7 @@ int gl_sizeof_attn_args(void);
  * 3 always 8 waves, 4 always 4 waves); keys 4-7 = small-tile / split-K / 256-row-tile thresholds; key 8 = short-K GEGLU
  * GEMMs on the BK 32 / 4-blocks-per-CU variant (1 default, 0 off); key 10 = s_setprio around the attention MFMA
  * clusters (-1 auto, 0 off, 1 on); key 13 = intra-block K-split GEMM/conv variants (0 off, 1 auto = default, 2 always);
- * key 16 = GroupNorm apply pixels per block; key 17 = single-launch small-map GroupNorm (1 default, 0 off); key 20 = (tests) execute the gated-SA fuser even at fuser_scale 0;
+ * key 16 = GroupNorm apply pixels per block; key 17 = single-launch GroupNorm kernels (1 default: small maps + group bundles up to 80 KB per block, 2 = small maps only, 0 off); key 20 = (tests) execute the gated-SA fuser even at fuser_scale 0;
  * key 21 = V^T written by the QKV GEMM epilogue (1, default) or by gl_transpose_v (0); key 23 = output-tile order (0 N-tiles
  * fastest, 1 = default: M-tiles fastest when the weight matrix is the larger operand, so each XCD's L2 streams only its
  * slice of the weights, 2 always M-fastest); key 24 = skinny-GEMM kernel (M <= 1024 rows, register operands, four waves split

@@ -319,6 +319,117 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const half_t* __restrict_
     }
 }
 
+// Single-launch GroupNorm for channel widths whose groups are NOT whole 8-channel vectors (C = 320 / 640 / 960 / 1920:
+// 10 / 20 / 30 / 60 channels per group): one block per (sample, BUNDLE of groups) where a bundle is the smallest run of
+// groups that is a whole number of vectors (lcm(cpg, 8) channels: 4 / 2 / 4 / 2 groups).  The bundle's HW x BC slab is
+// loaded once into registers (NV vectors per thread, up to 1024 threads), per-group statistics are taken two-pass (a
+// vector spans at most two groups: it contributes a low and a high part), and the rows are normalised from the
+// registers -- one read + one write of the tensor instead of gn_stats (read) + gn_apply (read + write) in two
+// latency-bound launches.  80..240-byte pieces per pixel: ~80 % sector efficiency, still far cheaper than a second pass.
+template <int NV, int NT>
+__global__ __launch_bounds__(NT) void gn_bundle_kernel(const half_t* __restrict__ x1, int C1, const half_t* __restrict__ x2, int C2,
+                                                       int HW, int cpg, int gb, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps, int silu, half_t* __restrict__ out) {
+    constexpr int NWV = (NT + 63) / 64;
+    __shared__ float red[NWV][4];
+    __shared__ float stat[2][4];
+    const int C = C1 + C2;
+    const int bc = cpg * gb;                 // channels per bundle (multiple of 8)
+    const int nvp = bc / 8;                  // vectors per pixel; NT % nvp == 0 (launcher), so a thread keeps ONE channel vector
+    const int ps = NT / nvp;                 // pixels covered per pass of the block
+    const int v = threadIdx.x % nvp;
+    const int pl = threadIdx.x / nvp;
+    const int c = blockIdx.x * bc + v * 8;   // this thread's 8 channels
+    const int b = blockIdx.y;
+    const int wave = threadIdx.x >> 6;
+    const int g0 = (v * 8) / cpg;            // group (within the bundle) of the vector's first channel
+    const int js = (g0 + 1) * cpg - v * 8;   // elements [0, js) belong to g0, the rest to g0 + 1 (a vector spans <= 2 groups)
+    const half_t* src = (c < C1) ? x1 + (size_t)b * HW * C1 + c : x2 + (size_t)b * HW * C2 + (c - C1);
+    const int sstride = (c < C1) ? C1 : C2;
+    // block-wide sums of the (up to 4) per-group values
+    auto bsum4 = [&](float lo, float hi, int slot) {
+        float vq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) vq[q] = wave_sum((q == g0 ? lo : 0.0f) + (q == g0 + 1 ? hi : 0.0f));
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) red[wave][q] = vq[q];
+        }
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            float t = 0.0f;
+            for (int w = 0; w < NWV; ++w) t += red[w][threadIdx.x];
+            stat[slot][threadIdx.x] = t;
+        }
+        __syncthreads();
+    };
+    uint4 raw[NV];
+    float lo = 0.0f, hi = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int p = pl + ps * k;
+        raw[k] = make_uint4(0u, 0u, 0u, 0u);
+        if (p < HW) {
+            raw[k] = ld16(src + (size_t)p * sstride);
+            const half8_t hv = *reinterpret_cast<half8_t*>(&raw[k]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float f = (float)hv[j];
+                if (j < js) lo += f; else hi += f;
+            }
+        }
+    }
+    const float n = (float)cpg * (float)HW;
+    bsum4(lo, hi, 0);
+    const int g1 = g0 + 1 < 4 ? g0 + 1 : 3;
+    const float m0 = stat[0][g0] / n, m1 = stat[0][g1] / n;
+    lo = 0.0f; hi = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        if (pl + ps * k < HW) {
+            const half8_t hv = *reinterpret_cast<half8_t*>(&raw[k]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = (float)hv[j] - (j < js ? m0 : m1);
+                if (j < js) lo = fmaf(d, d, lo); else hi = fmaf(d, d, hi);
+            }
+        }
+    }
+    bsum4(lo, hi, 1);
+    const float r0 = rsqrtf(stat[1][g0] / n + eps), r1 = rsqrtf(stat[1][g1] / n + eps);
+    // per-channel scale / shift: y = x * sc + sh
+    float sc[8], sh[8];
+    {
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + c), gb4 = *reinterpret_cast<const float4*>(gamma + c + 4);
+        const float4 ba = *reinterpret_cast<const float4*>(beta + c), bb4 = *reinterpret_cast<const float4*>(beta + c + 4);
+        const float gm[8] = {ga.x, ga.y, ga.z, ga.w, gb4.x, gb4.y, gb4.z, gb4.w};
+        const float bt[8] = {ba.x, ba.y, ba.z, ba.w, bb4.x, bb4.y, bb4.z, bb4.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float m = j < js ? m0 : m1, r = j < js ? r0 : r1;
+            sc[j] = r * gm[j];
+            sh[j] = bt[j] - m * sc[j];
+        }
+    }
+    half_t* dst = out + (size_t)b * HW * C + c;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int p = pl + ps * k;
+        if (p < HW) {
+            const half8_t hv = *reinterpret_cast<half8_t*>(&raw[k]);
+            half8_t ov;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float val = fmaf((float)hv[j], sc[j], sh[j]);
+                if (silu) val = silu_f(val);
+                ov[j] = (half_t)val;
+            }
+            st16(dst + (size_t)p * C, *reinterpret_cast<uint4*>(&ov));
+        }
+    }
+}
+
 // One wave per row; up to NV x 64 8-channel vectors per row.  XF32: the input row is fp32 (the residual stream), else
 // fp16.  Two-pass statistics in registers (mean, then sum of squared deviations).  Optionally stores (mean, rstd) per
 // input row so that a consumer can re-evaluate the normalisation in fp32 (rela_merge).
@@ -449,17 +560,62 @@ extern "C" int gl_groupnorm_apply(const void* x1, int32_t C1, const void* x2, in
 }
 
 // how many launches gl_groupnorm issues for this shape: 1 (fused small-map kernel) or 2 (statistics + apply)
+// bundle geometry of gn_bundle_kernel: groups per bundle (1, 2 or 4) such that the bundle is whole 8-channel vectors
+static inline int gn_bundle_groups(int C) {
+    const int cpg = C / 32;
+    if (cpg % 8 == 0) return 1;
+    if ((2 * cpg) % 8 == 0) return 2;
+    if ((4 * cpg) % 8 == 0) return 4;
+    return 0;
+}
+
 extern "C" int gl_groupnorm_launches(int32_t C, int32_t HW) {
-    if (!g_gn_fused || (C % 256) != 0) return 2;
-    const int64_t vecs = (int64_t)HW * (C / 256);
-    return vecs <= 256 * 10 ? 1 : 2;
+    if (!g_gn_fused) return 2;
+    if ((C % 256) == 0) {
+        const int64_t vecs = (int64_t)HW * (C / 256);
+        if (vecs <= 256 * 10) return 1;
+    }
+    if (g_gn_fused >= 2) return 2;                      // A/B: 2 = the small-map kernel only
+    const int gb = gn_bundle_groups(C);
+    if (gb == 0 || C / 32 < 8) return 2;                // a vector must span at most two groups
+    const int nvp = (C / 32) * gb / 8;                   // 5, 10 or 15 vectors per pixel
+    if (nvp != 5 && nvp != 10 && nvp != 15) return 2;
+    // one block moves the whole HW x bundle slab: measured faster than the two launches up to 80 KB per block (640 ch @ 32x32:
+    // 17.4 -> 15.0 us, 640 ch @ 16x16: 15.5 -> 8.1 us), slower beyond (320 ch @ 64x64 = 320 KB per block on 64 blocks: 22.8 -> 43 us)
+    if ((int64_t)HW * nvp * 16 > 80 * 1024) return 2;
+    return gl_cdiv(HW, 960 / nvp) <= 22 ? 1 : 2;        // and the slab fits the registers of one 960-thread block
 }
 
 extern "C" int gl_groupnorm(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t B, int32_t HW, const float* gamma,
                             const float* beta, float eps, int32_t silu, void* out, float* partial, int32_t nchunk, void* stream) {
     const int C = C1 + (x2 ? C2 : 0);
     if (!x1 || !gamma || !beta || !out || C <= 0 || (C % 32) || (C1 % 8) || (x2 && (C2 % 8))) return GL_ERR_BAD_ARG;
-    if (gl_groupnorm_launches(C, HW) == 1) {
+    const bool small_map = g_gn_fused && (C % 256) == 0 && (int64_t)HW * (C / 256) <= 256 * 10;
+    if (!small_map && gl_groupnorm_launches(C, HW) == 1) {
+        const int cpg = C / 32, gb = gn_bundle_groups(C);
+        const dim3 grid(32 / gb, B);
+        const half_t* a = reinterpret_cast<const half_t*>(x1);
+        const half_t* b2 = reinterpret_cast<const half_t*>(x2);
+        half_t* o = reinterpret_cast<half_t*>(out);
+        hipStream_t st = (hipStream_t)stream;
+        const int c2 = x2 ? C2 : 0;
+#define GL_GNB(V, T) gn_bundle_kernel<V, T><<<grid, dim3(T), 0, st>>>(a, C1, b2, c2, HW, cpg, gb, gamma, beta, eps, silu, o)
+        // block sizes that are whole multiples of the vectors per pixel (5, 10 or 15): 320 = 5 waves, 960 = 15 waves
+        const int nvp = cpg * gb / 8;
+        if (nvp == 15) {
+            const int passes = gl_cdiv(HW, 960 / 15);
+            if (passes <= 4) GL_GNB(4, 960); else if (passes <= 8) GL_GNB(8, 960); else if (passes <= 16) GL_GNB(16, 960); else GL_GNB(22, 960);
+        } else {
+            const int p320 = gl_cdiv(HW, 320 / nvp);
+            const int p960 = gl_cdiv(HW, 960 / nvp);
+            if (p320 <= 4) GL_GNB(4, 320); else if (p320 <= 8) GL_GNB(8, 320);
+            else if (p960 <= 8) GL_GNB(8, 960); else if (p960 <= 16) GL_GNB(16, 960); else GL_GNB(22, 960);
+        }
+#undef GL_GNB
+        GL_CHECK_LAUNCH();
+        return 0;
+    }
+    if (small_map) {
         const int64_t vecs = (int64_t)HW * (C / 256);
         const dim3 grid(32, B), blk(256);
         const half_t* a = reinterpret_cast<const half_t*>(x1);

@@ -567,27 +567,35 @@ def test_groupnorm(C1, C2, HW, silu, eps):
     check(out, ref.permute(0, 2, 1).reshape(B * HW, C), f"groupnorm_{C1}+{C2}_{HW}")
 
 
-def test_groupnorm_single_launch_form_matches_two_launch_form():
-    """the small-map single-launch kernel (knob 17) against the statistics + apply pair on the same input: same result to fp16
-    rounding (different fp32 summation order), and the launch-count query tells which form a shape takes"""
+@pytest.mark.parametrize("C1,C2,HW", [(1280, 1280, 256), (320, 0, 1024), (640, 320, 256), (640, 0, 1024), (1280, 640, 256), (1280, 0, 576), (320, 0, 100)])
+def test_groupnorm_single_launch_form_matches_two_launch_form(C1, C2, HW):
+    """the single-launch kernels (knob 17: whole-vector groups on small maps; group BUNDLES of 2 / 4 groups where a group is
+    10 / 20 / 30 / 60 channels) against the statistics + apply pair on the same input: same result to fp16 rounding (different
+    fp32 summation order); the launch-count query tells which form a shape takes"""
     from layoutllm_t2i_amd import _lib
     l = _lib.lib()
     assert l.gl_groupnorm_launches(1280, 256) == 1 and l.gl_groupnorm_launches(2560, 256) == 1 and l.gl_groupnorm_launches(1280, 64) == 1
-    assert l.gl_groupnorm_launches(320, 4096) == 2 and l.gl_groupnorm_launches(1920, 256) == 2 and l.gl_groupnorm_launches(1280, 576) == 2
-    B, C1, C2, HW = 2, 1280, 1280, 256
-    x1, x1d = h16(rnd("gf1", (B * HW, C1)) * 1.3 + 0.4)
-    x2, x2d = h16(rnd("gf2", (B * HW, C2)) * 0.6 - 3.0)
-    gam, bet = (1 + 0.1 * rnd("gfg", (C1 + C2,))).to(DEV), (0.1 * rnd("gfb", (C1 + C2,))).to(DEV)
+    assert l.gl_groupnorm_launches(640, 1024) == 1 and l.gl_groupnorm_launches(1920, 256) == 1 and l.gl_groupnorm_launches(320, 1024) == 1
+    assert l.gl_groupnorm_launches(320, 4096) == 2 and l.gl_groupnorm_launches(960, 1024) == 2 and l.gl_groupnorm_launches(128, 4096) == 2   # > 80 KB per block / 4-channel groups
+    B = 2
+    C = C1 + C2
+    assert l.gl_groupnorm_launches(C, HW) == 1
+    x1, x1d = h16(rnd(f"gf1{C1}{HW}", (B * HW, C1)) * 1.3 + 0.4)
+    x2d = None
+    if C2:
+        _, x2d = h16(rnd(f"gf2{C2}{HW}", (B * HW, C2)) * 0.6 - 3.0)
+    gam, bet = (1 + 0.1 * rnd(f"gfg{C}", (C,))).to(DEV), (0.1 * rnd(f"gfb{C}", (C,))).to(DEV)
     partial = torch.empty(B * 64 * 64, dtype=torch.float32, device=DEV)
-    a, b = (torch.empty(B * HW, C1 + C2, dtype=torch.float16, device=DEV) for _ in range(2))
-    ops.groupnorm(x1d, x2d, B, HW, gam, bet, 1e-5, True, a, partial)
+    a, b = (torch.full((B * HW + 3, C), 7.0, dtype=torch.float16, device=DEV) for _ in range(2))
+    ops.groupnorm(x1d, x2d, B, HW, gam, bet, 1e-5, True, a[:B * HW], partial)
     ops.set_option(17, 0)
     try:
-        ops.groupnorm(x1d, x2d, B, HW, gam, bet, 1e-5, True, b, partial)
+        ops.groupnorm(x1d, x2d, B, HW, gam, bet, 1e-5, True, b[:B * HW], partial)
     finally:
         ops.set_option(17, 1)
     d = (a.float() - b.float()).abs()
-    assert float(d.max()) <= 2e-3 and float((d > 0).float().mean()) < 0.02, (float(d.max()), float((d > 0).float().mean()))
+    assert float(d.max()) <= 4e-3 and float((d > 0).float().mean()) < 0.03, (float(d.max()), float((d > 0).float().mean()))
+    assert float((a[B * HW:].float() - 7.0).abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("C1,C2,HW", [(320, 0, 4096), (640, 320, 1024), (1280, 0, 144), (1280, 0, 256), (2560, 0, 64)])
