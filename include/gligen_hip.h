@@ -357,8 +357,7 @@ int gl_sizeof_attn_args(void);
  * fastest, 1 = default: M-tiles fastest when the weight matrix is the larger operand, so each XCD's L2 streams only its
  * slice of the weights, 2 always M-fastest); key 24 = skinny-GEMM kernel (M <= 1024 rows, register operands, four waves split
  * K) while its operand re-reads stay below this many MiB (64 default, 0 = LDS-staged kernels only); key 25 = gl_rela_merge
- * also writes the following LayerNorm (1, default) or a separate gl_layernorm launch does (0); key 26 = gl_ff_fused timing
- * ablations (results wrong when != 0); key 27 = fused FeedForward where applicable (1, default) or never (0); key 29 =
+ * also writes the following LayerNorm (1, default) or a separate gl_layernorm launch does (0); key 27 = fused FeedForward where applicable (1, default) or never (0); key 29 =
  * attention keeps the running max in the padding column of Q / K where the head dim leaves one (d % 16 == 8; 1 default, 0 off). */
 int gl_set_option(int key, int value);
 /* one-time per-process setup (raises dynamic-LDS limits of the tiled kernels); idempotent */

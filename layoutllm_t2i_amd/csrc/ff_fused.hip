@@ -32,7 +32,6 @@ __device__ __forceinline__ f32x16 ff_mfma(half8_t a, half8_t b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
-int g_ff_dbg = 0;      // timing ablations (gl_set_option 26); results are WRONG when != 0
 int g_ff_enable = 1;   // gl_set_option 27: 0 = gl_ff_fused_applicable answers no (two-launch FeedForward everywhere)
 
 template <int C>
@@ -50,9 +49,8 @@ struct FFGeom {
     static constexpr int LDS = B1_BASE + 8 * C * 4;   // rings + the packed GEGLU bias
 };
 
-template <int C, int DBG = 0>
+template <int C>
 __global__ __launch_bounds__(256, 1) void ff_fused_kernel(gl_ff_args p) {
-    constexpr int dbg = DBG;
     using G = FFGeom<C>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -132,7 +130,7 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(gl_ff_args p) {
     // then the erf arithmetic of chunk j (VALU) INTERLEAVED with phase 2 of chunk j - 1 (MFMA, independent of it); the
     // MFMAs execute in the matrix pipe while the wave keeps issuing the GELU instructions.
     constexpr int TG = 2;                                         // output tiles per phase-2 fragment group (NT2 is even)
-    constexpr int NTG = ((dbg & 4) ? TG : G::NT2) / TG;           // dbg 4: timing ablation, first group only
+    constexpr int NTG = G::NT2 / TG;
     half8_t hprev[2];
 #pragma unroll
     for (int q = 0; q < 8; ++q) { hprev[0][q] = (half_t)0.0f; hprev[1][q] = (half_t)0.0f; }
@@ -162,8 +160,7 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(gl_ff_args p) {
     for (int j = 0; j < G::NCH; ++j) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my share of chunk j has landed
         __syncthreads();                                       // ... everyone's has; W1 slot (j+1)&1 and W2 slot (j+1)%3 are free
-        if (j + 1 < G::NCH && !((dbg & 1) && j >= 2)) issue(j + 1);      // dbg 1: timing ablation, weights streamed for three chunks only
-        if constexpr ((dbg & 8) != 0) continue;               // dbg 8: timing ablation, weight stream + barriers only
+        if (j + 1 < G::NCH) issue(j + 1);
         const unsigned char* st = smem + (j & 1) * G::W1_BYTES;
         const unsigned char* w2prev = smem + G::W2_BASE + slot3 * G::W2_BYTES;
         slot3 = (j == 0) ? 0 : (slot3 == 2 ? 0 : slot3 + 1);  // -> j % 3
@@ -216,7 +213,7 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(gl_ff_args p) {
             for (int t = 0; t < 4; ++t) {
                 const float a = sx[rg * 4 + t] + bxs[t];
                 const float b = sg[rg * 4 + t] + bgs[t];
-                hf[rg >> 1][(rg & 1) * 4 + t] = (half_t)((dbg & 2) ? a * b : a * gelu_erf_f(b));     // dbg 2: ablation without the erf
+                hf[rg >> 1][(rg & 1) * 4 + t] = (half_t)(a * gelu_erf_f(b));
             }
             // a quarter of the previous chunk's phase 2 after every quarter of the erf work; fragments one group ahead
 #pragma unroll
@@ -229,7 +226,7 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(gl_ff_args p) {
         hprev[1] = hf[1];
         __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr ((dbg & 8) == 0) {
+    {
         // phase 2 of the last chunk
         const unsigned char* w2last = smem + G::W2_BASE + ((G::NCH - 1) % 3) * G::W2_BYTES;
         uint4 wva[TG][2];
@@ -282,16 +279,6 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(gl_ff_args p) {
 template <int C>
 int ff_launch(const gl_ff_args& a, hipStream_t st) {
     using G = FFGeom<C>;
-    if constexpr (C == 320) {
-        // timing ablations (results wrong): compile-time variants so that the register arrays stay statically indexed
-        const dim3 g(gl_cdiv(a.M, 128)), b(256);
-        if (g_ff_dbg == 1) { ff_fused_kernel<C, 1><<<g, b, G::LDS, st>>>(a); GL_CHECK_LAUNCH(); return 0; }
-        if (g_ff_dbg == 2) { ff_fused_kernel<C, 2><<<g, b, G::LDS, st>>>(a); GL_CHECK_LAUNCH(); return 0; }
-        if (g_ff_dbg == 4) { ff_fused_kernel<C, 4><<<g, b, G::LDS, st>>>(a); GL_CHECK_LAUNCH(); return 0; }
-        if (g_ff_dbg == 3) { ff_fused_kernel<C, 3><<<g, b, G::LDS, st>>>(a); GL_CHECK_LAUNCH(); return 0; }
-        if (g_ff_dbg == 7) { ff_fused_kernel<C, 7><<<g, b, G::LDS, st>>>(a); GL_CHECK_LAUNCH(); return 0; }
-        if (g_ff_dbg == 8) { ff_fused_kernel<C, 8><<<g, b, G::LDS, st>>>(a); GL_CHECK_LAUNCH(); return 0; }
-    }
     ff_fused_kernel<C><<<dim3(gl_cdiv(a.M, 128)), dim3(256), G::LDS, st>>>(a);
     GL_CHECK_LAUNCH();
     return 0;
@@ -302,14 +289,6 @@ int ff_launch(const gl_ff_args& a, hipStream_t st) {
 template <int C>
 int ff_set_attr() {
     hipError_t e = hipFuncSetAttribute((const void*)ff_fused_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, FFGeom<C>::LDS);
-    if constexpr (C == 320) {
-        hipFuncSetAttribute((const void*)ff_fused_kernel<C, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FFGeom<C>::LDS);
-        hipFuncSetAttribute((const void*)ff_fused_kernel<C, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, FFGeom<C>::LDS);
-        hipFuncSetAttribute((const void*)ff_fused_kernel<C, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, FFGeom<C>::LDS);
-        hipFuncSetAttribute((const void*)ff_fused_kernel<C, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, FFGeom<C>::LDS);
-        hipFuncSetAttribute((const void*)ff_fused_kernel<C, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, FFGeom<C>::LDS);
-        hipFuncSetAttribute((const void*)ff_fused_kernel<C, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, FFGeom<C>::LDS);
-    }
     return e == hipSuccess ? 0 : (int)e;
 }
 
@@ -324,7 +303,6 @@ extern "C" int gl_init_ff(void) {
 }
 
 extern "C" int gl_set_option_ff(int key, int value) {
-    if (key == 26) { g_ff_dbg = value; return 0; }
     if (key == 27) { g_ff_enable = value; return 0; }
     return GL_ERR_BAD_ARG;
 }

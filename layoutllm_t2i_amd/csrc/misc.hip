@@ -244,7 +244,7 @@ int g_gl_option_epoch = 0;
 extern "C" int gl_set_option(int key, int value) {
     ++g_gl_option_epoch;
     if (key == 16 || key == 17) return gl_set_option_norm(key, value);
-    if (key == 26 || key == 27) return gl_set_option_ff(key, value);
+    if (key == 27) return gl_set_option_ff(key, value);
     if (key == 20 || key == 21 || key == 25) return gl_set_option_engine(key, value);
     return (key == 3 || key == 10 || key == 29) ? gl_set_option_attn(key, value) : gl_set_option_gemm(key, value);   // 1,2,4-9: GEMM knobs
 }

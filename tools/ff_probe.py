@@ -33,10 +33,7 @@ for M in [int(a) for a in sys.argv[1:]] or [32768]:
     def fused():
         ops.ff_fused(x, w1, b1, w2, b2, res, out)
 
-    DBG = [int(v) for v in os.environ.get("FF_DBG", "").split(",") if v]
-    runs = [("two-launch", two, 0), ("fused", fused, 0), ("two-launch", two, 0), ("fused", fused, 0)] + [(f"fused dbg={d}", fused, d) for d in DBG]
-    for name, fn, dbg in runs:
-        ops.set_option(26, dbg)
+    for name, fn in (("two-launch", two), ("fused", fused), ("two-launch", two), ("fused", fused)):
         for _ in range(5):
             fn()
         torch.cuda.synchronize()
