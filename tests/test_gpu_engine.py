@@ -167,3 +167,40 @@ def test_plms_step_composite_equals_separate_calls():
     xa = x.clone()
     eng.plms_step(xa, xa, xa, e_out, [e_out] + old, coefs, div, 601.0, 2, 7.5, 1.0, False, sq_at, s1m, sq_ap, dirc)
     assert torch.equal(xa, x2)
+
+
+def test_two_engines_interleaved_and_option_toggles():
+    """Two engines of DIFFERENT architectures alive in one process, forwards interleaved, a process-global A/B knob flipped
+    in between (gl_set_option bumps an epoch that invalidates captured graphs): every output must equal the engine's own
+    solo result bit for bit -- handles share no activation state, and the knob state never leaks into a replayed graph."""
+    cfg_b = UNetConfig(image_size=16, model_channels=128, num_heads=8, channel_mult=(1, 2), attention_resolutions=(1, 2), num_res_blocks=1,
+                       context_dim=128, pos_in_dim=64, pos_out_dim=128)
+    ea, _ = engines(TINY, seed=1)
+    eb, _ = engines(cfg_b, seed=2)
+    ia = {k: T(v) for k, v in recipe.synth_inputs(TINY, 2, 16, n_boxes=5, n_rel=2, seed=21).items()}
+    ib = {k: T(v) for k, v in recipe.synth_inputs(cfg_b, 3, 24, n_boxes=9, n_rel=4, seed=22).items()}
+    xa, xb = ia["x"].to(DEV), ib["x"].to(DEV)
+    ea.set_conditioning(ia["context"], ia["relations"], ia["boxes"], ia["masks"], ia["positive_embeddings"], 16)
+    solo_a = [ea.forward(xa, 481.0, 1.0, False, 1).clone(), ea.forward(xa, 201.0, 0.0, True, 1).clone()]
+    eb.set_conditioning(ib["context"], ib["relations"], ib["boxes"], ib["masks"], ib["positive_embeddings"], 24)
+    solo_b = [eb.forward(xb, 481.0, 1.0, False, 1).clone(), eb.forward(xb, 201.0, 0.0, True, 1).clone()]
+    for rnd_ in range(3):
+        assert torch.equal(ea.forward(xa, 481.0, 1.0, False, 1), solo_a[0])
+        assert torch.equal(eb.forward(xb, 201.0, 0.0, True, 1), solo_b[1])
+        assert torch.equal(ea.forward(xa, 201.0, 0.0, True, 1), solo_a[1])
+        assert torch.equal(eb.forward(xb, 481.0, 1.0, False, 1), solo_b[0])
+        if rnd_ == 0:
+            # a knob that changes the launch sequence (LayerNorm inside rela_merge or as its own launch): results are
+            # bit-identical by construction, the graphs must be re-captured, and flipping it back restores the launch count
+            n1 = ea.num_launches()
+            ops.set_option(25, 0)
+            try:
+                assert torch.equal(ea.forward(xa, 481.0, 1.0, False, 1), solo_a[0])
+                assert ea.num_launches() > n1
+                assert torch.equal(eb.forward(xb, 481.0, 1.0, False, 1), solo_b[0])
+            finally:
+                ops.set_option(25, 1)
+    # destroying one engine leaves the other intact
+    del ea
+    torch.cuda.synchronize()
+    assert torch.equal(eb.forward(xb, 481.0, 1.0, False, 1), solo_b[0])
