@@ -358,8 +358,14 @@ int gl_sizeof_attn_args(void);
  * slice of the weights, 2 always M-fastest); key 24 = skinny-GEMM kernel (M <= 1024 rows, register operands, four waves split
  * K) while its operand re-reads stay below this many MiB (64 default, 0 = LDS-staged kernels only); key 25 = gl_rela_merge
  * also writes the following LayerNorm (1, default) or a separate gl_layernorm launch does (0); key 27 = fused FeedForward where applicable (1, default) or never (0); key 29 =
- * attention keeps the running max in the padding column of Q / K where the head dim leaves one (d % 16 == 8; 1 default, 0 off). */
+ * attention keeps the running max in the padding column of Q / K where the head dim leaves one (d % 16 == 8; 1 default, 0 off);
+ * key 30 = 8-wave deep-pipelined 256-row GEMM / conv kernel (0 off, 1 default: problems with at least key-31 (200) such tiles,
+ * 2 wherever it applies, with split-K); key 32 = (measurement) its timestamping instantiation, see gl_debug_read. */
 int gl_set_option(int key, int value);
+/* measurement hook (tools/g8_probe.py): what = 8 copies the per-block cycle stamps [entry, prologue done, main loop done,
+ * epilogue done] (4 x uint64 per block, up to 4096 blocks) that the timestamping instantiation of the 8-wave GEMM / conv
+ * kernel writes while gl_set_option(32, 1) is in effect.  Synchronous device-to-host copy. */
+int gl_debug_read(int what, void* dst, int64_t bytes);
 /* one-time per-process setup (raises dynamic-LDS limits of the tiled kernels); idempotent */
 int gl_init(void);
 

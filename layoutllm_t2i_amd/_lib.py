@@ -157,6 +157,7 @@ PROTOTYPES = {
     "gl_ff_fused_applicable": (i32, [i32, i32]),
     "gl_sizeof_ff_args": (i32, []),
     "gl_set_option": (i32, [i32, i32]),
+    "gl_debug_read": (i32, [i32, vp, i64]),
 }
 
 _lib = None

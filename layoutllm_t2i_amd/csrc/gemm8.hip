@@ -1,0 +1,517 @@
+// 8-wave deep-pipelined fp16 MFMA GEMM / implicit-GEMM 3x3 convolution for gfx950: the large-tile companion of the
+// 4-wave kernels in gemm_conv.hip (same arguments, same epilogues, same results up to fp32 summation order).
+//
+//   out[M, N] = A[M, K] . W[N, K]^T (+ epilogue),  A plain / two-source / implicit im2col (see gemm_conv.hip)
+//
+// Why a second kernel: the 4-wave kernels keep ONE K-tile of LDS-DMA in flight per block and drain it (vmcnt(0) +
+// __syncthreads) before every K-step, so the matrix pipe idles on operand delivery (round-2 PMC: MFMA busy 31 %, 66 % of
+// the wave cycles waiting / stalled).  Here:
+//   * block tile 256 x BN (BN = 160 for the UNet's N = 320 k channel widths, 128 otherwise), BK = 64, 512 threads = 8 waves,
+//     one block per CU; wave tile 64 x BN/2 from v_mfma_f32_16x16x32_f16 (BN/2 = 80 is not a multiple of 32);
+//   * a THREE-stage LDS ring (3 x 52 KiB at BN = 160) filled by global_load_lds_dwordx4; loads of K-tile t+2 are issued
+//     while K-tile t is consumed and are NEVER drained inside the loop: s_waitcnt vmcnt(N) with N counted so that exactly
+//     the pieces the NEXT phase reads have landed, then a raw s_barrier (a __syncthreads() would emit vmcnt(0));
+//   * two phases per K-tile (the wave's two 32-row halves), each = [ds_read fragments + issue LDS-DMA] barrier [MFMA]
+//     barrier, and the two wave groups (waves 0-3 / 4-7 = the two N halves; waves w and w+4 share a SIMD) run ONE barrier
+//     interval apart, so on every SIMD one wave feeds the matrix pipe while the other reads LDS and issues loads
+//     (s_setprio 1 around the MFMA cluster);
+//   * per-wave issue order inside a K-tile: A rows of the first halves (2 x 1 KiB), the B tile (2-3 x 1 KiB), A rows of
+//     the second halves (2 x 1 KiB) = the order they are consumed.
+// Hazards (cdna_hip_programming.md section 5, "read a staged buffer one phase AFTER the wait that retires it"):
+//   RAW  every wave's counted wait for the data of phase q+1 sits in its load section of phase q, followed by >= 1 barrier
+//        before any wave's reads of phase q+1 (2 for the lagging group);
+//   WAR  a stage is refilled two phases (>= 4 barriers) after the last ds_read of its previous contents was waited for.
+// LDS image, swizzle ((row >> 1) & 7 on the 16-byte chunk index, applied to the per-lane global SOURCE and to the fragment
+// reads), zero page for masked lanes, XCD-aware tile order and the epilogue's fp32 restaging are those of gemm_conv.hip.
+#include "common.h"
+#include "gligen_hip.h"
+#include "gemm_shared.h"
+
+namespace {
+
+template <int BN>
+struct G8 {
+    static constexpr int BM = 256;
+    static constexpr int BK = 64;
+    static constexpr int PW = BN / 2;                  // output columns per wave (N half)
+    static constexpr int TN = PW / 16;                 // 16-column MFMA tiles per wave: 5 / 4
+    static constexpr int A_BYTES = BM * BK * 2;        // 32 KiB
+    static constexpr int B_BYTES = BN * BK * 2;        // 20 / 16 KiB
+    static constexpr int STAGE = A_BYTES + B_BYTES;
+    static constexpr int NST = 3;
+    static constexpr int LDS = NST * STAGE;            // 159744 / 147456 bytes
+    static constexpr int B_UNITS = BN / 8;             // 1-KiB wave instructions per B tile: 20 / 16
+    static constexpr int NB0 = (B_UNITS + 7) / 8;      // B instructions of a group-0 wave: 3 / 2
+    static constexpr int NB1 = B_UNITS / 4 - NB0;      // ... of a group-1 wave: 2 / 2
+    static constexpr int NI0 = 4 + NB0;                // LDS-DMA instructions per K-tile, group-0 wave
+    static constexpr int NI1 = 4 + NB1;
+    static_assert(PW % 16 == 0 && B_UNITS % 4 == 0 && NB1 >= 1, "tile shape");
+    static_assert(STAGE % 128 == 0, "stage alignment (the k-half XOR of the fragment offsets relies on it)");
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ f32x4 mfma16(half8_t a, half8_t b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+#define G8_SBAR()                              \
+    do {                                       \
+        __builtin_amdgcn_sched_barrier(0);     \
+        __builtin_amdgcn_s_barrier();          \
+        __builtin_amdgcn_sched_barrier(0);     \
+    } while (0)
+
+// per-block timestamps of the DBG instantiation (gl_set_option(32, 1) selects it; read back with gl_debug_read(8, ...)):
+// [entry, prologue done, main loop done, epilogue done] x up to 4096 blocks, written by wave 0 of each block
+__device__ unsigned long long g8_stamps[4 * 4096];
+
+template <int BN, bool CONV, bool DBG = false>
+__global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom cg, int splitk, int kt_per_split, int order_m) {
+    using C = G8<BN>;
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+    if constexpr (DBG) ts0 = __builtin_readcyclecounter();
+    constexpr int TN = C::TN, PW = C::PW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;             // N half; also the stagger group (waves w and w + 4 share a SIMD)
+    const int wm = wave & 3;               // 64-row slice of the block tile
+    const int M = p.M, N = p.N, K = p.K;
+
+    // tile order: as gemm_conv.hip (XCD-contiguous runs of logical tiles, M-tiles fastest when the weights are the larger operand)
+    const int nt = (N + BN - 1) / BN;
+    int tile;
+    {
+        const int nwg = gridDim.x;
+        const int bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7;
+        const int xcd = bid & 7, local = bid >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
+    const int mt_ = (M + C::BM - 1) / C::BM;
+    const int tmi = order_m ? tile % mt_ : tile / nt;
+    const int m0 = tmi * C::BM;
+    const int n0 = (order_m ? tile / mt_ : tile - tmi * nt) * BN;
+    const int kt_begin = blockIdx.z * kt_per_split;
+    const int kt_end = min(K / 64, kt_begin + kt_per_split);
+    const int nkt = kt_end - kt_begin;
+
+    const half_t* __restrict__ Ag = reinterpret_cast<const half_t*>(p.a);
+    const half_t* __restrict__ A2g = reinterpret_cast<const half_t*>(p.a2);
+    const half_t* __restrict__ Wg = reinterpret_cast<const half_t*>(p.w);
+    const half_t* zsrc = reinterpret_cast<const half_t*>(g_zero16);
+
+    // ---- staging state.  A unit u = (half hi = u >> 1, j = u & 1): 8 consecutive tile rows, lane -> (row, 16-byte slot).
+    //      Group-of-32 index rho0 = 16 * wave + 8 * j over the 128 "first half" (or "second half") rows of the tile.
+    const int srow = lane >> 3;            // row within the unit
+    const int sslot = lane & 7;            // LDS chunk slot within the 128-byte row
+    int a_dst[4];                          // wave-uniform LDS byte offset of the unit inside a stage
+    const half_t* aptr[4];
+    unsigned amask = 0u;
+    unsigned cmask[4];
+    int cbyx[4];
+    const int k_first = kt_begin * 64;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int trow0 = 64 * (wave >> 1) + 16 * (wave & 1) + 8 * (u & 1) + 32 * (u >> 1);
+        a_dst[u] = trow0 * 128;
+        const int r = trow0 + srow;
+        const int gc = (sslot ^ ((r >> 1) & 7)) << 3;
+        const int m = m0 + r;
+        const bool rowok = m < M;
+        aptr[u] = zsrc; cmask[u] = 0u; cbyx[u] = -1;
+        if constexpr (CONV) {
+            if (rowok) {
+                const int hw = cg.Hout * cg.Wout;
+                const int b = m / hw;
+                const int rr = m - b * hw;
+                const int oy = rr / cg.Wout;
+                const int ox = rr - oy * cg.Wout;
+                cbyx[u] = (b << 20) | (oy << 10) | ox;
+                if (!cg.ups) {
+                    unsigned mk = 0u;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const int iy = oy * cg.stride + t / 3 - 1, ix = ox * cg.stride + t % 3 - 1;
+                        if (iy >= 0 && iy < cg.Hin && ix >= 0 && ix < cg.Win) mk |= 1u << t;
+                    }
+                    cmask[u] = mk;
+                    aptr[u] = cg.in + ((size_t)(b * cg.Hin + oy * cg.stride) * cg.Win + ox * cg.stride) * cg.Cin + gc;
+                }
+            }
+        } else {
+            if (rowok) {
+                if (A2g != nullptr && k_first >= p.ksplit) aptr[u] = A2g + (size_t)m * p.lda2 + (k_first - p.ksplit) + gc;
+                else aptr[u] = Ag + (size_t)m * p.lda + k_first + gc;
+                amask |= 1u << u;
+            }
+        }
+    }
+    // B units of this wave: group 0 waves own NB0 each (units 0 .. 4*NB0-1), group 1 waves NB1 each
+    const int nb = grp ? C::NB1 : C::NB0;
+    const int bunit0 = grp ? 4 * C::NB0 + C::NB1 * (wave - 4) : C::NB0 * wave;
+    const half_t* bptr[C::NB0];
+    unsigned bmask = 0u;
+#pragma unroll
+    for (int j = 0; j < C::NB0; ++j) {
+        const int r = 8 * (bunit0 + j) + srow;
+        const int gc = (sslot ^ ((r >> 1) & 7)) << 3;
+        const int n = n0 + r;
+        const bool ok = (j < nb) && (r < BN) && (n < N);
+        bptr[j] = ok ? (Wg + (size_t)n * K + k_first + gc) : zsrc;
+        if (ok) bmask |= 1u << j;
+    }
+
+    // conv: (channel block, tap) of the K-tile the next issue refers to
+    int is_cblk = 0, is_tap = 0;
+    if constexpr (CONV) {
+        is_cblk = kt_begin / 9;
+        is_tap = kt_begin - is_cblk * 9;
+    }
+    int is_kt = kt_begin;                  // absolute K-tile index of the next issue
+
+    // A units [u_lo, u_hi) of K-tile is_kt into stage `st`
+    auto issue_a = [&](const int st, const int u_lo, const int u_hi) {
+        unsigned char* sbase = smem + st * C::STAGE;
+        if constexpr (CONV) {
+            const int ky = is_tap / 3;
+            const int kx = is_tap - ky * 3;
+            const int ci0 = is_cblk << 6;
+            if (!cg.ups) {
+                const int off = ((ky - 1) * cg.Win + (kx - 1)) * cg.Cin + ci0;     // wave-uniform
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (u < u_lo || u >= u_hi) continue;
+                    const half_t* src = ((cmask[u] >> is_tap) & 1u) ? (aptr[u] + off) : zsrc;
+                    glds16(src, reinterpret_cast<half_t*>(sbase + a_dst[u]));
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (u < u_lo || u >= u_hi) continue;
+                    const int r = (a_dst[u] >> 7) + srow;
+                    const int gc = (sslot ^ ((r >> 1) & 7)) << 3;
+                    const half_t* src = zsrc;
+                    if (cbyx[u] >= 0) {
+                        const int uy = ((cbyx[u] >> 10) & 1023) + ky - 1, ux = (cbyx[u] & 1023) + kx - 1;
+                        if ((uy >= 0) && (uy < cg.Hout) && (ux >= 0) && (ux < cg.Wout))
+                            src = cg.in + ((size_t)((cbyx[u] >> 20) * cg.Hin + (uy >> 1)) * cg.Win + (ux >> 1)) * cg.Cin + ci0 + gc;
+                    }
+                    glds16(src, reinterpret_cast<half_t*>(sbase + a_dst[u]));
+                }
+            }
+        } else {
+            if (u_lo == 0 && A2g != nullptr && is_kt * 64 == p.ksplit && is_kt != kt_begin) {
+                // two-source A: crossing into the second matrix, once per block, before the first unit of that K-tile
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = (a_dst[u] >> 7) + srow;
+                    const int m = m0 + r;
+                    if (m < M) aptr[u] = A2g + (size_t)m * p.lda2 + ((sslot ^ ((r >> 1) & 7)) << 3);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (u < u_lo || u >= u_hi) continue;
+                glds16(aptr[u], reinterpret_cast<half_t*>(sbase + a_dst[u]));
+                aptr[u] += ((amask >> u) & 1u) ? 64 : 0;
+            }
+        }
+    };
+    auto issue_b = [&](const int st) {
+        unsigned char* sbase = smem + st * C::STAGE + C::A_BYTES;
+#pragma unroll
+        for (int j = 0; j < C::NB0; ++j) {
+            if (j < nb) {       // wave-uniform
+                glds16(bptr[j], reinterpret_cast<half_t*>(sbase + (bunit0 + j) * 1024));
+                bptr[j] += ((bmask >> j) & 1u) ? 64 : 0;
+            }
+        }
+    };
+    auto issue_advance = [&]() {
+        ++is_kt;
+        if constexpr (CONV) {
+            if (++is_tap == 9) { is_tap = 0; ++is_cblk; }
+        }
+    };
+    auto wait_steady = [&]() {
+        if (C::NI0 == C::NI1 || grp == 0) wait_vm<C::NI0 + 2>();
+        else wait_vm<C::NI1 + 2>();
+    };
+
+    // ---- fragment read offsets (bytes inside a stage): row = base16 + (lane & 15), logical chunk = 4 * kk + (lane >> 4)
+    const int lr = lane & 15, lq = lane >> 4;
+    const int fsw = ((lq ^ ((lr >> 1) & 7)) << 4);
+    const int a_off = (64 * wm + lr) * 128 + fsw;                       // kk = 1: ^ 64
+    const int b_off = C::A_BYTES + (PW * grp + lr) * 128 + fsw;
+
+    f32x4 acc[4][TN];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mi][ni][r] = 0.0f;
+
+    // ---- prologue: K-tiles 0 and 1 in flight, the first phase's pieces of K-tile 0 landed
+    issue_a(0, 0, 2); issue_b(0); issue_a(0, 2, 4); issue_advance();
+    if (nkt > 1) {
+        issue_a(1, 0, 2); issue_b(1); issue_a(1, 2, 4); issue_advance();
+        wait_steady();
+    } else {
+        wait_vm<0>();
+    }
+    G8_SBAR();
+    if (grp == 1) G8_SBAR();               // stagger: group 1 runs one barrier interval behind group 0
+
+    if constexpr (DBG) ts1 = __builtin_readcyclecounter();
+    int st_rd = 0, st_is = 2;
+    for (int t = 0; t < nkt; ++t) {
+        const unsigned char* rbase = smem + st_rd * C::STAGE;
+        const bool more = (t + 2 < nkt);   // block-uniform
+        half8_t af[2][2], bf[TN][2];
+
+        // ===== phase 0: rows [0, 32) of the wave's 64
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+                af[mi][kk] = *reinterpret_cast<const half8_t*>(rbase + ((a_off ^ (kk << 6)) + mi * 2048));
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+                bf[ni][kk] = *reinterpret_cast<const half8_t*>(rbase + ((b_off ^ (kk << 6)) + ni * 2048));
+        }
+        if (more) { issue_a(st_is, 0, 2); wait_steady(); } else { wait_vm<0>(); }
+        G8_SBAR();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = mfma16(bf[ni][kk], af[mi][kk], acc[mi][ni]);
+        __builtin_amdgcn_s_setprio(0);
+        G8_SBAR();
+
+        // ===== phase 1: rows [32, 64)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+                af[mi][kk] = *reinterpret_cast<const half8_t*>(rbase + ((a_off ^ (kk << 6)) + (2 + mi) * 2048));
+        if (more) { issue_b(st_is); issue_a(st_is, 2, 4); issue_advance(); wait_steady(); } else { wait_vm<0>(); }
+        G8_SBAR();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) acc[2 + mi][ni] = mfma16(bf[ni][kk], af[mi][kk], acc[2 + mi][ni]);
+        __builtin_amdgcn_s_setprio(0);
+        G8_SBAR();
+
+        st_rd = (st_rd == 2) ? 0 : st_rd + 1;
+        st_is = (st_is == 2) ? 0 : st_is + 1;
+    }
+    if (grp == 0) G8_SBAR();               // equal barrier counts; after it no wave reads the operand stages any more
+    if constexpr (DBG) ts2 = __builtin_readcyclecounter();
+
+    // ------------------------------------------------------------------ epilogue
+    // The wave's 64 x PW fp32 tile goes through a private LDS slab, 32 rows at a time, so that every lane then owns 8
+    // consecutive channels of one row (16-byte residual / row-bias reads and output stores).  MFMA result layout
+    // (operands swapped: weights are the row operand): lane holds token row (lane & 15), channels 4 * (lane >> 4) + [0, 4).
+    constexpr int EPS = PW + 4;
+    constexpr int CG8 = PW / 8;                        // 8-column groups per staged row: 10 / 8
+    constexpr int ITEMS = 32 * CG8;                    // 320 / 256 = 5 / 4 sweeps of the wave
+    static_assert(ITEMS % 64 == 0, "whole sweeps");
+    float* stage = reinterpret_cast<float*>(smem) + wave * (32 * EPS);
+    const int epi = p.epi;
+    const float* __restrict__ bias = p.bias;
+    float gate = 1.0f;
+    if (splitk == 1 && epi == GL_EPI_GATE_RES) gate = p.gate[0];
+    const int nbase = n0 + PW * grp;
+    half_t* outp = reinterpret_cast<half_t*>(p.out);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int mbase = m0 + 64 * wm + 32 * h;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+                *reinterpret_cast<float4*>(stage + (16 * mi + lr) * EPS + 16 * ni + 4 * lq) =
+                    make_float4(acc[2 * h + mi][ni][0], acc[2 * h + mi][ni][1], acc[2 * h + mi][ni][2], acc[2 * h + mi][ni][3]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (splitk > 1) {
+            // split-K slice: raw fp32 partial tile -> workspace[z][m][n]; the epilogue happens in the reduction
+            float* ws = reinterpret_cast<float*>(p.workspace) + (size_t)blockIdx.z * M * N;
+#pragma unroll
+            for (int q = 0; q < ITEMS / 64; ++q) {
+                const int idx = lane + 64 * q;
+                const int r = idx / CG8, c = (idx - r * CG8) * 8;
+                const int m = mbase + r, n = nbase + c;
+                if (m < M && n < N) {
+                    float* o = ws + (size_t)m * N + n;
+                    *reinterpret_cast<float4*>(o) = *reinterpret_cast<const float4*>(stage + r * EPS + c);
+                    *reinterpret_cast<float4*>(o + 4) = *reinterpret_cast<const float4*>(stage + r * EPS + c + 4);
+                }
+            }
+        } else if (p.vt != nullptr && nbase >= p.vt_col0) {
+            // V^T tail of a fused QKV projection: lane = one channel column, 8 consecutive tokens per 16-byte store
+            half_t* vtp = reinterpret_cast<half_t*>(p.vt);
+#pragma unroll
+            for (int c0 = 0; c0 < PW; c0 += 64) {
+                const int col = c0 + lane;
+                const int n = nbase + col;
+                if (col < PW && n < N) {
+                    const int nv = n - p.vt_col0;
+                    const int hh = nv / p.vt_d;
+                    const int cc = nv - hh * p.vt_d;
+                    const float bv = bias ? bias[n] : 0.0f;
+#pragma unroll
+                    for (int tg = 0; tg < 4; ++tg) {
+                        const int m = mbase + tg * 8;
+                        if (m >= M) continue;
+                        half8_t o;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) o[k] = (half_t)(stage[(tg * 8 + k) * EPS + col] + bv);
+                        if ((p.vt_rows & 7) == 0) {
+                            const int b = m / p.vt_rows;
+                            const int key = m - b * p.vt_rows;
+                            st16(vtp + ((size_t)(b * p.vt_H + hh) * p.vt_d + cc) * p.vt_ld + key, *reinterpret_cast<uint4*>(&o));
+                        } else {
+                            // ragged rows per sample (the fuser's N + 30 keys): 8 tokens may straddle two samples
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) {
+                                const int mm = m + k;
+                                if (mm < M) {
+                                    const int b = mm / p.vt_rows;
+                                    const int key = mm - b * p.vt_rows;
+                                    vtp[((size_t)(b * p.vt_H + hh) * p.vt_d + cc) * p.vt_ld + key] = o[k];
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        } else if (epi == GL_EPI_GEGLU) {
+            if constexpr (PW == 64) {
+                // one [x(32) | gate(32)] pair per staged row: 32 output columns, 8 per lane, 16 rows per sweep
+#pragma unroll
+                for (int ps = 0; ps < 2; ++ps) {
+                    const int r = ps * 16 + (lane >> 2);
+                    const int pc = (lane & 3) * 8;
+                    const int m = mbase + r;
+                    const int nx = nbase + pc;
+                    if (m < M && nx < N) {
+                        const float4 x0 = *reinterpret_cast<const float4*>(stage + r * EPS + pc);
+                        const float4 x1 = *reinterpret_cast<const float4*>(stage + r * EPS + pc + 4);
+                        const float4 g0 = *reinterpret_cast<const float4*>(stage + r * EPS + pc + 32);
+                        const float4 g1 = *reinterpret_cast<const float4*>(stage + r * EPS + pc + 36);
+                        float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                        float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                        half8_t o;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            float a = xv[j], b = gv[j];
+                            if (bias) { a += bias[nx + j]; b += bias[nx + 32 + j]; }
+                            o[j] = (half_t)(a * gelu_erf_f(b));
+                        }
+                        st16(outp + (size_t)m * p.ldc + (nbase >> 1) + pc, *reinterpret_cast<uint4*>(&o));
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < ITEMS / 64; ++q) {
+                const int idx = lane + 64 * q;
+                const int r = idx / CG8, c = (idx - r * CG8) * 8;
+                const int m = mbase + r, n = nbase + c;
+                if (m < M && n < N) {
+                    const float4 a0 = *reinterpret_cast<const float4*>(stage + r * EPS + c);
+                    const float4 a1 = *reinterpret_cast<const float4*>(stage + r * EPS + c + 4);
+                    float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                    finish8(p, gate, m, n, v);
+                }
+            }
+        }
+    }
+    if constexpr (DBG) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long ts3 = __builtin_readcyclecounter();
+        const int bid = blockIdx.x + gridDim.x * blockIdx.z;
+        if (tid == 0 && bid < 4096) {
+            g8_stamps[4 * bid + 0] = ts0; g8_stamps[4 * bid + 1] = ts1; g8_stamps[4 * bid + 2] = ts2; g8_stamps[4 * bid + 3] = ts3;
+        }
+    }
+}
+
+int g8_dbg = 0;
+
+template <int BN, bool CONV>
+int launch8(const gl_gemm_args& g, const ConvGeom& cg, int zs, int kper, int order_m, hipStream_t st) {
+    const int mt = gl_cdiv(g.M, 256), nt = gl_cdiv(g.N, BN);
+    dim3 grid(mt * nt, 1, zs);
+    if (g8_dbg && BN == 160) gemm8_kernel<BN, CONV, true><<<grid, dim3(512), G8<BN>::LDS, st>>>(g, cg, zs, kper, order_m);
+    else gemm8_kernel<BN, CONV><<<grid, dim3(512), G8<BN>::LDS, st>>>(g, cg, zs, kper, order_m);
+    GL_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int BN, bool CONV>
+int set_attr8() {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm8_kernel<BN, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, G8<BN>::LDS);
+    if (e == hipSuccess && BN == 160)
+        e = hipFuncSetAttribute((const void*)gemm8_kernel<BN, CONV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G8<BN>::LDS);
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+}  // namespace
+
+// What the 8-wave kernel implements: row-major outputs, every epilogue (GEGLU only on the 128-wide tile, whose wave owns
+// whole [x | gate] pairs), the V^T tail when it starts on a wave's column range.
+int gl8_supported(const gl_gemm_args& g, bool conv, int* bn_out) {
+    (void)conv;
+    if (g.out_mode == GL_OUT_F32_NCHW) return 0;
+    if ((g.K % 64) != 0 || (g.N % 8) != 0 || g.M < 256) return 0;
+    int bn = 128;
+    if (g.epi != GL_EPI_GEGLU && (g.N % 160) == 0) bn = 160;
+    if (g.vt != nullptr && (g.vt_col0 % (bn / 2)) != 0) {
+        if (bn == 160 && (g.vt_col0 % 64) == 0) bn = 128;
+        else return 0;
+    }
+    if (g.a2 != nullptr && (g.ksplit % 64) != 0) return 0;
+    *bn_out = bn;
+    return 1;
+}
+
+int gl8_launch(const gl_gemm_args& g, const ConvGeom& cg, bool conv, int bn, int zs, int kper, int order_m, hipStream_t st) {
+    if (bn == 160) return conv ? launch8<160, true>(g, cg, zs, kper, order_m, st) : launch8<160, false>(g, cg, zs, kper, order_m, st);
+    if (bn == 128) return conv ? launch8<128, true>(g, cg, zs, kper, order_m, st) : launch8<128, false>(g, cg, zs, kper, order_m, st);
+    return GL_ERR_UNSUPPORTED;
+}
+
+int gl8_init(void) {
+    int e;
+    if ((e = set_attr8<160, false>())) return e;
+    if ((e = set_attr8<160, true>())) return e;
+    if ((e = set_attr8<128, false>())) return e;
+    if ((e = set_attr8<128, true>())) return e;
+    return 0;
+}
+
+// measurement hooks (tools/g8_probe.py): option 32 selects the timestamping instantiation of the 160-wide kernel
+int gl8_set_debug(int v) { g8_dbg = v; return 0; }
+int gl8_read_stamps(void* dst, int64_t bytes) {
+    if (bytes > (int64_t)sizeof(unsigned long long) * 4 * 4096) return GL_ERR_BAD_ARG;
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g8_stamps), (size_t)bytes, 0, hipMemcpyDeviceToHost);
+}

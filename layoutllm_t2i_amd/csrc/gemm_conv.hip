@@ -27,9 +27,7 @@
 // optional fp16 copy for matrix-core consumers), so chained residual adds are never rounded to fp16.
 #include "common.h"
 #include "gligen_hip.h"
-
-// 16 zero bytes in global memory: the source of masked lanes of the direct-to-LDS loads.
-__device__ uint4 g_zero16[4];
+#include "gemm_shared.h"
 
 namespace {
 
@@ -44,19 +42,8 @@ int g_opt_splitk_nk = 16;    // ... and at least this many 64-wide K tiles
 int g_opt_skinny = 64;       // skinny-GEMM kernel while its operand re-reads stay below this many MiB (0 = off)
 int g_opt_order = 1;         // tile order: 0 = N-tiles fastest, 1 = M-tiles fastest when the weights are the larger operand, 2 = always M
 int g_opt_tile = 0;          // 0 = auto; 1 = force 128x128 (N >= 256); 2 = prefer 128x160 whenever N % 160 == 0
-
-struct ConvGeom {
-    const half_t* in;
-    int B, Hin, Win, Cin, Hout, Wout, stride, ups;
-};
-
-__device__ __forceinline__ void wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-__device__ __forceinline__ void glds16(const half_t* src, half_t* dst) {
-    __builtin_amdgcn_global_load_lds(
-        reinterpret_cast<const __attribute__((address_space(1))) void*>(reinterpret_cast<uintptr_t>(src)),
-        reinterpret_cast<__attribute__((address_space(3))) void*>(reinterpret_cast<uintptr_t>(dst)), 16, 0, 0);
-}
+int g_opt_g8 = 1;            // 8-wave deep-pipelined 256-row kernel (gemm8.hip): 0 off, 1 auto (enough tiles), 2 whenever it applies
+int g_opt_g8_tiles = 200;    // auto: at least this many 256-row tiles (x K slices)
 
 template <int BM, int BN, int BKT, int NW = 4>
 constexpr int lds_bytes() {
@@ -73,62 +60,6 @@ constexpr int min_waves() {
     if (BM * BN >= 256 * 128) return 2;
     if (BM * BN <= 128 * 128) return 4;
     return 3;
-}
-
-// One 8-column piece of one output row: bias / activation / residual, then the stores.  Shared by the GEMM epilogue
-// and the split-K reduction so that both produce bit-identical results from the same fp32 sums.
-__device__ __forceinline__ void finish8(const gl_gemm_args& p, float gate, int m, int n, float (&v)[8]) {
-    const int epi = p.epi;
-    if (p.bias) {
-        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n);
-        const float4 b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
-        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-        v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-    }
-    if (epi == GL_EPI_SILU) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = silu_f(v[j]);
-    } else if (epi == GL_EPI_RES || epi == GL_EPI_GATE_RES) {
-        float r[8];
-        if (p.res_f32) {
-            const float* rp = reinterpret_cast<const float*>(p.res) + (size_t)m * p.ldres + n;
-            const float4 r0 = *reinterpret_cast<const float4*>(rp);
-            const float4 r1 = *reinterpret_cast<const float4*>(rp + 4);
-            r[0] = r0.x; r[1] = r0.y; r[2] = r0.z; r[3] = r0.w; r[4] = r1.x; r[5] = r1.y; r[6] = r1.z; r[7] = r1.w;
-        } else {
-            uint4 raw = ld16(reinterpret_cast<const half_t*>(p.res) + (size_t)m * p.ldres + n);
-            const half8_t rv = *reinterpret_cast<half8_t*>(&raw);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) r[j] = (float)rv[j];
-        }
-        if (epi == GL_EPI_RES) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] += r[j];
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = r[j] + gate * v[j];
-        }
-    } else if (epi == GL_EPI_ROWBIAS) {
-        const int sidx = m / p.rows_per_sample;
-        uint4 raw = ld16(reinterpret_cast<const half_t*>(p.rowbias) + (size_t)sidx * p.ld_rowbias + n);
-        const half8_t rv = *reinterpret_cast<half8_t*>(&raw);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += (float)rv[j];
-    }
-    half_t* o16 = reinterpret_cast<half_t*>(p.out);
-    int ld16o = p.ldc;
-    if (p.out_mode == GL_OUT_F32_ROWMAJOR) {
-        float* o = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n;
-        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        o16 = reinterpret_cast<half_t*>(p.out2);
-        ld16o = p.ldc2;
-        if (o16 == nullptr) return;
-    }
-    half8_t o;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (half_t)v[j];
-    st16(o16 + (size_t)m * ld16o + n, *reinterpret_cast<uint4*>(&o));
 }
 
 // WK = 2: intra-block K split.  The waves form two groups that own the SAME output rows/columns but alternate
@@ -828,6 +759,32 @@ int dispatch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
             GL_CHECK_LAUNCH();
             return 0;
         }
+    }
+    if (g_opt_g8) {
+        int bn = 0;
+        if (gl8_supported(g, CONV, &bn)) {
+            const int tiles = gl_cdiv(g.M, 256) * gl_cdiv(g.N, bn);
+            const int nk = g.K / 64;
+            int splitk = 1;
+            if (g_opt_g8 == 2) splitk = choose_splitk(g, tiles, CONV);
+            if (g_opt_g8 == 2 || tiles >= g_opt_g8_tiles) {
+                const int kper = gl_cdiv(nk, splitk);
+                const int zs = gl_cdiv(nk, kper);
+                const int order_m = g_opt_order == 1 ? ((CONV ? 9L : 1L) * g.N > (long)g.M) : (g_opt_order == 2);
+                const int e = gl8_launch(g, cg, CONV, bn, zs, kper, order_m, st);
+                if (e) return e;
+                if (zs > 1) {
+                    const size_t total = (size_t)g.M * (g.N / 8);
+                    int nblk = (int)((total + 255) / 256);
+                    if (nblk > 2048) nblk = 2048;
+                    splitk_reduce_kernel<<<dim3(nblk), dim3(256), 0, st>>>(g, zs);
+                    GL_CHECK_LAUNCH();
+                }
+                return 0;
+            }
+        }
+    }
+    if constexpr (!CONV) {
         if (g_opt_geglu32 && g.epi == GL_EPI_GEGLU && g.K <= 640 && g.a2 == nullptr) return dispatch_shape<false, 32>(g, cg, st);
     }
     return dispatch_shape<CONV, 64>(g, cg, st);
@@ -882,6 +839,7 @@ extern "C" int gl_init_gemm(void) {
     if ((e = set_lds_attr2<256, 128, 4, 1, 32>())) return e;
     if ((e = set_lds_attr<64, 128, 2, 2, false, 32>())) return e;
     if ((e = set_lds_attr<128, 128, 2, 2, false, 32>())) return e;
+    if ((e = gl8_init())) return e;
     return 0;
 }
 
@@ -893,7 +851,16 @@ extern "C" int gl_set_option_gemm(int key, int value) {
     if (key == 13) { g_opt_ksplit = value; return 0; }
     if (key == 23) { g_opt_order = value; return 0; }
     if (key == 24) { g_opt_skinny = value; return 0; }
+    if (key == 30) { g_opt_g8 = value; return 0; }
+    if (key == 31) { g_opt_g8_tiles = value; return 0; }
+    if (key == 32) return gl8_set_debug(value);
     if (key == 5) { g_opt_splitk_tiles = value < 0 ? 300 : value; g_opt_splitk_tiles_conv = value < 0 ? 450 : value; return 0; }   // < 0: defaults
     if (key == 6) { g_opt_splitk_nk = value; return 0; }
+    return GL_ERR_BAD_ARG;
+}
+
+// measurement hook: per-block cycle stamps of the timestamping 8-wave kernel (gl_set_option(32, 1)); 4 x uint64 per block
+extern "C" int gl_debug_read(int what, void* dst, int64_t bytes) {
+    if (what == 8) return gl8_read_stamps(dst, bytes);
     return GL_ERR_BAD_ARG;
 }

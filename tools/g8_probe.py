@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""A/B probe of the 8-wave deep-pipelined GEMM / conv kernel (csrc/gemm8.hip) against the 4-wave kernels (GPU box).
+
+    python tools/g8_probe.py [check] [time] [race]
+
+check : every epilogue / operand form through gl_gemm / gl_conv3x3 with option 30 = 2 (8-wave kernel wherever it applies)
+        against option 30 = 0 (the parity-tested 4-wave kernels) on the same inputs; the two differ only in fp32 summation
+        order, so fp16 outputs may differ by one rounding step on a small fraction of elements and fp32 outputs by ~1e-6.
+time  : per-shape time of both, interleaved in one process (median of rounds).
+race  : repeats each 8-wave launch on fresh data and requires bitwise-identical results across repeats of the same data
+        (a staged buffer read before its DMA landed shows up as run-to-run differences).
+"""
+import math
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+from layoutllm_t2i_amd import ops
+from layoutllm_t2i_amd._lib import (EPI_BIAS, EPI_GATE_RES, EPI_GEGLU, EPI_RES, EPI_ROWBIAS, EPI_SILU, init_device)
+
+DEV = "cuda:0"
+F16, F32 = torch.float16, torch.float32
+G = torch.Generator(device="cpu").manual_seed(7)
+
+
+def h(*s, scale=1.0):
+    return (torch.randn(*s, generator=G) * scale).to(F16).to(DEV)
+
+
+def f(*s, scale=1.0):
+    return (torch.randn(*s, generator=G) * scale).to(DEV)
+
+
+def cmp(a, b, name, f32):
+    a, b = a.float(), b.float()
+    if not torch.isfinite(a).all():
+        print(f"  FAIL {name}: non-finite output")
+        return False
+    d = (a - b).abs()
+    scale = max(1.0, float(b.abs().max()))
+    tol = (2e-6 if f32 else 1.2e-3) * b.abs() + (2e-6 if f32 else 2e-4) * scale
+    bad = float((d > tol).float().mean())
+    rel = float((a - b).norm() / (b.norm() + 1e-30))
+    ok = bad == 0.0
+    print(f"  {'ok  ' if ok else 'FAIL'} {name}: max|d|={float(d.max()):.3e} rel_l2={rel:.2e} viol={bad:.2e}")
+    return ok
+
+
+def gemm_case(M, N, K, epi="bias", f32=False, a2=False, vt=0, vt_rows=0, out16=False):
+    """returns a closure that runs the case into fresh outputs and returns them"""
+    if a2:
+        K1 = K // 2 // 64 * 64
+        a, a_2 = h(M, K1), h(M, K - K1)
+    else:
+        a, a_2 = h(M, K), None
+    w = h(N, K, scale=K ** -0.5)
+    bias = f(N, scale=0.1)
+    res = (f(M, N) if f32 else h(M, N)) if epi in ("res", "gate") else None
+    gate = torch.tensor([-0.37], dtype=F32, device=DEV) if epi == "gate" else None
+    rb = h((M + 255) // 256, N) if epi == "rowbias" else None
+    e = {"bias": EPI_BIAS, "silu": EPI_SILU, "geglu": EPI_GEGLU, "res": EPI_RES, "gate": EPI_GATE_RES, "rowbias": EPI_ROWBIAS}[epi]
+    No = N // 2 if epi == "geglu" else N
+
+    def alloc():
+        out = torch.full((M, No), 7.0, dtype=F32 if f32 else F16, device=DEV)
+        o16 = torch.full((M, No), 7.0, dtype=F16, device=DEV) if (f32 and out16) else None
+        vtt = None
+        if vt:
+            d = 40 if (N - vt) % 40 == 0 else 64
+            vtt = torch.full((M // vt_rows, (N - vt) // d, d, ops.vt_ld(vt_rows)), 7.0, dtype=F16, device=DEV)
+        return [out, o16, vtt]
+
+    def launch(o):
+        kw = dict(vt=o[2], vt_col0=vt, vt_rows=vt_rows) if vt else {}
+        ops.gemm(a, w, o[0], bias, e, res=res, gate=gate, rowbias=rb, rows_per_sample=256, a2=a_2, out16=o[1], **kw)
+    return alloc, launch, 2.0 * M * N * K
+
+
+def conv_case(B, side, cin, cout, stride=1, up=False, epi="bias", f32=False):
+    x = h(B * side * side, cin)
+    w = h(cout, 9 * cin, scale=(9 * cin) ** -0.5)
+    bias = f(cout, scale=0.1)
+    ho = side * 2 if up else (side + 2 - 3) // stride + 1
+    M = B * ho * ho
+    res = (f(M, cout) if f32 else h(M, cout)) if epi == "res" else None
+    rb = h(B, cout) if epi == "rowbias" else None
+    e = {"bias": EPI_BIAS, "res": EPI_RES, "rowbias": EPI_ROWBIAS}[epi]
+
+    def alloc():
+        out = torch.full((M, cout), 7.0, dtype=F32 if f32 else F16, device=DEV)
+        o16 = torch.full((M, cout), 7.0, dtype=F16, device=DEV) if f32 else None
+        return [out, o16]
+
+    def launch(o):
+        ops.conv3x3(x, w, o[0], B, side, side, bias, stride=stride, upsample2x=up, epi=e, res=res, rowbias=rb,
+                    rows_per_sample=ho * ho, out16=o[1])
+    return alloc, launch, 2.0 * M * cout * 9 * cin
+
+
+def cases():
+    c = []
+    g = lambda name, *a, **k: c.append((name, *gemm_case(*a, **k)))
+    v = lambda name, *a, **k: c.append((name, *conv_case(*a, **k)))
+    if os.environ.get("G8_SWEEP"):
+        for K in (64, 128, 320, 640, 1280, 2560):
+            g(f"gemm 32768x320x{K} bias", 32768, 320, K)
+        for cin in (64, 128, 320, 640, 960):
+            v(f"conv 8x64^2 {cin}->320", 8, 64, cin, 320)
+        return c
+    if os.environ.get("G8_QUICK"):
+        g("gemm 4096x320x320 bias", 4096, 320, 320)
+        v("conv 2x32^2 320->320", 2, 32, 320, 320)
+        return c
+    g("gemm 32768x320x320 bias", 32768, 320, 320)
+    g("gemm 32768x320x320 res f32+o16", 32768, 320, 320, "res", f32=True, out16=True)
+    g("gemm 32768x960x320 qkv vt", 32768, 960, 320, vt=640, vt_rows=4096)
+    g("gemm 33008x960x320 fuser vt ragged", 33008, 960, 320, vt=640, vt_rows=4126)
+    g("gemm 32768x2560x320 geglu", 32768, 2560, 320, "geglu")
+    g("gemm 32768x320x1280 res f32", 32768, 320, 1280, "res", f32=True)
+    g("gemm 32768x320x640 a2", 32768, 320, 640, a2=True)
+    g("gemm 8192x1920x640 qkv vt", 8192, 1920, 640, vt=1280, vt_rows=1024)
+    g("gemm 8192x5120x640 geglu", 8192, 5120, 640, "geglu")
+    g("gemm 8192x640x2560 res f32", 8192, 640, 2560, "res", f32=True)
+    g("gemm 8192x640x640 gate f32", 8192, 640, 640, "gate", f32=True)
+    g("gemm 2048x10240x1280 geglu", 2048, 10240, 1280, "geglu")
+    g("gemm 2048x1280x5120 res", 2048, 1280, 5120, "res")
+    g("gemm 2048x3840x1280 qkv vt", 2048, 3840, 1280, vt=2560, vt_rows=256)
+    g("gemm 1000x320x320 silu (M tail)", 1000, 320, 320, "silu")
+    g("gemm 2000x200x128 rowbias (N tail, bn128)", 2000, 200, 128, "rowbias")
+    g("gemm 4096x512x64 bias (one K-tile)", 4096, 512, 64)
+    g("gemm 4096x256x128 bias (two K-tiles)", 4096, 256, 128)
+    v("conv 8x64^2 320->320", 8, 64, 320, 320)
+    v("conv 8x64^2 320->320 rowbias", 8, 64, 320, 320, epi="rowbias")
+    v("conv 8x64^2 320->320 res f32", 8, 64, 320, 320, epi="res", f32=True)
+    v("conv 8x64^2 960->320", 8, 64, 960, 320)
+    v("conv 8x64^2 320->320 s2", 8, 64, 320, 320, stride=2)
+    v("conv 8x32^2 640->640", 8, 32, 640, 640)
+    v("conv 8x32^2 640->640 up", 8, 32, 640, 640, up=True)
+    v("conv 8x16^2 1280->1280", 8, 16, 1280, 1280)
+    v("conv 8x8^2 1280->1280", 8, 8, 1280, 1280)
+    v("conv 3x20^2 128->256 (ragged, bn128)", 3, 20, 128, 256)
+    v("conv 16x64^2 320->320", 16, 64, 320, 320)
+    return c
+
+
+def timeit(fn, iters):
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def main():
+    which = set(sys.argv[1:]) or {"check", "time", "race"}
+    init_device()
+    cs = cases()
+    only = os.environ.get("G8_ONLY")
+    if only:
+        cs = [c for c in cs if only in c[0]]
+    allok = True
+    if "spin" in which:         # for rocprofv3: 20 launches of each case with the default dispatch
+        for name, alloc, launch, _ in cs:
+            o = alloc()
+            for _ in range(20):
+                launch(o)
+        torch.cuda.synchronize()
+    if "check" in which:
+        print("== check: 8-wave (option 30 = 2) vs 4-wave (30 = 0)")
+        for name, alloc, launch, _ in cs:
+            ops.set_option(30, 0)
+            ref = alloc()
+            launch(ref)
+            ops.set_option(30, 2)
+            got = alloc()
+            launch(got)
+            torch.cuda.synchronize()
+            for i, (a, b) in enumerate(zip(got, ref)):
+                if a is not None:
+                    allok &= cmp(a, b, f"{name} [{i}]", a.dtype == F32)
+    if "race" in which:
+        print("== race screen: 8-wave kernel, 12 repeats each, bitwise")
+        ops.set_option(30, 2)
+        for name, alloc, launch, _ in cs:
+            first = alloc()
+            launch(first)
+            same = True
+            for _ in range(12):
+                again = alloc()
+                launch(again)
+                same &= all(torch.equal(a, b) for a, b in zip(again, first) if a is not None)
+            print(f"  {'ok  ' if same else 'FAIL'} {name}")
+            allok &= same
+    if "time" in which:
+        print("== time (us, TF/s): 4-wave | 8-wave forced | auto")
+        iters = int(os.environ.get("G8_ITERS", "10"))
+        for name, alloc, launch, fl in cs:
+            ts = {0: [], 2: [], 1: []}
+            o = alloc()
+            run = lambda: launch(o)
+            for mode in (0, 2, 1):
+                ops.set_option(30, mode)
+                run()
+            for _ in range(5):
+                for mode in (0, 2, 1):
+                    ops.set_option(30, mode)
+                    ts[mode].append(timeit(run, iters))
+            med = {m: sorted(v)[len(v) // 2] for m, v in ts.items()}
+            print(f"  {name:44s} {med[0] * 1e6:8.1f} {fl / med[0] / 1e12:7.1f} | {med[2] * 1e6:8.1f} {fl / med[2] / 1e12:7.1f} | "
+                  f"{med[1] * 1e6:8.1f} {fl / med[1] / 1e12:7.1f}   x{med[0] / med[2]:.2f}")
+    if "stamps" in which:
+        import ctypes
+        import numpy as np
+        from layoutllm_t2i_amd import _lib
+        print("== stamps (cycles @100 MHz-or-shader clock, per block): prologue | main loop | epilogue | total ; spread of block start/end")
+        ops.set_option(30, 1)
+        for name, alloc, launch, fl in cs:
+            o = alloc()
+            ops.set_option(32, 1)
+            for _ in range(3):
+                launch(o)
+            torch.cuda.synchronize()
+            buf = np.zeros(4 * 4096, dtype=np.uint64)
+            _lib.check(_lib.lib().gl_debug_read(8, buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes), "gl_debug_read")
+            ops.set_option(32, 0)
+            st = buf.reshape(4096, 4).astype(np.int64)
+            st = st[st[:, 0] != 0]
+            if len(st) == 0:
+                print(f"  {name}: no stamps")
+                continue
+            t0 = st[:, 0].min()
+            pro, loop, epi = st[:, 1] - st[:, 0], st[:, 2] - st[:, 1], st[:, 3] - st[:, 2]
+            print(f"  {name:40s} blocks={len(st):4d} pro {np.median(pro):8.0f} loop {np.median(loop):9.0f} epi {np.median(epi):8.0f} "
+                  f"| start spread {int((st[:, 0] - t0).max()):7d} first-end {int(st[:, 3].min() - t0):8d} last-end {int(st[:, 3].max() - t0):8d}")
+    ops.set_option(30, 1)
+    print("ALL OK" if allok else "FAILURES")
+    sys.exit(0 if allok else 1)
+
+
+if __name__ == "__main__":
+    main()
