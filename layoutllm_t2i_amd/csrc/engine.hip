@@ -128,7 +128,12 @@ struct gl_engine {
     // graphs
     std::map<std::tuple<int, int, int, int, int, int, int>, hipGraphExec_t> graphs;
     float fuser_scale_cur = -1e30f;
-    std::vector<float> gate_host;      // the [n_st][4] array last uploaded (kept alive for the async copy)
+    std::vector<float> gate_host;      // the [n_st][4] array last computed
+    float* gate_pin[2] = {nullptr, nullptr};           // pinned double buffer the async upload reads from
+    hipEvent_t gate_pin_ev[2] = {nullptr, nullptr};    // completion of the upload that used the slot
+    bool gate_pin_used[2] = {false, false};
+    size_t gate_pin_bytes = 0;
+    int gate_pin_next = 0;
     int launches = 0;
     int opt_epoch = 0;                 // gl_set_option generation the captured graphs were built under
     std::string err;
@@ -448,8 +453,27 @@ int set_fuser_scale(gl_engine* e, float scale, hipStream_t st) {
         e->gate_host[i * 4 + 2] = e->gate_tanh[i * 4 + 2];
         e->gate_host[i * 4 + 3] = e->gate_tanh[i * 4 + 3];
     }
-    // pageable-source async copies are staged before the call returns, so gate_host may change afterwards
-    if (hipMemcpyAsync(gates, e->gate_host.data(), n * 4 * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess) return GL_ERR_BAD_ARG;
+    // Pinned, double-buffered staging: the async copy reads host memory when the stream gets there, and the stage-1 alpha ramp
+    // can change the scale on consecutive steps, so the source of the copy in flight must not be overwritten by the next call
+    // (a pageable source is NOT guaranteed to be staged before hipMemcpyAsync returns on every runtime path).
+    const size_t bytes = n * 4 * sizeof(float);
+    if (e->gate_pin_bytes < bytes) {
+        for (int k = 0; k < 2; ++k) {
+            if (e->gate_pin[k]) (void)hipHostFree(e->gate_pin[k]);
+            e->gate_pin[k] = nullptr;
+            if (hipHostMalloc(reinterpret_cast<void**>(&e->gate_pin[k]), bytes, hipHostMallocDefault) != hipSuccess) return GL_ERR_BAD_ARG;
+            if (e->gate_pin_ev[k] == nullptr && hipEventCreateWithFlags(&e->gate_pin_ev[k], hipEventDisableTiming) != hipSuccess) return GL_ERR_BAD_ARG;
+        }
+        e->gate_pin_bytes = bytes;
+        e->gate_pin_used[0] = e->gate_pin_used[1] = false;
+    }
+    const int slot = e->gate_pin_next;
+    e->gate_pin_next ^= 1;
+    if (e->gate_pin_used[slot] && hipEventSynchronize(e->gate_pin_ev[slot]) != hipSuccess) return GL_ERR_BAD_ARG;   // copy issued two calls ago
+    memcpy(e->gate_pin[slot], e->gate_host.data(), bytes);
+    if (hipMemcpyAsync(gates, e->gate_pin[slot], bytes, hipMemcpyHostToDevice, st) != hipSuccess) return GL_ERR_BAD_ARG;
+    if (hipEventRecord(e->gate_pin_ev[slot], st) != hipSuccess) return GL_ERR_BAD_ARG;
+    e->gate_pin_used[slot] = true;
     e->fuser_scale_cur = scale;
     return 0;
 }
@@ -764,6 +788,10 @@ extern "C" int gl_destroy(gl_engine* e) {
     e->drop_graphs();
     for (auto& kv : e->pool) (void)hipFree(kv.second.p);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
+    for (int k = 0; k < 2; ++k) {
+        if (e->gate_pin_ev[k]) { (void)hipEventSynchronize(e->gate_pin_ev[k]); (void)hipEventDestroy(e->gate_pin_ev[k]); }
+        if (e->gate_pin[k]) (void)hipHostFree(e->gate_pin[k]);
+    }
     delete e;
     return 0;
 }

@@ -18,6 +18,7 @@
 // bias / gelu_erf_f order), H is rounded to fp16 like the stored intermediate; phase 2 sums each 16-wide k-step in a
 // permuted order, so outputs agree with the two-launch form to fp32 rounding of the accumulation, not bit for bit.
 #include "common.h"
+#include <atomic>
 #include "gligen_hip.h"
 
 namespace {
@@ -314,12 +315,16 @@ extern "C" int gl_ff_fused_supported(int32_t C) { return C == 64 || C == 128 || 
 // (288 blocks on 256 CUs = two rounds).  Callers that must agree on the choice (the engine and its Python mirror) ask here.
 extern "C" int gl_ff_fused_applicable(int32_t C, int32_t M) {
     if (!g_ff_enable || !gl_ff_fused_supported(C) || M < 128) return 0;
-    static int cus = 0;
+    // CU count of the CURRENT device, cached per device id (relaxed atomics: concurrent first calls compute the same value)
+    static std::atomic<int> cu_cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    int cus = (dev >= 0 && dev < 64) ? cu_cache[dev].load(std::memory_order_relaxed) : 0;
     if (cus == 0) {
-        int dev = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
         cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (dev >= 0 && dev < 64) cu_cache[dev].store(cus, std::memory_order_relaxed);
     }
     const int blocks = gl_cdiv(M, 128);
     const int rounds = gl_cdiv(blocks, cus);

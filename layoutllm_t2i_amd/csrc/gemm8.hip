@@ -11,21 +11,23 @@
 //   * a THREE-stage LDS ring (3 x 52 KiB at BN = 160) filled by global_load_lds_dwordx4; loads of K-tile t+2 are issued
 //     while K-tile t is consumed and are NEVER drained inside the loop: s_waitcnt vmcnt(N) with N counted so that exactly
 //     the pieces the NEXT phase reads have landed, then a raw s_barrier (a __syncthreads() would emit vmcnt(0));
-//   * two phases per K-tile (the wave's two 32-row halves), each = [ds_read fragments + issue LDS-DMA] barrier [MFMA]
-//     barrier, and the two wave groups (waves 0-3 / 4-7 = the two N halves; waves w and w+4 share a SIMD) run ONE barrier
-//     interval apart, so on every SIMD one wave feeds the matrix pipe while the other reads LDS and issues loads
-//     (s_setprio 1 around the MFMA cluster);
-//   * per-wave issue order inside a K-tile: A rows of the first halves (2 x 1 KiB), the B tile (2-3 x 1 KiB), A rows of
-//     the second halves (2 x 1 KiB) = the order they are consumed.
+//   * two phases per K-tile (its two 32-wide k halves), each = [ds_read 4 + TN fragments] barrier [4 * TN MFMAs with the
+//     LDS-DMA instructions of K-tile t+2 issued BETWEEN them, one per ~5 MFMAs: an LDS-DMA issue costs the wave 60-180
+//     cycles, which the matrix pipe covers] barrier; the two wave groups (waves 0-3 / 4-7 = the two N halves; waves w and
+//     w+4 share a SIMD) run ONE barrier interval apart, so on every SIMD one wave feeds the matrix pipe while the other
+//     reads LDS (s_setprio 1 around the MFMA cluster).  (First version, measured: issue in the read section, phases = row
+//     halves, 14 + 4 reads: 2100-2600 cycles per K-tile against 1280 of MFMA time; DESIGN.md.)
 // Hazards (cdna_hip_programming.md section 5, "read a staged buffer one phase AFTER the wait that retires it"):
-//   RAW  every wave's counted wait for the data of phase q+1 sits in its load section of phase q, followed by >= 1 barrier
-//        before any wave's reads of phase q+1 (2 for the lagging group);
-//   WAR  a stage is refilled two phases (>= 4 barriers) after the last ds_read of its previous contents was waited for.
+//   RAW  every wave's counted wait for K-tile t+1 sits at the end of its phase-1 read section of K-tile t, followed by >= 1
+//        barrier before any wave's first read of K-tile t+1 (2 for the leading group);
+//   WAR  stage (t+2) % 3 held K-tile t-1; its last ds_reads were waited for (lgkmcnt) before the lagging group's phase-1
+//        MFMAs of K-tile t-1, >= 1 barrier before the leading group's first refill instruction in phase 0 of K-tile t.
 // LDS image, swizzle ((row >> 1) & 7 on the 16-byte chunk index, applied to the per-lane global SOURCE and to the fragment
 // reads), zero page for masked lanes, XCD-aware tile order and the epilogue's fp32 restaging are those of gemm_conv.hip.
 #include "common.h"
 #include "gligen_hip.h"
 #include "gemm_shared.h"
+#include <type_traits>
 
 namespace {
 
@@ -65,15 +67,17 @@ __device__ __forceinline__ f32x4 mfma16(half8_t a, half8_t b, f32x4 c) {
         __builtin_amdgcn_sched_barrier(0);     \
     } while (0)
 
-// per-block timestamps of the DBG instantiation (gl_set_option(32, 1) selects it; read back with gl_debug_read(8, ...)):
-// [entry, prologue done, main loop done, epilogue done] x up to 4096 blocks, written by wave 0 of each block
+// measurement instantiations (gl_set_option(32, v) selects DBG = v for the 160-wide tile): bit 0 = per-block cycle stamps
+// [entry, prologue done, main loop done, epilogue done] x up to 4096 blocks, written by wave 0 of each block (read back with
+// gl_debug_read(8, ...)); bit 1 = every A lane reads the zero page, bit 2 = every B lane does (results invalid: isolates the
+// cost of fetching operand bytes from the cost of issuing / landing LDS-DMA instructions)
 __device__ unsigned long long g8_stamps[4 * 4096];
 
-template <int BN, bool CONV, bool DBG = false>
-__global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom cg, int splitk, int kt_per_split, int order_m) {
+template <int BN, bool CONV, int DBG = 0>
+__global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom cg, int splitk, int kt_per_split, int order_flags) {
     using C = G8<BN>;
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
-    if constexpr (DBG) ts0 = __builtin_readcyclecounter();
+    if constexpr (DBG & 1) ts0 = __builtin_readcyclecounter();
     constexpr int TN = C::TN, PW = C::PW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -95,6 +99,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
     }
     const int mt_ = (M + C::BM - 1) / C::BM;
+    const int order_m = order_flags & 1;
+    const bool tap_major = CONV && (order_flags & 2);      // conv K order: (tap, channel block) instead of (channel block, tap)
     const int tmi = order_m ? tile % mt_ : tile / nt;
     const int m0 = tmi * C::BM;
     const int n0 = (order_m ? tile / mt_ : tile - tmi * nt) * BN;
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
     const half_t* __restrict__ Ag = reinterpret_cast<const half_t*>(p.a);
     const half_t* __restrict__ A2g = reinterpret_cast<const half_t*>(p.a2);
     const half_t* __restrict__ Wg = reinterpret_cast<const half_t*>(p.w);
-    const half_t* zsrc = reinterpret_cast<const half_t*>(g_zero16);
+    const half_t* zsrc = cg.zero;          // 16 zero bytes (kernel argument: stays in SGPRs instead of being rematerialised per use)
 
     // ---- staging state.  A unit u = (half hi = u >> 1, j = u & 1): 8 consecutive tile rows, lane -> (row, 16-byte slot).
     //      Group-of-32 index rho0 = 16 * wave + 8 * j over the 128 "first half" (or "second half") rows of the tile.
@@ -115,7 +121,6 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
     const half_t* aptr[4];
     unsigned amask = 0u;
     unsigned cmask[4];
-    int cbyx[4];
     const int k_first = kt_begin * 64;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -125,25 +130,30 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
         const int gc = (sslot ^ ((r >> 1) & 7)) << 3;
         const int m = m0 + r;
         const bool rowok = m < M;
-        aptr[u] = zsrc; cmask[u] = 0u; cbyx[u] = -1;
+        aptr[u] = zsrc; cmask[u] = 0u;
         if constexpr (CONV) {
             if (rowok) {
+                // (sample, oy, ox) of the output pixel: shifts when the map sides are powers of two (every UNet level), else divisions
+                int b, oy, ox;
                 const int hw = cg.Hout * cg.Wout;
-                const int b = m / hw;
-                const int rr = m - b * hw;
-                const int oy = rr / cg.Wout;
-                const int ox = rr - oy * cg.Wout;
-                cbyx[u] = (b << 20) | (oy << 10) | ox;
-                if (!cg.ups) {
-                    unsigned mk = 0u;
-#pragma unroll
-                    for (int t = 0; t < 9; ++t) {
-                        const int iy = oy * cg.stride + t / 3 - 1, ix = ox * cg.stride + t % 3 - 1;
-                        if (iy >= 0 && iy < cg.Hin && ix >= 0 && ix < cg.Win) mk |= 1u << t;
-                    }
-                    cmask[u] = mk;
-                    aptr[u] = cg.in + ((size_t)(b * cg.Hin + oy * cg.stride) * cg.Win + ox * cg.stride) * cg.Cin + gc;
+                if (((cg.Wout & (cg.Wout - 1)) | (hw & (hw - 1))) == 0) {
+                    const int lw = __builtin_ctz(cg.Wout), lhw = __builtin_ctz(hw);
+                    b = m >> lhw;
+                    const int rr = m & (hw - 1);
+                    oy = rr >> lw;
+                    ox = rr & (cg.Wout - 1);
+                } else {
+                    b = m / hw;
+                    const int rr = m - b * hw;
+                    oy = rr / cg.Wout;
+                    ox = rr - oy * cg.Wout;
                 }
+                // tap (ky, kx) reads input (oy * s + ky - 1, ox * s + kx - 1): valid rows / columns as 3-bit sets, mask = their product
+                const int iy = oy * cg.stride, ix = ox * cg.stride;
+                const unsigned rb = (iy >= 1 ? 1u : 0u) | 2u | (iy + 1 < cg.Hin ? 4u : 0u);
+                const unsigned cb = (ix >= 1 ? 1u : 0u) | 2u | (ix + 1 < cg.Win ? 4u : 0u);
+                cmask[u] = ((rb & 1u) ? cb : 0u) | (cb << 3) | ((rb & 4u) ? (cb << 6) : 0u);
+                aptr[u] = cg.in + ((size_t)(b * cg.Hin + iy) * cg.Win + ix) * cg.Cin + gc;
             }
         } else {
             if (rowok) {
@@ -164,50 +174,38 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
         const int gc = (sslot ^ ((r >> 1) & 7)) << 3;
         const int n = n0 + r;
         const bool ok = (j < nb) && (r < BN) && (n < N);
-        bptr[j] = ok ? (Wg + (size_t)n * K + k_first + gc) : zsrc;
+        bptr[j] = ok ? (Wg + (size_t)n * K + gc) : zsrc;       // + the K-tile's offset at issue time
         if (ok) bmask |= 1u << j;
     }
 
     // conv: (channel block, tap) of the K-tile the next issue refers to
-    int is_cblk = 0, is_tap = 0;
+    const int ncblk = CONV ? cg.Cin >> 6 : 1;
+    // K-tile visiting order as (outer, inner) counters: inner = tap (9) with channel blocks outside, or inner = channel block
+    // with taps outside (tap-major: consecutive K-tiles then touch DIFFERENT 128-byte lines of the input pixels)
+    const int in_lim = tap_major ? ncblk : 9;
+    int is_out = 0, is_in = 0;
+    int is_cblk = 0, is_tap = 0;           // of the K-tile being issued (set by issue_begin)
     if constexpr (CONV) {
-        is_cblk = kt_begin / 9;
-        is_tap = kt_begin - is_cblk * 9;
+        is_out = kt_begin / in_lim;
+        is_in = kt_begin - is_out * in_lim;
     }
-    int is_kt = kt_begin;                  // absolute K-tile index of the next issue
+    int is_kt = kt_begin;                  // index (in visiting order) of the K-tile the next issue refers to
 
-    // A units [u_lo, u_hi) of K-tile is_kt into stage `st`
-    auto issue_a = [&](const int st, const int u_lo, const int u_hi) {
-        unsigned char* sbase = smem + st * C::STAGE;
+    // per-K-tile issue state: refreshed by issue_begin() before the first unit of a K-tile
+    int is_off = 0;                        // conv: wave-uniform element offset of (tap, channel block) from the centre pixel
+    int is_ky = 0, is_kx = 0;
+    int is_boff = 0;                       // element offset of the K-tile inside a weight row
+    auto issue_begin = [&]() __attribute__((always_inline)) {
         if constexpr (CONV) {
-            const int ky = is_tap / 3;
-            const int kx = is_tap - ky * 3;
-            const int ci0 = is_cblk << 6;
-            if (!cg.ups) {
-                const int off = ((ky - 1) * cg.Win + (kx - 1)) * cg.Cin + ci0;     // wave-uniform
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (u < u_lo || u >= u_hi) continue;
-                    const half_t* src = ((cmask[u] >> is_tap) & 1u) ? (aptr[u] + off) : zsrc;
-                    glds16(src, reinterpret_cast<half_t*>(sbase + a_dst[u]));
-                }
-            } else {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (u < u_lo || u >= u_hi) continue;
-                    const int r = (a_dst[u] >> 7) + srow;
-                    const int gc = (sslot ^ ((r >> 1) & 7)) << 3;
-                    const half_t* src = zsrc;
-                    if (cbyx[u] >= 0) {
-                        const int uy = ((cbyx[u] >> 10) & 1023) + ky - 1, ux = (cbyx[u] & 1023) + kx - 1;
-                        if ((uy >= 0) && (uy < cg.Hout) && (ux >= 0) && (ux < cg.Wout))
-                            src = cg.in + ((size_t)((cbyx[u] >> 20) * cg.Hin + (uy >> 1)) * cg.Win + (ux >> 1)) * cg.Cin + ci0 + gc;
-                    }
-                    glds16(src, reinterpret_cast<half_t*>(sbase + a_dst[u]));
-                }
-            }
+            is_tap = tap_major ? is_out : is_in;
+            is_cblk = tap_major ? is_in : is_out;
+            is_ky = (is_tap * 11) >> 5;                 // tap / 3 for tap in [0, 9)
+            is_kx = is_tap - is_ky * 3;
+            is_off = ((is_ky - 1) * cg.Win + (is_kx - 1)) * cg.Cin + (is_cblk << 6);
+            is_boff = (is_cblk * 9 + is_tap) << 6;
         } else {
-            if (u_lo == 0 && A2g != nullptr && is_kt * 64 == p.ksplit && is_kt != kt_begin) {
+            is_boff = is_kt << 6;
+            if (A2g != nullptr && is_kt * 64 == p.ksplit && is_kt != kt_begin) {
                 // two-source A: crossing into the second matrix, once per block, before the first unit of that K-tile
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -216,33 +214,44 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
                     if (m < M) aptr[u] = A2g + (size_t)m * p.lda2 + ((sslot ^ ((r >> 1) & 7)) << 3);
                 }
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (u < u_lo || u >= u_hi) continue;
-                glds16(aptr[u], reinterpret_cast<half_t*>(sbase + a_dst[u]));
+        }
+    };
+    // LDS-DMA instruction i of the K-tile (i = 0..3: A units, 4..: B units of this wave) into stage `st`
+    auto issue_unit = [&](const int st, const int i) __attribute__((always_inline)) {
+        unsigned char* sbase = smem + st * C::STAGE;
+        if (i < 4) {
+            const int u = i;
+            if constexpr (CONV) {
+                // masked taps (the halo) read the zero page: branch-free 64-bit select (v_bfi), no exec games inside the MFMA stream
+                const uint64_t a = reinterpret_cast<uint64_t>(aptr[u] + is_off), z = reinterpret_cast<uint64_t>(zsrc);
+                const uint64_t keep = (uint64_t)0 - (uint64_t)((cmask[u] >> is_tap) & 1u);
+                const half_t* src = reinterpret_cast<const half_t*>((a & keep) | (z & ~keep));
+                if constexpr (DBG & 2) src = zsrc;
+                glds16(src, reinterpret_cast<half_t*>(sbase + a_dst[u]));
+            } else {
+                glds16((DBG & 2) ? zsrc : aptr[u], reinterpret_cast<half_t*>(sbase + a_dst[u]));
                 aptr[u] += ((amask >> u) & 1u) ? 64 : 0;
             }
-        }
-    };
-    auto issue_b = [&](const int st) {
-        unsigned char* sbase = smem + st * C::STAGE + C::A_BYTES;
-#pragma unroll
-        for (int j = 0; j < C::NB0; ++j) {
+        } else {
+            const int j = i - 4;
             if (j < nb) {       // wave-uniform
-                glds16(bptr[j], reinterpret_cast<half_t*>(sbase + (bunit0 + j) * 1024));
-                bptr[j] += ((bmask >> j) & 1u) ? 64 : 0;
+                const half_t* src = ((bmask >> j) & 1u) ? bptr[j] + is_boff : zsrc;
+                if constexpr (DBG & 4) src = zsrc;
+                glds16(src, reinterpret_cast<half_t*>(sbase + C::A_BYTES + (bunit0 + j) * 1024));
             }
         }
     };
-    auto issue_advance = [&]() {
+    auto issue_advance = [&]() __attribute__((always_inline)) {
         ++is_kt;
         if constexpr (CONV) {
-            if (++is_tap == 9) { is_tap = 0; ++is_cblk; }
+            if (++is_in == in_lim) { is_in = 0; ++is_out; }
         }
     };
-    auto wait_steady = [&]() {
-        if (C::NI0 == C::NI1 || grp == 0) wait_vm<C::NI0 + 2>();
-        else wait_vm<C::NI1 + 2>();
+    auto issue_all = [&](const int st) __attribute__((always_inline)) {
+        issue_begin();
+#pragma unroll
+        for (int i = 0; i < 4 + C::NB0; ++i) issue_unit(st, i);
+        issue_advance();
     };
 
     // ---- fragment read offsets (bytes inside a stage): row = base16 + (lane & 15), logical chunk = 4 * kk + (lane >> 4)
@@ -259,69 +268,85 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[mi][ni][r] = 0.0f;
 
-    // ---- prologue: K-tiles 0 and 1 in flight, the first phase's pieces of K-tile 0 landed
-    issue_a(0, 0, 2); issue_b(0); issue_a(0, 2, 4); issue_advance();
+    // ---- prologue: K-tiles 0 and 1 in flight, K-tile 0 landed
+    issue_all(0);
     if (nkt > 1) {
-        issue_a(1, 0, 2); issue_b(1); issue_a(1, 2, 4); issue_advance();
-        wait_steady();
+        issue_all(1);
+        if (C::NI0 == C::NI1 || grp == 0) wait_vm<C::NI0>();
+        else wait_vm<C::NI1>();
     } else {
         wait_vm<0>();
     }
     G8_SBAR();
     if (grp == 1) G8_SBAR();               // stagger: group 1 runs one barrier interval behind group 0
 
-    if constexpr (DBG) ts1 = __builtin_readcyclecounter();
+    if constexpr (DBG & 1) ts1 = __builtin_readcyclecounter();
+    // Loop invariants at the top of iteration t: K-tile t has landed (every wave waited for its share one phase ago and
+    // two barriers have passed since), K-tile t+1 is in flight, stage (t+2) % 3 is free.
+    // Phase kk (the two 32-wide k halves of the K-tile): [read 4 A + TN B fragments] barrier [4*TN MFMAs, with the LDS-DMA
+    // instructions of K-tile t+2 issued in between: X_FIRST of them in phase 0, the rest in phase 1] barrier.
+    // The ONE counted wait per K-tile sits at the end of phase 1's read section: everything but the X_FIRST instructions
+    // this wave has issued for K-tile t+2 so far must have landed, i.e. all of K-tile t+1.
+    constexpr int X_FIRST = 3;
+    constexpr int NMF = 4 * TN;                    // MFMAs per phase: 20 / 16
+    constexpr int GAP = NMF / 4;                   // an LDS-DMA instruction after every GAP MFMAs
     int st_rd = 0, st_is = 2;
-    for (int t = 0; t < nkt; ++t) {
+    // one K-tile; MORE (compile-time) = K-tile t+2 exists and is issued here: two copies of the body, no branches inside
+    auto ktile = [&](auto more_c) __attribute__((always_inline)) {
+        constexpr bool MORE = decltype(more_c)::value;
         const unsigned char* rbase = smem + st_rd * C::STAGE;
-        const bool more = (t + 2 < nkt);   // block-uniform
-        half8_t af[2][2], bf[TN][2];
-
-        // ===== phase 0: rows [0, 32) of the wave's 64
+        half8_t af[4], bf[TN];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-                af[mi][kk] = *reinterpret_cast<const half8_t*>(rbase + ((a_off ^ (kk << 6)) + mi * 2048));
+            for (int mi = 0; mi < 4; ++mi)
+                af[mi] = *reinterpret_cast<const half8_t*>(rbase + ((a_off ^ (kk << 6)) + mi * 2048));
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni)
-                bf[ni][kk] = *reinterpret_cast<const half8_t*>(rbase + ((b_off ^ (kk << 6)) + ni * 2048));
+                bf[ni] = *reinterpret_cast<const half8_t*>(rbase + ((b_off ^ (kk << 6)) + ni * 2048));
+            if (kk == 1) {
+                if constexpr (MORE) wait_vm<X_FIRST>();
+                else wait_vm<0>();
+            }
+            G8_SBAR();
+            if constexpr (MORE) {
+                if (kk == 0) issue_begin();
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < NMF; ++i) {
+                const int mi = i / TN, ni = i % TN;
+                acc[mi][ni] = mfma16(bf[ni], af[mi], acc[mi][ni]);
+                if constexpr (MORE) {
+                    if (i == GAP - 1) issue_unit(st_is, 3 * kk + 0);
+                    if (i == 2 * GAP - 1) issue_unit(st_is, 3 * kk + 1);
+                    if (i == 3 * GAP - 1) issue_unit(st_is, 3 * kk + 2);
+                }
+            }
+            if constexpr (MORE) {
+                // pin the interleave (hipcc otherwise hoists the three LDS-DMA instructions to the head of the cluster)
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, GAP, 0);       // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);         // VMEM read (the LDS-DMA)
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, NMF - 3 * GAP, 0);
+                if (C::NB0 == 3 && kk == 1) issue_unit(st_is, 6);              // group-0 waves' third B unit (wave-uniform branch)
+            }
+            __builtin_amdgcn_s_setprio(0);
+            if constexpr (MORE) {
+                if (kk == 1) issue_advance();
+            }
+            G8_SBAR();
         }
-        if (more) { issue_a(st_is, 0, 2); wait_steady(); } else { wait_vm<0>(); }
-        G8_SBAR();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = mfma16(bf[ni][kk], af[mi][kk], acc[mi][ni]);
-        __builtin_amdgcn_s_setprio(0);
-        G8_SBAR();
-
-        // ===== phase 1: rows [32, 64)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-                af[mi][kk] = *reinterpret_cast<const half8_t*>(rbase + ((a_off ^ (kk << 6)) + (2 + mi) * 2048));
-        if (more) { issue_b(st_is); issue_a(st_is, 2, 4); issue_advance(); wait_steady(); } else { wait_vm<0>(); }
-        G8_SBAR();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < TN; ++ni) acc[2 + mi][ni] = mfma16(bf[ni][kk], af[mi][kk], acc[2 + mi][ni]);
-        __builtin_amdgcn_s_setprio(0);
-        G8_SBAR();
-
         st_rd = (st_rd == 2) ? 0 : st_rd + 1;
         st_is = (st_is == 2) ? 0 : st_is + 1;
-    }
+    };
+    int t = 0;
+    for (; t + 2 < nkt; ++t) ktile(std::true_type{});
+    for (; t < nkt; ++t) ktile(std::false_type{});
     if (grp == 0) G8_SBAR();               // equal barrier counts; after it no wave reads the operand stages any more
-    if constexpr (DBG) ts2 = __builtin_readcyclecounter();
+    if constexpr (DBG & 1) ts2 = __builtin_readcyclecounter();
 
     // ------------------------------------------------------------------ epilogue
     // The wave's 64 x PW fp32 tile goes through a private LDS slab, 32 rows at a time, so that every lane then owns 8
@@ -431,6 +456,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
                 }
             }
         } else {
+            // (issuing all the pass's bias / residual loads ahead of the first store was measured: 11.0 k -> 12.3 k cycles -- the
+            //  epilogue is bound by the chip's write bandwidth, all 256 blocks store their tiles at the same time)
 #pragma unroll
             for (int q = 0; q < ITEMS / 64; ++q) {
                 const int idx = lane + 64 * q;
@@ -445,7 +472,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
             }
         }
     }
-    if constexpr (DBG) {
+    if constexpr (DBG & 1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long ts3 = __builtin_readcyclecounter();
         const int bid = blockIdx.x + gridDim.x * blockIdx.z;
@@ -457,12 +484,27 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
 
 int g8_dbg = 0;
 
+const half_t* g8_zero_page = nullptr;      // device address of this translation unit's zero page (gl8_init)
+
 template <int BN, bool CONV>
-int launch8(const gl_gemm_args& g, const ConvGeom& cg, int zs, int kper, int order_m, hipStream_t st) {
+int launch8(const gl_gemm_args& g, const ConvGeom& cg_in, int zs, int kper, int order_m, hipStream_t st) {
+    if (!g8_zero_page) return GL_ERR_BAD_ARG;          // gl_init() was not called
+    if (CONV && cg_in.ups) return GL_ERR_UNSUPPORTED;
+    ConvGeom cg = cg_in;
+    cg.zero = g8_zero_page;
     const int mt = gl_cdiv(g.M, 256), nt = gl_cdiv(g.N, BN);
     dim3 grid(mt * nt, 1, zs);
-    if (g8_dbg && BN == 160) gemm8_kernel<BN, CONV, true><<<grid, dim3(512), G8<BN>::LDS, st>>>(g, cg, zs, kper, order_m);
-    else gemm8_kernel<BN, CONV><<<grid, dim3(512), G8<BN>::LDS, st>>>(g, cg, zs, kper, order_m);
+    bool done = false;
+    if constexpr (BN == 160) {
+        void (*k)(gl_gemm_args, ConvGeom, int, int, int) = nullptr;
+        if (g8_dbg == 1) k = gemm8_kernel<BN, CONV, 1>;
+        if (g8_dbg == 3) k = gemm8_kernel<BN, CONV, 3>;
+        if (k) {
+            k<<<grid, dim3(512), G8<BN>::LDS, st>>>(g, cg, zs, kper, order_m);
+            done = true;
+        }
+    }
+    if (!done) gemm8_kernel<BN, CONV><<<grid, dim3(512), G8<BN>::LDS, st>>>(g, cg, zs, kper, order_m);
     GL_CHECK_LAUNCH();
     return 0;
 }
@@ -470,8 +512,10 @@ int launch8(const gl_gemm_args& g, const ConvGeom& cg, int zs, int kper, int ord
 template <int BN, bool CONV>
 int set_attr8() {
     hipError_t e = hipFuncSetAttribute((const void*)gemm8_kernel<BN, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, G8<BN>::LDS);
-    if (e == hipSuccess && BN == 160)
-        e = hipFuncSetAttribute((const void*)gemm8_kernel<BN, CONV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G8<BN>::LDS);
+    if constexpr (BN == 160) {
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm8_kernel<BN, CONV, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, G8<BN>::LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm8_kernel<BN, CONV, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, G8<BN>::LDS);
+    }
     return e == hipSuccess ? 0 : (int)e;
 }
 
@@ -480,7 +524,6 @@ int set_attr8() {
 // What the 8-wave kernel implements: row-major outputs, every epilogue (GEGLU only on the 128-wide tile, whose wave owns
 // whole [x | gate] pairs), the V^T tail when it starts on a wave's column range.
 int gl8_supported(const gl_gemm_args& g, bool conv, int* bn_out) {
-    (void)conv;
     if (g.out_mode == GL_OUT_F32_NCHW) return 0;
     if ((g.K % 64) != 0 || (g.N % 8) != 0 || g.M < 256) return 0;
     int bn = 128;
@@ -502,6 +545,9 @@ int gl8_launch(const gl_gemm_args& g, const ConvGeom& cg, bool conv, int bn, int
 
 int gl8_init(void) {
     int e;
+    void* zp = nullptr;
+    if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero16)) != hipSuccess) return GL_ERR_BAD_ARG;
+    g8_zero_page = reinterpret_cast<const half_t*>(zp);
     if ((e = set_attr8<160, false>())) return e;
     if ((e = set_attr8<160, true>())) return e;
     if ((e = set_attr8<128, false>())) return e;
@@ -513,5 +559,9 @@ int gl8_init(void) {
 int gl8_set_debug(int v) { g8_dbg = v; return 0; }
 int gl8_read_stamps(void* dst, int64_t bytes) {
     if (bytes > (int64_t)sizeof(unsigned long long) * 4 * 4096) return GL_ERR_BAD_ARG;
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g8_stamps), (size_t)bytes, 0, hipMemcpyDeviceToHost);
+    hipError_t e = hipMemcpyFromSymbol(dst, HIP_SYMBOL(g8_stamps), (size_t)bytes, 0, hipMemcpyDeviceToHost);
+    void* p = nullptr;
+    if (e == hipSuccess) e = hipGetSymbolAddress(&p, HIP_SYMBOL(g8_stamps));
+    if (e == hipSuccess) e = hipMemset(p, 0, sizeof(unsigned long long) * 4 * 4096);      // next reader sees only its own launch
+    return (int)e;
 }

@@ -44,6 +44,10 @@ int g_opt_order = 1;         // tile order: 0 = N-tiles fastest, 1 = M-tiles fas
 int g_opt_tile = 0;          // 0 = auto; 1 = force 128x128 (N >= 256); 2 = prefer 128x160 whenever N % 160 == 0
 int g_opt_g8 = 1;            // 8-wave deep-pipelined 256-row kernel (gemm8.hip): 0 off, 1 auto (enough tiles), 2 whenever it applies
 int g_opt_g8_tiles = 200;    // auto: at least this many 256-row tiles (x K slices)
+int g_opt_g8_tapmajor = 0;   // conv K order of the 8-wave kernel: 1 = (tap, channel block), 0 = (channel block, tap); measured equal in time,
+                             // tap-major re-fetches the input 9x from beyond L2 once a level's slab outgrows the 4 MiB L2 (r3 PMC)
+int g_opt_g8_minkt = 11;     // split-K of the 8-wave kernel: at least this many K-tiles per slice
+int g_opt_g8_minnk = 5;      // 8-wave kernel only for K >= 64 * this
 
 template <int BM, int BN, int BKT, int NW = 4>
 constexpr int lds_bytes() {
@@ -762,16 +766,28 @@ int dispatch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     }
     if (g_opt_g8) {
         int bn = 0;
-        if (gl8_supported(g, CONV, &bn)) {
+        if (!(CONV && cg.ups) && gl8_supported(g, CONV, &bn)) {      // (nearest-2x-upsampled input: 4-wave kernels only)
             const int tiles = gl_cdiv(g.M, 256) * gl_cdiv(g.N, bn);
             const int nk = g.K / 64;
+            // One block per CU: when the 256-row grid underfills the chip (32x32 levels and below), K is cut into slices up to ONE
+            // round of blocks (256), never below g_opt_g8_minkt K-tiles per slice (prologue + epilogue cost ~4 K-tiles of time).
             int splitk = 1;
-            if (g_opt_g8 == 2) splitk = choose_splitk(g, tiles, CONV);
-            if (g_opt_g8 == 2 || tiles >= g_opt_g8_tiles) {
+            if (tiles < g_opt_g8_tiles && g.workspace && g.epi != GL_EPI_GEGLU && g.vt == nullptr) {
+                splitk = 256 / tiles;
+                if (splitk > nk / g_opt_g8_minkt) splitk = nk / g_opt_g8_minkt;
+                while (splitk > 1 && (int64_t)splitk * g.M * g.N * 4 > g.workspace_bytes) --splitk;
+                if (splitk < 1) splitk = 1;
+            }
+            // plain GEMMs: measured per shape (profiles/r3_g8_probe.txt) -- multi-round grids with a short K stay on the 4-wave kernels
+            // (several resident blocks hide each other's prologue / epilogue), split-K slices need >= 20 K-tiles to pay for the reduction
+            if (!CONV && splitk > 1 && nk / splitk < 20) splitk = nk / 20 > 0 ? nk / 20 : 1;
+            bool enough = tiles * splitk >= g_opt_g8_tiles && nk >= g_opt_g8_minnk;
+            if (!CONV && enough) enough = nk >= 16 || tiles * splitk <= 256 || (g.epi == GL_EPI_GEGLU && nk >= 10);
+            if (g_opt_g8 == 2 || enough) {
                 const int kper = gl_cdiv(nk, splitk);
                 const int zs = gl_cdiv(nk, kper);
                 const int order_m = g_opt_order == 1 ? ((CONV ? 9L : 1L) * g.N > (long)g.M) : (g_opt_order == 2);
-                const int e = gl8_launch(g, cg, CONV, bn, zs, kper, order_m, st);
+                const int e = gl8_launch(g, cg, CONV, bn, zs, kper, order_m | (CONV && g_opt_g8_tapmajor ? 2 : 0), st);
                 if (e) return e;
                 if (zs > 1) {
                     const size_t total = (size_t)g.M * (g.N / 8);
@@ -810,7 +826,7 @@ extern "C" int gl_conv3x3(const gl_conv_args* a, void* stream) {
     g.M = a->B * a->Hout * a->Wout;
     g.K = 9 * a->Cin;
     ConvGeom cg{reinterpret_cast<const half_t*>(a->in), a->B, a->Hin, a->Win, a->Cin, a->Hout, a->Wout, a->stride,
-                a->upsample2x};
+                a->upsample2x, nullptr};
     return dispatch<true>(g, cg, (hipStream_t)stream);
 }
 
@@ -854,6 +870,9 @@ extern "C" int gl_set_option_gemm(int key, int value) {
     if (key == 30) { g_opt_g8 = value; return 0; }
     if (key == 31) { g_opt_g8_tiles = value; return 0; }
     if (key == 32) return gl8_set_debug(value);
+    if (key == 33) { g_opt_g8_tapmajor = value; return 0; }
+    if (key == 34) { g_opt_g8_minkt = value < 1 ? 1 : value; return 0; }
+    if (key == 35) { g_opt_g8_minnk = value; return 0; }
     if (key == 5) { g_opt_splitk_tiles = value < 0 ? 300 : value; g_opt_splitk_tiles_conv = value < 0 ? 450 : value; return 0; }   // < 0: defaults
     if (key == 6) { g_opt_splitk_nk = value; return 0; }
     return GL_ERR_BAD_ARG;

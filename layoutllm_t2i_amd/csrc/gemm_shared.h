@@ -11,6 +11,7 @@ static __device__ uint4 g_zero16[4];
 struct ConvGeom {
     const half_t* in;
     int B, Hin, Win, Cin, Hout, Wout, stride, ups;
+    const half_t* zero;        // gemm8.hip: device address of 16 zero bytes (filled by its launcher)
 };
 
 namespace {
@@ -23,45 +24,60 @@ __device__ __forceinline__ void glds16(const half_t* src, half_t* dst) {
         reinterpret_cast<__attribute__((address_space(3))) void*>(reinterpret_cast<uintptr_t>(dst)), 16, 0, 0);
 }
 
-// One 8-column piece of one output row: bias / activation / residual, then the stores.  Shared by the GEMM epilogue
-// and the split-K reduction so that both produce bit-identical results from the same fp32 sums.
-__device__ __forceinline__ void finish8(const gl_gemm_args& p, float gate, int m, int n, float (&v)[8]) {
+// One 8-column piece of one output row: bias / activation / residual, then the stores.  Shared by the GEMM epilogues
+// and the split-K reduction so that all of them produce bit-identical results from the same fp32 sums.
+// Two halves, so that a caller with several pieces in hand can issue ALL their global loads before the first dependent
+// store (the stores may alias the loads as far as the compiler knows, which otherwise serialises load -> store -> load).
+struct Fin8Aux {
+    float b[8];     // bias (zeros when absent)
+    float r[8];     // residual or row bias, as fp32
+};
+
+__device__ __forceinline__ void fin8_load(const gl_gemm_args& p, int m, int n, Fin8Aux& a) {
     const int epi = p.epi;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a.b[j] = 0.0f; a.r[j] = 0.0f; }
     if (p.bias) {
         const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n);
         const float4 b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
-        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-        v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+        a.b[0] = b0.x; a.b[1] = b0.y; a.b[2] = b0.z; a.b[3] = b0.w; a.b[4] = b1.x; a.b[5] = b1.y; a.b[6] = b1.z; a.b[7] = b1.w;
     }
-    if (epi == GL_EPI_SILU) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = silu_f(v[j]);
-    } else if (epi == GL_EPI_RES || epi == GL_EPI_GATE_RES) {
-        float r[8];
+    if (epi == GL_EPI_RES || epi == GL_EPI_GATE_RES) {
         if (p.res_f32) {
             const float* rp = reinterpret_cast<const float*>(p.res) + (size_t)m * p.ldres + n;
             const float4 r0 = *reinterpret_cast<const float4*>(rp);
             const float4 r1 = *reinterpret_cast<const float4*>(rp + 4);
-            r[0] = r0.x; r[1] = r0.y; r[2] = r0.z; r[3] = r0.w; r[4] = r1.x; r[5] = r1.y; r[6] = r1.z; r[7] = r1.w;
+            a.r[0] = r0.x; a.r[1] = r0.y; a.r[2] = r0.z; a.r[3] = r0.w; a.r[4] = r1.x; a.r[5] = r1.y; a.r[6] = r1.z; a.r[7] = r1.w;
         } else {
             uint4 raw = ld16(reinterpret_cast<const half_t*>(p.res) + (size_t)m * p.ldres + n);
             const half8_t rv = *reinterpret_cast<half8_t*>(&raw);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) r[j] = (float)rv[j];
-        }
-        if (epi == GL_EPI_RES) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] += r[j];
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = r[j] + gate * v[j];
+            for (int j = 0; j < 8; ++j) a.r[j] = (float)rv[j];
         }
     } else if (epi == GL_EPI_ROWBIAS) {
         const int sidx = m / p.rows_per_sample;
         uint4 raw = ld16(reinterpret_cast<const half_t*>(p.rowbias) + (size_t)sidx * p.ld_rowbias + n);
         const half8_t rv = *reinterpret_cast<half8_t*>(&raw);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += (float)rv[j];
+        for (int j = 0; j < 8; ++j) a.r[j] = (float)rv[j];
+    }
+}
+
+__device__ __forceinline__ void fin8_store(const gl_gemm_args& p, float gate, int m, int n, float (&v)[8], const Fin8Aux& a) {
+    const int epi = p.epi;
+    if (p.bias) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += a.b[j];
+    }
+    if (epi == GL_EPI_SILU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = silu_f(v[j]);
+    } else if (epi == GL_EPI_RES || epi == GL_EPI_ROWBIAS) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += a.r[j];
+    } else if (epi == GL_EPI_GATE_RES) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = a.r[j] + gate * v[j];
     }
     half_t* o16 = reinterpret_cast<half_t*>(p.out);
     int ld16o = p.ldc;
@@ -77,6 +93,12 @@ __device__ __forceinline__ void finish8(const gl_gemm_args& p, float gate, int m
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = (half_t)v[j];
     st16(o16 + (size_t)m * ld16o + n, *reinterpret_cast<uint4*>(&o));
+}
+
+__device__ __forceinline__ void finish8(const gl_gemm_args& p, float gate, int m, int n, float (&v)[8]) {
+    Fin8Aux a;
+    fin8_load(p, m, n, a);
+    fin8_store(p, gate, m, n, v, a);
 }
 
 }  // namespace

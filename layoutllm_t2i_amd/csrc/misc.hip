@@ -65,10 +65,11 @@ __global__ void cfg_combine_kernel(const float* __restrict__ eps2b, float guidan
     }
 }
 
-__global__ void plms_update_kernel(const float* __restrict__ x, const float* __restrict__ e, const float* __restrict__ e1,
-                                   const float* __restrict__ e2, const float* __restrict__ e3, float c0, float c1,
+// No __restrict__: gl_plms_step updates in place (x == x_prev) and an eps term may alias the output; every access is
+// same-index and element-wise, which is well defined only without the no-alias promise.
+__global__ void plms_update_kernel(const float* x, const float* e, const float* e1, const float* e2, const float* e3, float c0, float c1,
                                    float c2, float c3, float div, float sqrt_at, float s1m, float sqrt_aprev,
-                                   float dir_coef, size_t n, float* __restrict__ x_prev) {
+                                   float dir_coef, size_t n, float* x_prev) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         // e' : (c0*e + c1*e1 + c2*e2 + c3*e3) / div, left to right as plms.py:146-159 writes it
         float ep = c0 * e[i];

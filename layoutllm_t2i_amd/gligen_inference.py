@@ -36,6 +36,9 @@ def run(meta, config, starting_noise=None, clip_model=None, clip_processor=None)
     if ckpt not in _MODELS:
         _MODELS[ckpt] = interface.load_all_models(ckpt, device)
     all_models = _MODELS[ckpt]
+    # The reference reloads the checkpoint on every run() (gligen_inference.py:346), so each run starts from the GLIGEN
+    # first conv; the cached model here must be put back (restore_first_conv_from_SD is permanent, openaimodel.py:393-411).
+    all_models[0].first_conv_type = "GLIGEN"
     bs = _get(config, "batch_size", 1)
     args = dict(batch_size=bs, no_plms=bool(_get(config, "no_plms", False)), guidance_scale=_get(config, "guidance_scale", 7.5))
     m = dict(prompt=meta["prompt"], phrases=meta.get("phrases"), locations=meta["locations"],

@@ -93,20 +93,22 @@ def load_ckpt(ckpt_path, device="cuda"):
     """interface.py:78-101.  The UNet ('model') is built by this package from saved_ckpt['model'];
     autoencoder / text_encoder / grounding tokenizer are instantiated from the checkpoint's config.
 
-    Like the reference (openaimodel.py:393-405) the SD first-conv file is mandatory for a non-inpainting model:
-    a missing file raises FileNotFoundError here (the reference fails at the first scale-0 step) instead of silently
-    keeping the GLIGEN conv.  ``GLIGEN_ALLOW_NO_SD_CONV=1`` opts out explicitly (first_conv_restorable = False)."""
+    Like the reference (openaimodel.py:393-405) the SD first-conv file is needed as soon as a fuser-scale-0 step runs:
+    a missing file warns here and raises in ``restore_first_conv_from_SD`` (where the reference fails), never silently
+    keeps the GLIGEN conv.  ``GLIGEN_ALLOW_NO_SD_CONV=1`` opts out explicitly (first_conv_restorable = False)."""
     saved_ckpt = torch.load(ckpt_path, map_location="cpu")
     config = saved_ckpt["config_dict"]["_content"]
     cfg = UNetConfig.from_dict(config["model"]["params"])
     sd_path = find_sd_first_conv(ckpt_path)
-    if sd_path is None and os.environ.get("GLIGEN_ALLOW_NO_SD_CONV") != "1":
-        raise FileNotFoundError(
+    allow_missing = os.environ.get("GLIGEN_ALLOW_NO_SD_CONV") == "1"
+    if sd_path is None and not allow_missing:
+        warnings.warn(
             "SD_input_conv_weight_bias.pth not found (looked at $GLIGEN_SD_FIRST_CONV, next to the checkpoint, $GLIGEN_HOME and "
-            "the importable ldm package's GLIGEN directory): the sampler switches to it on every fuser-scale-0 step "
-            "(openaimodel.py:393-405).  Set GLIGEN_ALLOW_NO_SD_CONV=1 to run without it (results then differ from the reference).")
+            "the importable ldm package's GLIGEN directory): the first fuser-scale-0 step will raise, exactly where the reference "
+            "fails (openaimodel.py:393-405); schedules without a scale-0 stage run.  GLIGEN_ALLOW_NO_SD_CONV=1 keeps the GLIGEN conv "
+            "instead (results then differ from the reference).")
     model = UNetModel(cfg, saved_ckpt["model"], device=device, sd_first_conv=load_sd_first_conv(sd_path),
-                      allow_missing_sd_conv=sd_path is None)
+                      allow_missing_sd_conv=sd_path is None and allow_missing)
     dparams = config["diffusion"].get("params", {})
     diffusion = LatentDiffusion(linear_start=dparams.get("linear_start", 0.00085), linear_end=dparams.get("linear_end", 0.012),
                                 timesteps=dparams.get("timesteps", 1000), device=device)
@@ -330,7 +332,7 @@ def _run(all_models, args, meta, starting_noise, clip_model, clip_processor, dev
     uc = text_encoder.encode([""]).repeat(bs, 1, 1)          # the reference encodes bs copies of "" (interface.py:496)
     # S is a harness parameter: the reference hard-codes 50 (interface.py:507); ``args["steps"]`` overrides it
     samples = denoise(all_models, context, uc, relations, batch, starting_noise, meta.get("alpha_type"), cfg.guidance_scale,
-                      steps=int(cfg.get("steps", PLMS_STEPS)))
+                      steps=int(args.get("steps", PLMS_STEPS)))        # per call: not sticky through the cached config dict
     return _postprocess(autoencoder.decode(samples))
 
 

@@ -44,16 +44,36 @@ def test_unet_config_rejects_lookalike_variants():
             UNetConfig.from_dict({**base, **bad})
 
 
-def test_load_ckpt_requires_the_sd_first_conv(tmp_path, monkeypatch):
-    """A missing SD_input_conv_weight_bias.pth is an error, as in the reference (openaimodel.py:396-398), not a
-    silent fallback to the GLIGEN first conv."""
+def test_missing_sd_first_conv_fails_where_the_reference_does(tmp_path, monkeypatch):
+    """A missing SD_input_conv_weight_bias.pth is an error at the first fuser-scale-0 step, as in the reference
+    (openaimodel.py:396-398) -- never a silent fallback to the GLIGEN first conv; loading only warns, so schedules
+    without a scale-0 stage (alpha_type [1, 0, 0]) still run."""
+    from layoutllm_t2i_amd.model import UNetModel
     p = str(tmp_path / "ckpt.pth")
     stubs.write_synthetic_checkpoint(p, TINY, VAE_TINY, with_sd_conv=False)
     for k in ("GLIGEN_SD_FIRST_CONV", "GLIGEN_HOME", "GLIGEN_ALLOW_NO_SD_CONV"):
         monkeypatch.delenv(k, raising=False)
     monkeypatch.setattr(itf, "find_sd_first_conv", lambda ckpt_path=None: None)
-    with pytest.raises(FileNotFoundError):
+    built = {}
+
+    class _Stop(Exception):
+        pass
+
+    def fake_unet(cfg, sd, device=None, sd_first_conv=None, allow_missing_sd_conv=False):
+        built.update(sd_first_conv=sd_first_conv, allow=allow_missing_sd_conv)
+        raise _Stop()
+    monkeypatch.setattr(itf, "UNetModel", fake_unet)
+    with pytest.warns(UserWarning, match="SD_input_conv_weight_bias.pth not found"), pytest.raises(_Stop):
         itf.load_ckpt(p, "cpu")
+    assert built == dict(sd_first_conv=None, allow=False)
+    m = object.__new__(UNetModel)                       # the model such a load produces: not restorable, not opted out
+    m.first_conv_restorable, m.allow_missing_sd_conv, m.first_conv_type = False, False, "GLIGEN"
+    with pytest.raises(RuntimeError, match="SD first-conv"):
+        m.restore_first_conv_from_SD()
+    monkeypatch.setenv("GLIGEN_ALLOW_NO_SD_CONV", "1")
+    with pytest.raises(_Stop):
+        itf.load_ckpt(p, "cpu")
+    assert built == dict(sd_first_conv=None, allow=True)
 
 
 def test_prepare_batch_accepts_phrases_none():

@@ -143,6 +143,14 @@ def cases():
     v("conv 8x8^2 1280->1280", 8, 8, 1280, 1280)
     v("conv 3x20^2 128->256 (ragged, bn128)", 3, 20, 128, 256)
     v("conv 16x64^2 320->320", 16, 64, 320, 320)
+    v("conv 8x32^2 1920->640", 8, 32, 1920, 640)
+    v("conv 8x32^2 640->640 s2", 8, 32, 640, 640, stride=2)
+    v("conv 8x16^2 2560->1280", 8, 16, 2560, 1280)
+    v("conv 8x16^2 1280->1280 res f32", 8, 16, 1280, 1280, epi="res", f32=True)
+    v("conv 8x8^2 2560->1280", 8, 8, 2560, 1280)
+    g("gemm 8192x640x1920 a2 bias", 8192, 640, 1920, a2=True)
+    g("gemm 2048x1280x2560 a2 bias", 2048, 1280, 2560, a2=True)
+    g("gemm 512x1280x5120 res f32", 512, 1280, 5120, "res", f32=True)
     return c
 
 
@@ -198,22 +206,27 @@ def main():
             print(f"  {'ok  ' if same else 'FAIL'} {name}")
             allok &= same
     if "time" in which:
-        print("== time (us, TF/s): 4-wave | 8-wave forced | auto")
+        cfgs = [("4-wave", {30: 0}), ("auto", {30: 1, 34: 11}), ("auto minkt 20", {30: 1, 34: 20}), ("auto minkt 6", {30: 1, 34: 6}), ("forced", {30: 2, 34: 11})]
+        print("== time (us, TF/s): " + " | ".join(c[0] for c in cfgs))
         iters = int(os.environ.get("G8_ITERS", "10"))
+
+        def setopts(d):
+            for k, v in d.items():
+                ops.set_option(k, v)
         for name, alloc, launch, fl in cs:
-            ts = {0: [], 2: [], 1: []}
+            ts = [[] for _ in cfgs]
             o = alloc()
             run = lambda: launch(o)
-            for mode in (0, 2, 1):
-                ops.set_option(30, mode)
+            for _, d in cfgs:
+                setopts(d)
                 run()
             for _ in range(5):
-                for mode in (0, 2, 1):
-                    ops.set_option(30, mode)
-                    ts[mode].append(timeit(run, iters))
-            med = {m: sorted(v)[len(v) // 2] for m, v in ts.items()}
-            print(f"  {name:44s} {med[0] * 1e6:8.1f} {fl / med[0] / 1e12:7.1f} | {med[2] * 1e6:8.1f} {fl / med[2] / 1e12:7.1f} | "
-                  f"{med[1] * 1e6:8.1f} {fl / med[1] / 1e12:7.1f}   x{med[0] / med[2]:.2f}")
+                for i, (_, d) in enumerate(cfgs):
+                    setopts(d)
+                    ts[i].append(timeit(run, iters))
+            med = [sorted(v)[len(v) // 2] for v in ts]
+            print(f"  {name:44s} " + " | ".join(f"{m * 1e6:8.1f} {fl / m / 1e12:7.1f}" for m in med) + f"   x{med[0] / min(med[1:4]):.2f}")
+        setopts({30: 1, 34: 11})
     if "stamps" in which:
         import ctypes
         import numpy as np
@@ -222,22 +235,22 @@ def main():
         ops.set_option(30, 1)
         for name, alloc, launch, fl in cs:
             o = alloc()
-            ops.set_option(32, 1)
-            for _ in range(3):
-                launch(o)
-            torch.cuda.synchronize()
-            buf = np.zeros(4 * 4096, dtype=np.uint64)
-            _lib.check(_lib.lib().gl_debug_read(8, buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes), "gl_debug_read")
-            ops.set_option(32, 0)
-            st = buf.reshape(4096, 4).astype(np.int64)
-            st = st[st[:, 0] != 0]
-            if len(st) == 0:
-                print(f"  {name}: no stamps")
-                continue
-            t0 = st[:, 0].min()
-            pro, loop, epi = st[:, 1] - st[:, 0], st[:, 2] - st[:, 1], st[:, 3] - st[:, 2]
-            print(f"  {name:40s} blocks={len(st):4d} pro {np.median(pro):8.0f} loop {np.median(loop):9.0f} epi {np.median(epi):8.0f} "
-                  f"| start spread {int((st[:, 0] - t0).max()):7d} first-end {int(st[:, 3].min() - t0):8d} last-end {int(st[:, 3].max() - t0):8d}")
+            row = []
+            for dbg in (1, 3):     # stamps; + A from the zero page
+                buf = np.zeros(4 * 4096, dtype=np.uint64)
+                ops.set_option(32, dbg)
+                for _ in range(3):
+                    launch(o)
+                torch.cuda.synchronize()
+                _lib.check(_lib.lib().gl_debug_read(8, buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes), "gl_debug_read")
+                ops.set_option(32, 0)
+                st = buf.reshape(4096, 4).astype(np.int64)
+                st = st[st[:, 0] != 0]
+                if len(st) == 0:
+                    break
+                pro, loop, epi = st[:, 1] - st[:, 0], st[:, 2] - st[:, 1], st[:, 3] - st[:, 2]
+                row.append(f"[dbg {dbg}] pro {np.median(pro):6.0f} loop {np.median(loop):8.0f} epi {np.median(epi):6.0f} tot {int(st[:, 3].max() - st[:, 0].min()):8d}")
+            print(f"  {name:36s} " + " | ".join(row))
     ops.set_option(30, 1)
     print("ALL OK" if allok else "FAILURES")
     sys.exit(0 if allok else 1)
