@@ -216,31 +216,40 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
             }
         }
     };
-    // LDS-DMA instruction i of the K-tile (i = 0..3: A units, 4..: B units of this wave) into stage `st`
-    auto issue_unit = [&](const int st, const int i) __attribute__((always_inline)) {
-        unsigned char* sbase = smem + st * C::STAGE;
+    // LDS-DMA instruction i of the K-tile (i = 0..3: A units, 4..: B units of this wave), in two halves: the source address is
+    // worked out in the READ section of the phase (the wave then only waits for the barrier; ~7 VALU per conv unit), the
+    // instruction itself goes out between the MFMAs of the following cluster.
+    auto unit_src = [&](const int i) __attribute__((always_inline)) -> const half_t* {
+        const half_t* src;
         if (i < 4) {
             const int u = i;
             if constexpr (CONV) {
-                // masked taps (the halo) read the zero page: branch-free 64-bit select (v_bfi), no exec games inside the MFMA stream
+                // masked taps (the halo) read the zero page: branch-free 64-bit select (v_bfi), no exec games
                 const uint64_t a = reinterpret_cast<uint64_t>(aptr[u] + is_off), z = reinterpret_cast<uint64_t>(zsrc);
                 const uint64_t keep = (uint64_t)0 - (uint64_t)((cmask[u] >> is_tap) & 1u);
-                const half_t* src = reinterpret_cast<const half_t*>((a & keep) | (z & ~keep));
-                if constexpr (DBG & 2) src = zsrc;
-                glds16(src, reinterpret_cast<half_t*>(sbase + a_dst[u]));
+                src = reinterpret_cast<const half_t*>((a & keep) | (z & ~keep));
             } else {
-                glds16((DBG & 2) ? zsrc : aptr[u], reinterpret_cast<half_t*>(sbase + a_dst[u]));
+                src = aptr[u];
                 aptr[u] += ((amask >> u) & 1u) ? 64 : 0;
             }
+            if constexpr (DBG & 2) src = zsrc;
         } else {
             const int j = i - 4;
-            if (j < nb) {       // wave-uniform
-                const half_t* src = ((bmask >> j) & 1u) ? bptr[j] + is_boff : zsrc;
-                if constexpr (DBG & 4) src = zsrc;
-                glds16(src, reinterpret_cast<half_t*>(sbase + C::A_BYTES + (bunit0 + j) * 1024));
-            }
+            src = ((bmask >> (j < C::NB0 ? j : 0)) & 1u) ? bptr[j < C::NB0 ? j : 0] + is_boff : zsrc;
+            if constexpr (DBG & 4) src = zsrc;
+        }
+        return src;
+    };
+    auto unit_fire = [&](const int st, const int i, const half_t* src) __attribute__((always_inline)) {
+        unsigned char* sbase = smem + st * C::STAGE;
+        if (i < 4) {
+            glds16(src, reinterpret_cast<half_t*>(sbase + a_dst[i]));
+        } else {
+            const int j = i - 4;
+            if (j < nb) glds16(src, reinterpret_cast<half_t*>(sbase + C::A_BYTES + (bunit0 + j) * 1024));     // wave-uniform
         }
     };
+    auto issue_unit = [&](const int st, const int i) __attribute__((always_inline)) { unit_fire(st, i, unit_src(i)); };
     auto issue_advance = [&]() __attribute__((always_inline)) {
         ++is_kt;
         if constexpr (CONV) {
@@ -304,23 +313,27 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni)
                 bf[ni] = *reinterpret_cast<const half8_t*>(rbase + ((b_off ^ (kk << 6)) + ni * 2048));
+            const half_t* nsrc[4] = {zsrc, zsrc, zsrc, zsrc};
+            if constexpr (MORE) {
+                if (kk == 0) issue_begin();
+#pragma unroll
+                for (int q = 0; q < 3; ++q) nsrc[q] = unit_src(3 * kk + q);
+                if (C::NB0 == 3 && kk == 1) nsrc[3] = unit_src(6);
+            }
             if (kk == 1) {
                 if constexpr (MORE) wait_vm<X_FIRST>();
                 else wait_vm<0>();
             }
             G8_SBAR();
-            if constexpr (MORE) {
-                if (kk == 0) issue_begin();
-            }
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < NMF; ++i) {
                 const int mi = i / TN, ni = i % TN;
                 acc[mi][ni] = mfma16(bf[ni], af[mi], acc[mi][ni]);
                 if constexpr (MORE) {
-                    if (i == GAP - 1) issue_unit(st_is, 3 * kk + 0);
-                    if (i == 2 * GAP - 1) issue_unit(st_is, 3 * kk + 1);
-                    if (i == 3 * GAP - 1) issue_unit(st_is, 3 * kk + 2);
+                    if (i == GAP - 1) unit_fire(st_is, 3 * kk + 0, nsrc[0]);
+                    if (i == 2 * GAP - 1) unit_fire(st_is, 3 * kk + 1, nsrc[1]);
+                    if (i == 3 * GAP - 1) unit_fire(st_is, 3 * kk + 2, nsrc[2]);
                 }
             }
             if constexpr (MORE) {
@@ -331,7 +344,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
                     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);         // VMEM read (the LDS-DMA)
                 }
                 __builtin_amdgcn_sched_group_barrier(0x008, NMF - 3 * GAP, 0);
-                if (C::NB0 == 3 && kk == 1) issue_unit(st_is, 6);              // group-0 waves' third B unit (wave-uniform branch)
+                if (C::NB0 == 3 && kk == 1) unit_fire(st_is, 6, nsrc[3]);      // group-0 waves' third B unit (wave-uniform branch)
             }
             __builtin_amdgcn_s_setprio(0);
             if constexpr (MORE) {
