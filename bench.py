@@ -123,15 +123,23 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             sd_cpu_sample = {k: v.cpu() for k, v in sd.items()}
         del sd
+    # VAE decoder weights: built on rank 0 and sent with the UNet in the SAME broadcast (dist.broadcast_bundle: one flat buffer)
+    want_vae = not args.no_vae and not args.tiny
+    vae = None
+    if rank == 0 and want_vae:
+        vae = VAEDecoder(random_vae_state_dict(VAEConfig(), dev, seed=1), VAEConfig(), dev)
     bcast_ms = None
     if world > 1:
+        from layoutllm_t2i_amd.dist import broadcast_bundle
         torch.cuda.synchronize()
         dist.barrier()
         tb = time.time()
-        packed = broadcast_packed(packed, cfg, dev, src=0)
+        packed, vae_w, _ = broadcast_bundle(packed, vae.W if vae is not None else None, cfg if rank == 0 else None, dev, src=0)
         torch.cuda.synchronize()
         dist.barrier()
         bcast_ms = (time.time() - tb) * 1e3
+        if rank != 0 and want_vae:
+            vae = VAEDecoder.from_packed(vae_w, VAEConfig(), dev)
     model = UNetModel.__new__(UNetModel)
     # assemble the facade around already-packed weights (UNetModel.__init__ packs from a state_dict)
     model.cfg, model.device = cfg, dev
@@ -141,9 +149,6 @@ def main():
     model.fuser_scale, model.training, model._cond_key = 1.0, False, None
     model.engine = UNetEngine(packed)
     diffusion = LatentDiffusion(device=dev)
-    vae = None
-    if not args.no_vae and not args.tiny:
-        vae = VAEDecoder(random_vae_state_dict(VAEConfig(), dev, seed=1 + rank), VAEConfig(), dev)   # 0.1 GB: built per rank
     all_models = (model, vae, None, diffusion, {})
     setup_s = time.time() - t0
 

@@ -58,6 +58,67 @@ def broadcast_packed(P: Optional[PackedWeights], cfg: UNetConfig, device, src: i
     return unflatten_packed(flat, manifest, cfg, device)
 
 
+_DT = {"torch.float16": torch.float16, "torch.float32": torch.float32, "torch.int32": torch.int32, "torch.uint8": torch.uint8}
+
+
+def flatten_tensors(tensors: Dict[str, torch.Tensor], device) -> Tuple[torch.Tensor, list]:
+    """name -> tensor dict as ONE 256-byte-aligned uint8 buffer + a manifest [(name, dtype, shape, offset, nbytes)]."""
+    man, off = [], 0
+    for k in sorted(tensors):
+        t = tensors[k]
+        nb = t.numel() * t.element_size()
+        man.append((k, str(t.dtype), tuple(t.shape), off, nb))
+        off += (nb + _ALIGN - 1) // _ALIGN * _ALIGN
+    flat = torch.zeros(max(off, _ALIGN), dtype=torch.uint8, device=device)
+    for k, _, _, o, nb in man:
+        if nb:
+            flat[o:o + nb].copy_(tensors[k].contiguous().view(-1).view(torch.uint8))
+    return flat, man
+
+
+def unflatten_tensors(flat: torch.Tensor, manifest: list) -> Dict[str, torch.Tensor]:
+    """Views into ``flat`` (no copies)."""
+    out = {}
+    for k, dt, shape, o, nb in manifest:
+        out[k] = flat[o:o + nb].view(_DT[dt]).view(tuple(shape))
+    return out
+
+
+def broadcast_bundle(P: Optional[PackedWeights], vae_w: Optional[Dict[str, torch.Tensor]], cfg: Optional[UNetConfig], device,
+                     src: int = 0, extra: Optional[dict] = None):
+    """The job's ONE data-path collective: the packed UNet buffer (2.5 GB, the C engine's weight-table layout)
+    AND the packed VAE-decoder tensors (0.1 GB) travel in a single ``broadcast`` of one flat byte buffer; the few host-side
+    facts (offsets, configs, ``extra``) go ahead of it as a pickled object.  Rank ``src`` passes its objects, the others
+    pass None.  Returns (PackedWeights, vae tensor dict or None, extra) on every rank; tensors are views of the buffer."""
+    rank = dist.get_rank()
+    if rank == src:
+        uflat, uman = flatten_packed(P)
+        vflat, vman = (flatten_tensors(vae_w, uflat.device) if vae_w is not None else (None, None))
+        usz = int(uflat.numel())
+        total = usz + (int(vflat.numel()) if vflat is not None else 0)
+        head = dict(unet=uman, unet_bytes=usz, vae=vman, total=total, cfg=cfg, extra=extra)
+        if vflat is not None:
+            flat = torch.empty(total, dtype=torch.uint8, device=uflat.device)
+            flat[:usz].copy_(uflat)
+            flat[usz:].copy_(vflat)
+        else:
+            flat = uflat
+        box = [head]
+    else:
+        flat, box = None, [None]
+    dist.broadcast_object_list(box, src=src)
+    head = box[0]
+    if rank != src:
+        flat = torch.empty(head["total"], dtype=torch.uint8, device=device)
+    dist.broadcast(flat.view(torch.int64) if flat.numel() % 8 == 0 else flat, src=src)      # the one collective
+    if rank == src:
+        return P, vae_w, extra                  # the sender keeps its own objects (the staging buffer is dropped)
+    usz = head["unet_bytes"]
+    Pb = unflatten_packed(flat[:usz], head["unet"], head["cfg"], device)
+    vw = unflatten_tensors(flat[usz:], head["vae"]) if head["vae"] is not None else None
+    return Pb, vw, head["extra"]
+
+
 def checksum(P: PackedWeights) -> int:
     """Order-independent integer checksum of all packed bytes (broadcast-then-compare tests)."""
     tot = 0

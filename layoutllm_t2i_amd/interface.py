@@ -366,3 +366,130 @@ def generate_batch_images(all_models, captions, labels, bboxes, clip_model=None,
     starting_noise = torch.randn(bs, 4, 64, 64).to(device)
     warnings.filterwarnings("ignore", category=DeprecationWarning)
     return run_batch_images(all_models, args, meta, starting_noise, clip_model, clip_processor, device=device)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Multi-GPU product entry.  The reference's inference path is single-GPU (txt2img.py:535-536,
+# train_rl.py:321); prompts are independent units, so the 8-GPU mode is: rank 0 reads the checkpoint, ONE broadcast
+# carries the packed UNet + VAE weights, every call shards the prompts round-robin (rank r takes prompts r, r + world, ...),
+# per-PROMPT seeds make a sample's result independent of the rank that ran it, and the uint8 images are gathered on rank 0.
+# One process per GPU under torch.distributed ("nccl" = RCCL over xGMI on ROCm; "gloo" in the tests).
+# ------------------------------------------------------------------------------------------------------------------
+def _unet_facade(packed, cfg, device):
+    from .engine import UNetEngine
+    m = UNetModel.__new__(UNetModel)
+    m.cfg, m.device = cfg, torch.device(device)
+    m.image_size, m.in_channels, m.out_channels, m.model_channels = cfg.image_size, cfg.in_channels, cfg.out_channels, cfg.model_channels
+    m.first_conv_restorable, m.allow_missing_sd_conv, m.first_conv_type = bool(packed.has_sd_conv), False, "GLIGEN"
+    m.grounding_tokenizer_input = GroundingNetInput()
+    m.fuser_scale, m.training, m._cond_key = 1.0, False, None
+    m.engine = UNetEngine(packed)
+    return m
+
+
+def load_all_models_sharded(ckpt, device, src=0):
+    """``load_all_models`` for a torch.distributed job: only rank ``src`` touches the checkpoint file; the others receive the
+    packed UNet (the C engine's flat weight buffer) and the packed VAE decoder in dist.broadcast_bundle's single collective,
+    plus the config dict.  On the receiving ranks ``text_encoder`` is None: conditioning is prepared on ``src`` and
+    scattered per call (generate_batch_images_sharded).  Returns the usual 5-tuple on every rank."""
+    import torch.distributed as dist
+    from .dist import broadcast_bundle
+    if not (dist.is_available() and dist.is_initialized()):
+        return load_all_models(ckpt, device)
+    rank = dist.get_rank()
+    if rank == src:
+        am = load_all_models(ckpt, device)
+        model, autoencoder, text_encoder, diffusion, config = am
+        if not isinstance(autoencoder, VAEDecoder):
+            raise NotImplementedError("the sharded entry broadcasts the HIP VAE decoder's packed weights (unset GLIGEN_REFERENCE_VAE)")
+        dcfg = dict(linear_start=diffusion.linear_start, linear_end=diffusion.linear_end, timesteps=diffusion.num_timesteps)
+        broadcast_bundle(model.engine.P, autoencoder.W, model.cfg, device, src,
+                         extra=dict(config=config, vcfg=autoencoder.cfg, diffusion=dcfg))
+        return am
+    P, vw, extra = broadcast_bundle(None, None, None, device, src)
+    model = _unet_facade(P, P.cfg, device)
+    autoencoder = VAEDecoder.from_packed(vw, extra["vcfg"], device)
+    d = extra["diffusion"]
+    diffusion = LatentDiffusion(linear_start=d["linear_start"], linear_end=d["linear_end"], timesteps=d["timesteps"], device=device)
+    return model, autoencoder, None, diffusion, extra["config"]
+
+
+@torch.no_grad()
+def prepare_conditioning(all_models, captions, labels, bboxes, clip_model, clip_processor, device):
+    """Everything ``run_batch_images`` feeds the sampler (interface.py:486-535), per prompt row, on the CPU: context / uc
+    [n, 77, 768], relations [n, R, 768], boxes / masks / text_embeddings [n, 30, ...].  Rows are independent, so any subset of
+    rows is a valid batch."""
+    model, autoencoder, text_encoder, diffusion, config = all_models
+    n = len(captions)
+    meta = dict(prompts=captions, phrases=labels, locations=bboxes)
+    batch = prepare_batch_multiple(meta, clip_model, clip_processor, n, device=device)
+    cond = dict(context=text_encoder.encode(captions), uc=text_encoder.encode([""]).repeat(n, 1, 1),
+                relations=prepare_relation_phrases_batch(captions, config.get("max_relations", 10), text_encoder, device=device),
+                boxes=batch["boxes"], masks=batch["masks"], text_embeddings=batch["text_embeddings"])
+    return {k: v.detach().float().cpu().contiguous() for k, v in cond.items()}
+
+
+def prompt_noise(seeds, latent=64):
+    """Starting noise [n, 4, latent, latent], row i drawn from its OWN CPU generator seeded with ``seeds[i]``: a prompt's
+    noise does not depend on the batch it is in or the rank it runs on."""
+    rows = []
+    for sd_ in seeds:
+        g = torch.Generator(device="cpu")
+        g.manual_seed(int(sd_))
+        rows.append(torch.randn(1, 4, latent, latent, generator=g))
+    return torch.cat(rows, 0) if rows else torch.zeros(0, 4, latent, latent)
+
+
+@torch.no_grad()
+def run_shard(all_models, cond, noise, device, alpha_type=(0.3, 0.0, 0.7), guidance_scale=7.5, steps=PLMS_STEPS):
+    """Denoise + decode the rows of ``cond`` (a prepare_conditioning dict, or a row subset of one) as ONE batch;
+    returns uint8 [n, H, W, 3] (the arithmetic of _postprocess, interface.py:543-547)."""
+    model, autoencoder = all_models[0], all_models[1]
+    n = noise.shape[0]
+    if n == 0:
+        return np.zeros((0, 0, 0, 3), dtype=np.uint8)
+    model.first_conv_type = "GLIGEN"      # every sharded call starts from the checkpoint's state, whatever ran before on this rank
+    dv = lambda t: t.to(device)
+    batch = dict(boxes=dv(cond["boxes"]), masks=dv(cond["masks"]), text_embeddings=dv(cond["text_embeddings"]))
+    lat = denoise(all_models, dv(cond["context"]), dv(cond["uc"]), dv(cond["relations"]), batch, dv(noise), list(alpha_type),
+                  guidance_scale, steps=steps)
+    img = autoencoder.decode(lat)
+    img = torch.clamp(img, min=-1, max=1) * 0.5 + 0.5
+    return (img.cpu().numpy().transpose(0, 2, 3, 1) * 255).astype(np.uint8)
+
+
+def generate_batch_images_sharded(all_models, captions=None, labels=None, bboxes=None, clip_model=None, clip_processor=None,
+                                  device=None, seeds=None, src=0, steps=PLMS_STEPS, latent=64):
+    """``generate_batch_images`` (interface.py:551-570) across the ranks of a torch.distributed job.  Rank ``src`` passes the
+    prompts (the others pass None) and gets the list of PIL images in prompt order; the other ranks get None.
+    Per call: one object broadcast of the conditioning rows (~0.4 MB per prompt), no collective during the 51 sampling
+    steps, one gather of uint8 images.  ``seeds[i]`` seeds prompt i's starting noise (default: i)."""
+    import torch.distributed as dist
+    from .dist import shard_indices
+    from PIL import Image
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    rank, world = (dist.get_rank(), dist.get_world_size()) if multi else (0, 1)
+    box = [None]
+    if rank == src or not multi:
+        n = len(captions)
+        seeds = list(range(n)) if seeds is None else [int(s_) for s_ in seeds]
+        assert len(seeds) == n
+        box = [dict(cond=prepare_conditioning(all_models, captions, labels, bboxes, clip_model, clip_processor, device), seeds=seeds)]
+    if multi:
+        dist.broadcast_object_list(box, src=src)
+    cond, seeds = box[0]["cond"], box[0]["seeds"]
+    n = len(seeds)
+    mine = shard_indices(n, rank, world)
+    sub = {k: v[mine] for k, v in cond.items()}
+    imgs = run_shard(all_models, sub, prompt_noise([seeds[i] for i in mine], latent), device, steps=steps)
+    if not multi:
+        return [Image.fromarray(a) for a in imgs]
+    parts = [None] * world if rank == src else None
+    dist.gather_object((mine, imgs), parts, dst=src)
+    if rank != src:
+        return None
+    out = [None] * n
+    for idx, arr in parts:
+        for j, i in enumerate(idx):
+            out[i] = Image.fromarray(arr[j])
+    return out

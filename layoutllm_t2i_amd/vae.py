@@ -62,6 +62,19 @@ class VAEDecoder:
         self.W = W
         self._pool: Dict[tuple, torch.Tensor] = {}
 
+    @classmethod
+    def from_packed(cls, W: Mapping[str, torch.Tensor], cfg: VAEConfig, device="cuda:0") -> "VAEDecoder":
+        """A decoder around ALREADY PACKED tensors (``self.W`` of another instance, e.g. received through
+        dist.broadcast_bundle): no state_dict, no repacking."""
+        if not torch.cuda.is_available():
+            raise RuntimeError("VAEDecoder needs a GPU: there is no CPU fallback")
+        init_device()
+        self = cls.__new__(cls)
+        self.cfg, self.device, self.scale_factor = cfg, torch.device(device), cfg.scale_factor
+        self.W = {k: v.to(self.device) for k, v in W.items()}
+        self._pool = {}
+        return self
+
     def buf(self, tag, shape, dtype=F16):
         key = (tag, tuple(shape), dtype)
         t = self._pool.get(key)

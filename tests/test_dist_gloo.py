@@ -68,3 +68,41 @@ def test_shard_indices_ragged():
     assert shard_indices(64, 3, 8) == [3, 11, 19, 27, 35, 43, 51, 59]
     assert shard_indices(5, 7, 8) == []
     assert sum(len(shard_indices(13, r, 4)) for r in range(4)) == 13
+
+
+def test_bundle_broadcast_world2_one_collective():
+    """dist.broadcast_bundle: UNet flat buffer + VAE tensors in ONE tensor broadcast (plus one pickled header); both ranks end
+    with identical bytes, dtypes, shapes, the sender's extras and config."""
+    import json
+    import subprocess
+    world, port = 2, _free_port()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_bundle_worker.py")
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, worker], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    res = []
+    try:
+        for p in procs:
+            out, err = p.communicate(timeout=240)
+            assert p.returncode == 0, err[-2000:]
+            res.append(json.loads(next(l for l in out.splitlines() if l.startswith("RESULT "))[7:]))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    a, b = sorted(res, key=lambda d: d["rank"])
+    assert a["checksum"] == b["checksum"] and a["has_sd"] and b["has_sd"] and a["cfg_ok"] and b["cfg_ok"]
+    assert a["vae"] == b["vae"] and len(a["vae"]) == 4
+    assert a["extra"] == b["extra"] == {"tag": "hello", "n": 3}
+    assert a["tensor_broadcasts"] == b["tensor_broadcasts"] == 1
+
+
+def test_flatten_tensors_roundtrip():
+    from layoutllm_t2i_amd.dist import flatten_tensors, unflatten_tensors
+    g = torch.Generator().manual_seed(1)
+    d = {"b": torch.randn(5, 3, generator=g).half(), "a": torch.randn(7, generator=g), "z": torch.zeros(0)}
+    flat, man = flatten_tensors(d, "cpu")
+    assert flat.dtype == torch.uint8 and flat.numel() % 256 == 0 and [m[0] for m in man] == ["a", "b", "z"]
+    back = unflatten_tensors(flat, man)
+    assert all(torch.equal(back[k], d[k]) and back[k].dtype == d[k].dtype for k in d)

@@ -32,7 +32,10 @@ def rel_l2(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-def report(name, out, ref):
+def report(name, out, ref, frac_bound=None):
+    """rel-L2, and the fraction of elements outside north_star's elementwise rtol 1e-3 / atol 1e-4 -- which is NOT met with
+    fp16 matrix operands (floor: 43 % outside at rel-L2 1.1e-3, tools/precision_sim.py); ``frac_bound`` asserts that the
+    engine stays at that floor (<= 1.1x the measured fraction) instead of only printing it."""
     out, ref = out.float().cpu(), ref.float().cpu()
     r = rel_l2(out, ref)
     d = (out - ref).abs()
@@ -40,6 +43,8 @@ def report(name, out, ref):
     print(f"[{name}] rel_l2={r:.3e} max|err|={float(d.max()):.3e} |ref|max={float(ref.abs().max()):.3f} "
           f"outside rtol1e-3/atol1e-4: {100 * frac:.1f}%")
     assert torch.isfinite(out).all(), name
+    if frac_bound is not None:
+        assert frac <= frac_bound, f"{name}: {100 * frac:.1f}% of elements outside rtol 1e-3 / atol 1e-4 (bound {100 * frac_bound:.1f}%)"
     return r
 
 
@@ -95,12 +100,14 @@ def oracle_one(sd, cfg, inp, k, cond, tval, fuser_scale=1.0, first_conv=None):
 
 
 # measured on MI355X (round 2): see DESIGN.md section 4; asserts are <= 1.5x these
-BOUND_FULL = 1.8e-3          # measured 1.11e-3 .. 1.21e-3 over all six (batch, mode) cases and both 768px rows
+BOUND_FULL = 1.8e-3          # measured 1.11e-3 .. 1.21e-3 over all (batch, mode) cases and both 768px rows
+FRAC_FULL = 0.52             # elements outside rtol 1e-3 / atol 1e-4: measured 42 .. 47 % (fp16-operand floor 43 %); bound = 1.1x
 
 
-@pytest.mark.parametrize("B", [4, 16], ids=["configs1_2B8", "configs4_2B32"])
+@pytest.mark.parametrize("B", [4, 8, 16], ids=["configs1_2B8", "configs3_2B16", "configs4_2B32"])
 def test_config2_shapes_at_bench_batch_vs_oracle(B):
-    """configs[1] (B = 4 -> 2B = 8) and configs[4] (B = 16 -> 2B = 32): the 2B batch the sampler launches, checked
+    """configs[1] (B = 4 -> 2B = 8), configs[3]'s per-GPU batch (64 / 8 GPUs = 8 -> 2B = 16: other tile / split-K / 8-wave
+    dispatch decisions than either neighbour) and configs[4] (B = 16 -> 2B = 32): the 2B batch the sampler launches, checked
     against the oracle on one conditional sample (k = 1) and its unconditional twin (row B + 1); fuser on, then the
     scale-0 / SD-first-conv form the last 35 sampling steps use."""
     model, sd, fc, cfg = full_model()
@@ -112,9 +119,9 @@ def test_config2_shapes_at_bench_batch_vs_oracle(B):
     e_on = eng.forward(x, 481.0, 1.0, False, 2).clone()
     e_off = eng.forward(x, 201.0, 0.0, True, 2).clone()
     assert e_on.shape == (2 * B, 4, hw, hw)
-    r = [report(f"2B={2 * B} cond  fuser on ", e_on[k:k + 1], oracle_one(sd, cfg, inp, k, True, 481)),
-         report(f"2B={2 * B} uncond fuser on ", e_on[B + k:B + k + 1], oracle_one(sd, cfg, inp, k, False, 481)),
-         report(f"2B={2 * B} cond  fuser off", e_off[k:k + 1], oracle_one(sd, cfg, inp, k, True, 201, 0.0, fc))]
+    r = [report(f"2B={2 * B} cond  fuser on ", e_on[k:k + 1], oracle_one(sd, cfg, inp, k, True, 481), FRAC_FULL),
+         report(f"2B={2 * B} uncond fuser on ", e_on[B + k:B + k + 1], oracle_one(sd, cfg, inp, k, False, 481), FRAC_FULL),
+         report(f"2B={2 * B} cond  fuser off", e_off[k:k + 1], oracle_one(sd, cfg, inp, k, True, 201, 0.0, fc), FRAC_FULL)]
     assert max(r) < BOUND_FULL, r
     # samples are independent: every row of the batch is a different image, and a replay is deterministic
     assert rel_l2(e_on[0:1], e_on[1:2]) > 1e-2 and rel_l2(e_on[0:1], e_on[B:B + 1]) > 1e-3
@@ -154,8 +161,8 @@ def test_config3_768px_whole_unet_vs_oracle_and_50_steps():
     eng.set_conditioning(two["context"], two["relations"], two["boxes"], two["masks"], two["positive_embeddings"], hw)
     x = inp["x"].to(DEV)
     e = eng.forward(x, 481.0, 1.0, False, 2).clone()
-    r = [report("768px cond", e[k:k + 1], oracle_one(sd, cfg, inp, k, True, 481)),
-         report("768px uncond", e[B + k:B + k + 1], oracle_one(sd, cfg, inp, k, False, 481))]
+    r = [report("768px cond", e[k:k + 1], oracle_one(sd, cfg, inp, k, True, 481), FRAC_FULL),
+         report("768px uncond", e[B + k:B + k + 1], oracle_one(sd, cfg, inp, k, False, 481), FRAC_FULL)]
     assert max(r) < BOUND_FULL, r
     assert torch.equal(e, eng.forward(x, 481.0, 1.0, False, 2))
     # the unconditional half ignores boxes / phrase embeddings entirely (null tokens; rela_fuse == LN3)
@@ -171,3 +178,39 @@ def test_config3_768px_whole_unet_vs_oracle_and_50_steps():
     model.first_conv_type = "GLIGEN"
     lat2 = denoise(am, inp["context"], inp["uc"], inp["relations"], batch, x, [0.3, 0.0, 0.7], 7.5, steps=50)
     assert torch.equal(lat, lat2), "the sampling run is deterministic (fixed reduction orders, graph replay)"
+
+
+def test_config0_single_prompt_64px_10_steps_vs_oracle_plms():
+    """configs[0] (the txt2img plumbing case -- 1 image, 64x64 latent, S = 10 PLMS steps,
+    2 grounding boxes, CFG 7.5, alpha_type [0.3, 0, 0.7] -> 3 fuser-on and 7 fuser-off steps with the SD first conv,
+    22 UNet evaluations) through ``denoise`` on the FULL-SIZE model, against the oracle's PLMS loop driving the oracle UNet
+    (plms.py:58-163 restated in oracle/plms_ref.py).  The B = 1 batch takes the small-grid dispatch paths (2B = 2) that no
+    other whole-model test reaches."""
+    from oracle import plms_ref
+    model, sd, fc, cfg = full_model()
+    model.first_conv_type = "GLIGEN"
+    B, hw, S = 1, 64, 10
+    inp, _ = cfg_batch(cfg, B, hw, 2, seed=99)
+    assert float(inp["masks"].sum()) == 2.0
+    batch = dict(boxes=inp["boxes"], masks=inp["masks"], text_embeddings=inp["positive_embeddings"])
+    am = (model, None, None, LatentDiffusion(device=DEV), {})
+    torch.manual_seed(5)
+    lat = denoise(am, inp["context"], inp["uc"], inp["relations"], batch, inp["x"].to(DEV), [0.3, 0.0, 0.7], 7.5, steps=S)
+    assert lat.shape == (B, 4, hw, hw) and model.first_conv_type == "SD"
+    torch.set_num_threads(min(32, max(1, os.cpu_count() or 1)))
+    z = torch.zeros_like
+    state = dict(sd=False)
+
+    def eps_fn(x, t, i, alpha):
+        if alpha == 0:
+            state["sd"] = True                       # permanent, like restore_first_conv_from_SD (openaimodel.py:393-411)
+        first = fc if state["sd"] else None
+        with torch.no_grad():
+            e_c = unet_ref.unet_forward(sd, cfg, x, t, inp["context"], inp["relations"], inp["boxes"], inp["masks"],
+                                        inp["positive_embeddings"], fuser_scale=float(alpha), first_conv=first)
+            e_u = unet_ref.unet_forward(sd, cfg, x, t, inp["uc"], inp["relations"], z(inp["boxes"]), z(inp["masks"]),
+                                        z(inp["positive_embeddings"]), fuser_scale=float(alpha), first_conv=first)
+        return e_u + 7.5 * (e_c - e_u)
+    ref = plms_ref.plms_sample(eps_fn, inp["x"], S, [0.3, 0.0, 0.7])
+    r = report("configs[0] B=1 S=10 final latent", lat.cpu(), ref)
+    assert r < 3.5e-3, r           # 22 chained evaluations; the 5-step full-size run measures 1.7e-3, the tiny 10-step golden 2.9e-3

@@ -66,3 +66,53 @@ def test_rank_outputs_equal_single_process_bitwise(tmp_path):
     k = list(both["idx"]).index(2)
     rel = np.linalg.norm(both["lat"][k] - solo[0]) / np.linalg.norm(solo[0])
     assert rel < 5e-3, rel
+
+
+def test_product_entry_two_ranks_equal_single_process_bitwise(tmp_path):
+    """The product-level 8-GPU mode on two ranks sharing one GPU: load_all_models_sharded (rank 0 alone reads the
+    checkpoint; UNet + VAE in ONE broadcast) -> generate_batch_images_sharded (round-robin prompts, per-prompt seeds, uint8
+    gather on rank 0).  The gathered images must equal, BITWISE, what this process computes for the same shards from its own
+    load of the same checkpoint -- nothing depends on the rank, and the broadcast is lossless."""
+    import stubs
+    import dist_product_worker as W
+    from layoutllm_t2i_amd import interface as itf
+    from layoutllm_t2i_amd.arch import TINY, VAE_TINY
+    from layoutllm_t2i_amd.dist import shard_indices
+    ckpt = str(tmp_path / "tiny_gligen.pth")
+    stubs.write_synthetic_checkpoint(ckpt, TINY, VAE_TINY, max_relations=10)
+    world, port = 2, _free_port()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_product_worker.py")
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, worker, ckpt, str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    res = []
+    try:
+        for p in procs:
+            out, err = p.communicate(timeout=600)
+            assert p.returncode == 0, err[-3000:]
+            res.append(json.loads(next(l for l in out.splitlines() if l.startswith("RESULT "))[7:]))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    a, b = sorted(res, key=lambda d: d["rank"])
+    assert a["ckpt_reads"] >= 1 and b["ckpt_reads"] == 0, "only rank 0 may read the checkpoint"
+    assert a["text_encoder"] and not b["text_encoder"] and a["n_images"] == len(W.PROMPTS) and b["n_images"] is None
+    got = np.load(tmp_path / "images.npz")["imgs"]
+    assert got.shape[0] == len(W.PROMPTS) and got.dtype == np.uint8 and got.shape[-1] == 3
+    # the same shards in THIS process
+    dev = "cuda:0"
+    stubs.install_fake_sng_parser()
+    am = itf.load_all_models(ckpt, dev)
+    cond = itf.prepare_conditioning(am, W.PROMPTS, W.PHRASES, W.BOXES, stubs.toy_clip().to(dev), stubs.ToyProcessor(), dev)
+    for r in range(world):
+        mine = shard_indices(len(W.PROMPTS), r, world)
+        ref = itf.run_shard(am, {k: v[mine] for k, v in cond.items()}, itf.prompt_noise([W.SEEDS[i] for i in mine], W.LATENT), dev,
+                            steps=W.STEPS)
+        assert np.array_equal(got[mine], ref), f"rank {r}: {np.abs(got[mine].astype(int) - ref.astype(int)).max()}"
+    # single-process call of the same entry: one batch of all prompts; per-prompt seeds keep every image close to its sharded twin
+    solo = itf.generate_batch_images_sharded(am, W.PROMPTS, W.PHRASES, W.BOXES, stubs.toy_clip().to(dev), stubs.ToyProcessor(), device=dev,
+                                             seeds=W.SEEDS, steps=W.STEPS, latent=W.LATENT)
+    solo = np.stack([np.asarray(im) for im in solo])
+    assert solo.shape == got.shape and np.mean(np.abs(solo.astype(int) - got.astype(int)) <= 3) > 0.97

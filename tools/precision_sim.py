@@ -3,6 +3,11 @@ rounding the RESIDUAL STREAM to fp16 at every add, and what floor remains when o
 fp16 (fp32 accumulate, fp32 residual stream).  Runs the oracle under a TorchFunctionMode that injects roundings.
 
     python tools/precision_sim.py [tiny|full32|full64]
+    python tools/precision_sim.py attribute [tiny|full32|full64]     per-op-class attribution of the fp16-operand floor:
+        operands (activations in, weights) are rounded to fp16 for ONE class of matrix products at a time -- 3x3 convs,
+        1x1 convs (proj_in / proj_out / skip), q|k|v projections, attention to_out, GEGLU projection, FF output projection,
+        Q.K^T, P.V (P and V rounded), small conditioning-side Linears -- everything else exact fp32; rel-L2^2 of the
+        classes adds up to the all-classes floor when the contributions are independent.
 """
 import os
 import sys
@@ -49,7 +54,83 @@ class Sim(TorchFunctionMode):
         return func(*args, **kwargs)
 
 
+CLASSES = ("conv3x3", "conv1x1", "qkv", "attn_out", "ff_in", "ff_out", "qk", "pv", "cond")
+
+
+def classify(name: str, w: torch.Tensor) -> str:
+    if w.dim() == 4:
+        return "conv3x3" if w.shape[-1] == 3 else "conv1x1"
+    if ".to_q." in name or ".to_k." in name or ".to_v." in name:
+        return "qkv"
+    if ".to_out." in name:
+        return "attn_out"
+    if ".net.0.proj." in name:
+        return "ff_in"
+    if ".net.2." in name:
+        return "ff_out"
+    return "cond"          # time_embed, emb_layers, position_net, fuser.linear
+
+
+class ClassSim(TorchFunctionMode):
+    """fp16 operand rounding for the enabled classes only (fp32 accumulate, fp32 everything else)."""
+
+    def __init__(self, wclass: dict, enabled):
+        super().__init__()
+        self.wclass, self.enabled, self.mm = wclass, set(enabled), 0
+
+    def __torch_function__(self, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func in (F.linear, F.conv2d):
+            if self.wclass.get(id(args[1]), "cond") in self.enabled:
+                a = list(args)
+                a[0], a[1] = h(a[0]), h(a[1])
+                return func(*a, **kwargs)
+            return func(*args, **kwargs)
+        if func is torch.matmul:
+            cls = "qk" if self.mm % 2 == 0 else "pv"      # oracle.attention: Q.K^T then P.V, strictly alternating
+            self.mm += 1
+            if cls in self.enabled:
+                return func(h(args[0]), h(args[1]))
+            return func(*args, **kwargs)
+        return func(*args, **kwargs)
+
+
+def attribute(which):
+    torch.set_num_threads(8)
+    if which == "tiny":
+        import numpy as np
+        cfg, hw = TINY, 16
+        sd = {k: torch.from_numpy(np.asarray(v)).float() for k, v in recipe.state_dict(cfg, 0).items()}
+    else:
+        cfg, hw = UNetConfig(), int(which[4:])
+        sd = random_state_dict(cfg, torch.device("cpu"), seed=3)
+    sd = {k: (v.half().float() if v.dim() >= 2 else v) for k, v in sd.items()}
+    wclass = {id(v): classify(k, v) for k, v in sd.items() if k.endswith(".weight") and v.dim() >= 2}
+    inp = {k: torch.from_numpy(v) for k, v in recipe.synth_inputs(cfg, 1, hw, n_boxes=8, n_rel=3, seed=4321).items()}
+    t = torch.full((1,), 481, dtype=torch.long)
+    args = (sd, cfg, inp["x"].half().float(), t, inp["context"].half().float(), inp["relations"].half().float(), inp["boxes"], inp["masks"],
+            inp["positive_embeddings"])
+    with torch.no_grad():
+        ref = unet_ref.unet_forward(*args)
+        tol = 1e-4 + 1e-3 * ref.abs()
+        rows = []
+        for name, en in [("ALL classes", CLASSES)] + [(c, (c,)) for c in CLASSES] + [("all but qk+pv", [c for c in CLASSES if c not in ("qk", "pv")]),
+                                                                                     ("all but conv3x3", [c for c in CLASSES if c != "conv3x3"])]:
+            t0 = time.time()
+            with ClassSim(wclass, en):
+                out = unet_ref.unet_forward(*args)
+            d = out - ref
+            r = float(d.norm() / ref.norm())
+            rows.append((name, r))
+            print(f"{name:18s} rel_l2={r:.3e}  rel_l2^2 share={r * r / (rows[0][1] ** 2) * 100:5.1f}%  max|err|={float(d.abs().max()):.3e} "
+                  f"outside rtol1e-3/atol1e-4: {float((d.abs() > tol).float().mean()) * 100:5.1f}%   ({time.time() - t0:.0f}s)", flush=True)
+        s2 = sum(r * r for n, r in rows[1:1 + len(CLASSES)])
+        print(f"sum of single-class rel_l2^2 = {s2:.3e} vs all-classes {rows[0][1] ** 2:.3e} (ratio {s2 / rows[0][1] ** 2:.2f})")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "attribute":
+        return attribute(sys.argv[2] if len(sys.argv) > 2 else "tiny")
     which = sys.argv[1] if len(sys.argv) > 1 else "tiny"
     torch.set_num_threads(8)
     if which == "tiny":
