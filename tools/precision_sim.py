@@ -5,7 +5,7 @@ fp16 (fp32 accumulate, fp32 residual stream).  Runs the oracle under a TorchFunc
     python tools/precision_sim.py [tiny|full32|full64]
     python tools/precision_sim.py attribute [tiny|full32|full64]     per-op-class attribution of the fp16-operand floor:
         operands (activations in, weights) are rounded to fp16 for ONE class of matrix products at a time -- 3x3 convs,
-        1x1 convs (proj_in / proj_out / skip), q|k|v projections, attention to_out, GEGLU projection, FF output projection,
+        the three kinds of 1x1 conv (proj_in, proj_out, ResBlock skip), q|k|v projections, attention to_out, GEGLU projection, FF output projection,
         Q.K^T, P.V (P and V rounded), small conditioning-side Linears -- everything else exact fp32; rel-L2^2 of the
         classes adds up to the all-classes floor when the contributions are independent.
 """
@@ -54,12 +54,14 @@ class Sim(TorchFunctionMode):
         return func(*args, **kwargs)
 
 
-CLASSES = ("conv3x3", "conv1x1", "qkv", "attn_out", "ff_in", "ff_out", "qk", "pv", "cond")
+CLASSES = ("conv3x3", "proj_in", "proj_out", "skip1x1", "qkv", "attn_out", "ff_in", "ff_out", "qk", "pv", "cond")
 
 
 def classify(name: str, w: torch.Tensor) -> str:
     if w.dim() == 4:
-        return "conv3x3" if w.shape[-1] == 3 else "conv1x1"
+        if w.shape[-1] == 3:
+            return "conv3x3"
+        return "proj_in" if ".proj_in." in name else "proj_out" if ".proj_out." in name else "skip1x1"
     if ".to_q." in name or ".to_k." in name or ".to_v." in name:
         return "qkv"
     if ".to_out." in name:
@@ -114,8 +116,8 @@ def attribute(which):
         ref = unet_ref.unet_forward(*args)
         tol = 1e-4 + 1e-3 * ref.abs()
         rows = []
-        for name, en in [("ALL classes", CLASSES)] + [(c, (c,)) for c in CLASSES] + [("all but qk+pv", [c for c in CLASSES if c not in ("qk", "pv")]),
-                                                                                     ("all but conv3x3", [c for c in CLASSES if c != "conv3x3"])]:
+        for name, en in [("ALL classes", CLASSES)] + [(c, (c,)) for c in CLASSES] + [("all but proj_out", [c for c in CLASSES if c != "proj_out"]),
+                                                                                     ("all but 1x1 convs", [c for c in CLASSES if c not in ("proj_in", "proj_out", "skip1x1")])]:
             t0 = time.time()
             with ClassSim(wclass, en):
                 out = unet_ref.unet_forward(*args)
