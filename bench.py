@@ -42,6 +42,35 @@ MFMA_PEAK_TFLOPS = 2500.0
 CONFIGS = {2: (1, 4, 64, 8), 3: (2, 2, 96, 16), 4: (3, 8, 64, 8), 5: (4, 16, 64, 8)}
 
 
+def random_clip_vit_l14_state_dict(dev, gen):
+    """Random-init weights with transformers.CLIPModel's key names and openai/clip-vit-large-patch14's shapes (vision 24 x 1024 /
+    16 heads / 4096, 257 positions; text 12 x 768 / 12 heads / 3072, 77 positions, vocab 49408; projection 768)."""
+    sd = {}
+    r = lambda *s_: torch.randn(*s_, device=dev, generator=gen)
+
+    def tower(prefix, n, c, inter):
+        for i in range(n):
+            p = f"{prefix}.encoder.layers.{i}"
+            for ln in ("layer_norm1", "layer_norm2"):
+                sd[f"{p}.{ln}.weight"], sd[f"{p}.{ln}.bias"] = 1 + 0.1 * r(c), 0.05 * r(c)
+            for w in ("q_proj", "k_proj", "v_proj", "out_proj"):
+                sd[f"{p}.self_attn.{w}.weight"], sd[f"{p}.self_attn.{w}.bias"] = r(c, c) * (0.7 / c ** 0.5), 0.02 * r(c)
+            sd[f"{p}.mlp.fc1.weight"], sd[f"{p}.mlp.fc1.bias"] = r(inter, c) / c ** 0.5, 0.02 * r(inter)
+            sd[f"{p}.mlp.fc2.weight"], sd[f"{p}.mlp.fc2.bias"] = r(c, inter) * (0.5 / inter ** 0.5), 0.02 * r(c)
+    tower("vision_model", 24, 1024, 4096)
+    tower("text_model", 12, 768, 3072)
+    sd["vision_model.embeddings.patch_embedding.weight"] = r(1024, 3, 14, 14) / 588 ** 0.5
+    sd["vision_model.embeddings.class_embedding"] = r(1024)
+    sd["vision_model.embeddings.position_embedding.weight"] = 0.3 * r(257, 1024)
+    for ln, c in (("vision_model.pre_layrnorm", 1024), ("vision_model.post_layernorm", 1024), ("text_model.final_layer_norm", 768)):
+        sd[ln + ".weight"], sd[ln + ".bias"] = 1 + 0.1 * r(c), 0.05 * r(c)
+    sd["visual_projection.weight"] = r(768, 1024) / 32.0
+    sd["text_model.embeddings.token_embedding.weight"] = 0.5 * r(49408, 768)
+    sd["text_model.embeddings.position_embedding.weight"] = 0.3 * r(77, 768)
+    sd["text_projection.weight"] = r(768, 768) / 768 ** 0.5
+    return sd
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -173,12 +202,14 @@ def main():
     eng.plms_step = timed_step
 
     vae_events = []
-    # configs[4] (train_rl rollout): the reward-scoring stage runs after the decode.  The CLIP towers that turn decoded
-    # images / captions into features are the caller's modules (HF CLIPModel), so the stage is fed synthetic CLIP features
-    # [B, 768] resident on the device; what is timed is this repo's part (similarities + AestheticMLP, gl_reward_score).
+    # configs[4] (train_rl rollout): the reward stage runs after the decode, as Reward_Model.forward does (models/policy.py:106-135):
+    # decoded images -> uint8 -> the HF CLIP image processor on the HOST (PIL bicubic resize 512 -> 224, crop, normalise: the
+    # reference's own CPU step) -> CLIP ViT-L/14 vision tower (HIP) on the 16 predictions and the 16 ground-truth images, text tower
+    # (HIP) on the 16 captions -> similarities + AestheticMLP (gl_reward_score).  Random-init towers of the ViT-L/14 architecture.
     scorer, score_events, score_in = None, [], None
+    reward_stage_ms = {"processor_cpu": [], "clip_towers": [], "score": []}
     if cnum == 5 and not args.tiny:
-        from layoutllm_t2i_amd.reward import RewardScorer
+        from layoutllm_t2i_amd.reward import RewardModel
         gsc = torch.Generator(device=dev)
         gsc.manual_seed(4242 + rank)
         shp = {0: (1024, 768), 2: (128, 1024), 4: (64, 128), 6: (16, 64), 7: (1, 16)}
@@ -186,8 +217,20 @@ def main():
         for li, (n_, k_) in shp.items():
             aes_sd[f"layers.{li}.weight"] = (torch.rand(n_, k_, device=dev, generator=gsc) * 2 - 1) * (3.0 / k_) ** 0.5
             aes_sd[f"layers.{li}.bias"] = (torch.rand(n_, device=dev, generator=gsc) * 2 - 1) * 0.1
-        scorer = RewardScorer(aes_sd, dev)
-        score_in = tuple(torch.randn(B, 768, device=dev, generator=gsc) for _ in range(3))
+        scorer = RewardModel(random_clip_vit_l14_state_dict(dev, gsc), aes_sd, dev)
+        try:
+            from transformers import CLIPImageProcessor
+            processor = CLIPImageProcessor()
+        except Exception as e:                                   # pragma: no cover
+            raise SystemExit(f"--config 5 needs transformers' CLIPImageProcessor for the host-side preprocessing step: {e}")
+        gt_pixels = torch.randn(B, 3, 224, 224, device=dev, generator=gsc)              # processed ground-truth images
+        cap_ids = torch.randint(1, 49406, (B, 77), device=dev, generator=gsc)
+        cap_ids[:, 0] = 49406
+        for b_ in range(B):
+            L_ = 8 + (b_ * 5) % 40
+            cap_ids[b_, L_] = 49407
+            cap_ids[b_, L_ + 1:] = 49407
+        score_in = (cap_ids, gt_pixels, processor)
 
     def one_step():
         model.first_conv_type = "GLIGEN"
@@ -201,12 +244,22 @@ def main():
         e1.record()
         vae_events.append((e0, e1))
         if scorer is not None:
-            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            cap_ids, gt_pixels, processor = score_in
+            torch.cuda.synchronize()        # (the .cpu() below would wait for the queued denoise + decode anyway; keep it out of the host timer)
+            tc = time.time()
+            u8 = ((torch.clamp(img, -1, 1) * 0.5 + 0.5).cpu().numpy().transpose(0, 2, 3, 1) * 255).astype("uint8")     # interface.py:543-547
+            px = processor(images=[u for u in u8], return_tensors="pt")["pixel_values"].to(dev)
+            reward_stage_ms["processor_cpu"].append((time.time() - tc) * 1e3)
+            s0, s1, s2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
             s0.record()
-            sc = scorer.score(*score_in)
+            txt = scorer.towers.get_text_features(cap_ids)
+            fp = scorer.towers.get_image_features(px)
+            fg = scorer.towers.get_image_features(gt_pixels)
             s1.record()
-            score_events.append((s0, s1))
-            assert sc["reward"].shape == (B,)
+            sc = scorer.scorer.score(txt, fp, fg)
+            s2.record()
+            score_events.append((s0, s1, s2))
+            assert sc["reward"].shape == (B,) and bool(torch.isfinite(sc["reward"]).all())
         return img
 
     def sync():
@@ -296,9 +349,14 @@ def main():
         "step_includes": f"PLMS denoise ({args.plms_steps + 1} x gl_plms_step: 2B UNet forward + CFG + update)" + (" + VAE decode to fp32 images" if vae is not None else "") + (" + reward scoring (gl_reward_score)" if scorer is not None else ""),
         "launches_per_forward": eng.num_launches(),
         "images_per_sec_per_gpu": round(value / world, 4),
-        "reward_score_ms_per_batch": (round(sum(a.elapsed_time(b) for a, b in score_events) / max(len(score_events), 1), 4) if score_events else None),
-        "reward_score_note": ("similarities + AestheticMLP (gl_reward_score) on synthetic CLIP features [B, 768]; the CLIP towers and the CPU "
-                              "layout rewards (IoU / DocSim) are the caller's and not timed" if score_events else None),
+        "reward_score_ms_per_batch": (round(sum(a.elapsed_time(c) for a, b, c in score_events) / max(len(score_events), 1), 3) if score_events else None),
+        "reward_stage_ms": ({"clip_towers(text 16 + vision 2x16, HIP)": round(sum(a.elapsed_time(b) for a, b, c in score_events) / len(score_events), 3),
+                             "similarities+aesthetic (gl_reward_score)": round(sum(b.elapsed_time(c) for a, b, c in score_events) / len(score_events), 3),
+                             "image processor (host CPU, PIL, as the reference)": round(sum(reward_stage_ms["processor_cpu"][-len(score_events):]) / len(score_events), 1)}
+                            if score_events else None),
+        "reward_score_note": ("Reward_Model.forward's GPU part on the decoded images: host image processor -> CLIP ViT-L/14 towers (random-init, "
+                              "HIP) on 16 predictions + 16 ground-truth images + 16 captions -> similarities + AestheticMLP; the CPU layout "
+                              "rewards (IoU / DocSim, policy.py:126-133) are the caller's and not timed" if score_events else None),
         "roofline": roofline,
         "setup_s": round(setup_s, 1),
     }

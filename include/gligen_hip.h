@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GL_ABI_VERSION 8
+#define GL_ABI_VERSION 9
 
 /* error codes (negative; positive values are hipError_t) */
 #define GL_ERR_BAD_ARG (-1)
@@ -341,6 +341,30 @@ int gl_sizeof_reward_args(void);
 int gl_gemm(const gl_gemm_args* a, void* stream);
 int gl_conv3x3(const gl_conv_args* a, void* stream);
 int gl_attention(const gl_attn_args* a, void* stream);
+
+/*
+ * CLIP towers of the reward stage: transformers.CLIPModel.get_image_features / get_text_features as the
+ * reference's Reward_Model calls them (models/policy.py:106-113).  Projections / MLPs / LayerNorms / the vision tower's
+ * attention run on gl_gemm / gl_layernorm / gl_attention; these are the tower-specific pieces.
+ *   gl_clip_patchify      CLIPVisionEmbeddings.patch_embedding as a GEMM operand: pixel_values fp32 [B, 3, S, S] -> fp16
+ *                         [B * (S/patch)^2, Kpad], K index (c * patch + i) * patch + j, zero-padded to Kpad (% 64 == 0)
+ *   gl_clip_assemble      x[b, 0] = class_embedding, x[b, 1 + p] = patch_emb[b * (T-1) + p]; x += position_embedding; then, when
+ *                         ln_gamma != NULL, x = LayerNorm(x) in fp32 (the vision tower's pre_layrnorm, whose OUTPUT is the start of
+ *                         the fp32 residual stream); fp32 [B, T, C], C <= 4096
+ *   gl_clip_embed_tokens  CLIPTextEmbeddings: x[b, t] = token_embedding[ids[b, t]] + position_embedding[t]; fp32 [B, T, C]
+ *   gl_clip_gather_rows   out[b] = x[rows[b]]   (class-token rows / EOS rows = input_ids.argmax(-1)), fp32
+ *   gl_attention_small    softmax(scale * q k^T [+ causal mask]) v for T <= 128, d <= 64; q / k / v fp16 rows of stride ld with head
+ *                         h at column h * d (e.g. the three column blocks of a fused q|k|v projection), fp32 arithmetic;
+ *                         the text tower's causal attention (create_causal_mask, CLIPTextModel.forward)
+ */
+int gl_clip_patchify(const float* pixel_values, int32_t B, int32_t S, int32_t patch, int32_t Kpad, void* out, void* stream);
+int gl_clip_assemble(const void* patch_emb, int32_t ldpe, const float* class_emb, const float* pos_emb, int32_t B, int32_t T,
+                     int32_t C, const float* ln_gamma, const float* ln_beta, float ln_eps, float* x, void* stream);
+int gl_clip_embed_tokens(const int32_t* ids, const float* tok_emb, const float* pos_emb, int32_t B, int32_t T, int32_t C,
+                         int32_t vocab, float* x, void* stream);
+int gl_clip_gather_rows(const float* x, int32_t ldx, const int32_t* rows, int32_t B, int32_t C, float* out, void* stream);
+int gl_attention_small(const void* q, const void* k, const void* v, int32_t ld, int32_t B, int32_t T, int32_t H, int32_t d,
+                       float scale, int32_t causal, void* out, int32_t ldo, void* stream);
 
 /* introspection: ABI version and struct sizes (checked by the host loader) */
 int gl_abi_version(void);

@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgligen_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 # enum gl_epilogue / gl_out_mode
 EPI_BIAS, EPI_SILU, EPI_GEGLU, EPI_RES, EPI_GATE_RES, EPI_ROWBIAS = range(6)
@@ -158,6 +158,11 @@ PROTOTYPES = {
     "gl_sizeof_ff_args": (i32, []),
     "gl_set_option": (i32, [i32, i32]),
     "gl_debug_read": (i32, [i32, vp, i64]),
+    "gl_clip_patchify": (i32, [fp, i32, i32, i32, i32, vp, vp]),
+    "gl_clip_assemble": (i32, [vp, i32, fp, fp, i32, i32, i32, fp, fp, f32, fp, vp]),
+    "gl_clip_embed_tokens": (i32, [vp, fp, fp, i32, i32, i32, i32, fp, vp]),
+    "gl_clip_gather_rows": (i32, [fp, i32, vp, i32, i32, fp, vp]),
+    "gl_attention_small": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp, i32, vp]),
 }
 
 _lib = None

@@ -424,3 +424,56 @@ def latent_affine_pack(z: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, pre
 def set_option(key: int, value: int) -> None:
     """Tuning knob for A/B measurements (see gl_set_option in include/gligen_hip.h)."""
     check(_lib.lib().gl_set_option(key, value), "gl_set_option")
+
+
+# ------------------------------------------------------------------------------------------- CLIP towers (reward stage)
+def clip_patchify(pixel_values: torch.Tensor, patch: int, Kpad: int, out: torch.Tensor) -> torch.Tensor:
+    """pixel_values fp32 [B, 3, S, S] -> fp16 [B * (S/patch)^2, Kpad] patch rows (K index (c, i, j), zero-padded)."""
+    _req(pixel_values, F32, "pixel_values")
+    _req(out, F16, "out")
+    B, c3, S, S2 = pixel_values.shape
+    if c3 != 3 or S != S2 or not pixel_values.is_contiguous():
+        raise ValueError("pixel_values must be a contiguous [B, 3, S, S] tensor")
+    check(_lib.lib().gl_clip_patchify(pixel_values.data_ptr(), B, S, patch, Kpad, out.data_ptr(), _stream()), "gl_clip_patchify")
+    return out
+
+
+def clip_assemble(patch_emb: torch.Tensor, class_emb: torch.Tensor, pos_emb: torch.Tensor, B: int, T: int, x: torch.Tensor,
+                  ln_gamma: Optional[torch.Tensor] = None, ln_beta: Optional[torch.Tensor] = None, eps: float = 1e-5) -> torch.Tensor:
+    _req(patch_emb, F16, "patch_emb")
+    for t, n in ((class_emb, "class_emb"), (pos_emb, "pos_emb"), (x, "x")):
+        _req(t, F32, n)
+    C_ = x.shape[-1]
+    check(_lib.lib().gl_clip_assemble(patch_emb.data_ptr(), _rows(patch_emb, "patch_emb")[2], class_emb.data_ptr(), pos_emb.data_ptr(), B, T, C_,
+                                      _ptr(ln_gamma), _ptr(ln_beta), eps, x.data_ptr(), _stream()), "gl_clip_assemble")
+    return x
+
+
+def clip_embed_tokens(ids: torch.Tensor, tok_emb: torch.Tensor, pos_emb: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    _req(ids, torch.int32, "ids", 4)
+    for t, n in ((tok_emb, "tok_emb"), (pos_emb, "pos_emb"), (x, "x")):
+        _req(t, F32, n)
+    B, T = ids.shape
+    check(_lib.lib().gl_clip_embed_tokens(ids.data_ptr(), tok_emb.data_ptr(), pos_emb.data_ptr(), B, T, x.shape[-1], tok_emb.shape[0],
+                                          x.data_ptr(), _stream()), "gl_clip_embed_tokens")
+    return x
+
+
+def clip_gather_rows(x: torch.Tensor, rows: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    _req(x, F32, "x")
+    _req(rows, torch.int32, "rows", 4)
+    _req(out, F32, "out")
+    check(_lib.lib().gl_clip_gather_rows(x.data_ptr(), _rows(x, "x")[2], rows.data_ptr(), rows.numel(), x.shape[-1], out.data_ptr(), _stream()),
+          "gl_clip_gather_rows")
+    return out
+
+
+def attention_small(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, ld: int, B: int, T: int, H: int, d: int, scale: float,
+                    causal: bool, out: torch.Tensor) -> torch.Tensor:
+    """q / k / v: fp16 views whose element (b, t, h*d + c) sits at data_ptr + (b*T + t)*ld + h*d + c; out fp16 [B*T, H*d]."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        _req(t, F16, n, 2)
+    _req(out, F16, "out", 2)
+    check(_lib.lib().gl_attention_small(q.data_ptr(), k.data_ptr(), v.data_ptr(), ld, B, T, H, d, scale, int(causal), out.data_ptr(),
+                                        _rows(out, "out")[2], _stream()), "gl_attention_small")
+    return out

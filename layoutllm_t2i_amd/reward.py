@@ -4,8 +4,9 @@ Mirrors the GPU part of ``Reward_Model.forward`` (models/policy.py:106-135): CLI
 similarities and the AestheticMLP score (tools/aesthetic.py:15-31) run in ONE HIP kernel (``gl_reward_score``) on the
 CLIP features of the rollout batch; ``reward = clip + 0.1 * aes + 10 * mIoU + 10 * DocSim`` (policy.py:135) is finished
 on the host with the layout terms the reference computes in CPU python (``compute_maximum_iou`` / ``compute_docsim``),
-which are passed in.  The CLIP towers that produce the features are the caller's modules (HF ``CLIPModel``), exactly as
-``all_models``' text encoder is for the denoiser.
+which are passed in.  ``RewardModel`` adds the CLIP towers (``clip.ClipTowers``: get_text_features / get_image_features of
+the reference's transformers.CLIPModel on the HIP kernels), i.e. the whole GPU part of ``Reward_Model.forward``; the
+tokenizer and the image processor (PIL resize / crop / normalise) stay the caller's CPU objects, as in the reference.
 """
 from __future__ import annotations
 
@@ -66,3 +67,28 @@ class RewardScorer:
         if laysim is not None:
             reward = reward + f(laysim) * 10
         return dict(sims_ti=out[0], sims_ii=out[1], clip_reward=out[0] + out[1], aes_reward=out[2], reward=reward)
+
+
+class RewardModel:
+    """GPU part of ``Reward_Model.forward`` (models/policy.py:106-124,135): CLIP text / image features -> cosine
+    similarities + aesthetic score -> reward.  ``clip_state_dict`` = ``transformers.CLIPModel.state_dict()`` of the model
+    policy.py:40 loads, ``aesthetic_state_dict`` = the AestheticMLP checkpoint (policy.py:44-46)."""
+
+    def __init__(self, clip_state_dict, aesthetic_state_dict, device="cuda:0", vision_heads: int = 16, text_heads: int = 12):
+        from .clip import ClipTowers
+        self.towers = ClipTowers(clip_state_dict, vision_heads, text_heads, device)
+        self.scorer = RewardScorer(aesthetic_state_dict, device, input_size=int(self.towers.vproj.shape[0]))
+        self.device = self.towers.device
+
+    @torch.no_grad()
+    def forward(self, input_ids, pixel_values_pred, pixel_values_gt, attention_mask=None, miou=None, laysim=None) -> dict:
+        """``input_ids`` [B, T] (tokenizer output), ``pixel_values_*`` [B, 3, S, S] (processor output); returns the dict of
+        RewardScorer.score plus the three feature tensors."""
+        txt = self.towers.get_text_features(input_ids, attention_mask)
+        pred = self.towers.get_image_features(pixel_values_pred)
+        gt = self.towers.get_image_features(pixel_values_gt)
+        out = self.scorer.score(txt, pred, gt, miou, laysim)
+        out.update(txt_features=txt, img_pred_features=pred, img_gt_features=gt)
+        return out
+
+    __call__ = forward

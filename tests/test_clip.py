@@ -1,0 +1,128 @@
+"""CLIP towers of the reward stage.  CPU: the oracle (oracle/clip_ref.py) against outputs of transformers' own
+CLIPModel on a small random-init config (tests/golden/clip_tiny.npz, tools/make_clip_goldens.py).  GPU: the HIP towers
+(layoutllm_t2i_amd/clip.py) against that golden and, at ViT-L/14 layer sizes, against the oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(__file__))
+from layoutllm_t2i_amd import recipe
+from oracle import clip_ref
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "clip_tiny.npz")
+T = torch.from_numpy
+
+
+def golden():
+    z = np.load(GOLD)
+    sd = {k[2:]: T(z[k]) for k in z.files if k.startswith("w:")}
+    return z, sd
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / b.norm())
+
+
+def test_oracle_matches_transformers_clip_golden():
+    z, sd = golden()
+    heads = int(z["heads"])
+    with torch.no_grad():
+        img = clip_ref.image_features(sd, T(z["pixel_values"]), heads)
+        txt = clip_ref.text_features(sd, T(z["input_ids"]), heads)
+    assert img.shape == z["image_features"].shape and txt.shape == z["text_features"].shape
+    assert float(np.abs(img.numpy() - z["image_features"]).max()) < 5e-5 * float(np.abs(z["image_features"]).max())
+    assert float(np.abs(txt.numpy() - z["text_features"]).max()) < 5e-5 * float(np.abs(z["text_features"]).max())
+
+
+def test_oracle_text_pooling_ignores_right_padding():
+    """the pooled row (EOS = largest id) is causal: tokens after it, whatever they are, cannot change it"""
+    z, sd = golden()
+    ids = T(z["input_ids"]).clone()
+    base = clip_ref.text_features(sd, ids, int(z["heads"]))
+    eos = ids.argmax(-1)
+    for b in range(ids.shape[0]):
+        ids[b, int(eos[b]) + 1:] = 5
+    assert torch.allclose(clip_ref.text_features(sd, ids, int(z["heads"])), base, atol=1e-6)
+
+
+def vit_l_like_sd(layers_v=2, layers_t=2, seed=0):
+    """ViT-L/14 layer SIZES (vision 1024 / 16 heads / 4096, 257 tokens; text 768 / 12 heads / 3072, 77 positions; projection
+    768) with few layers and recipe weights scaled like a trained model (LN gains ~1, projections ~1/sqrt(fan_in))."""
+    sd = {}
+
+    def lin(name, n, k, bias=True, scale=1.0):
+        sd[name + ".weight"] = T(recipe.normal(name + ".w", (n, k), seed)) * (scale / np.sqrt(k))
+        if bias:
+            sd[name + ".bias"] = T(recipe.normal(name + ".b", (n,), seed)) * 0.1
+
+    def ln(name, c):
+        sd[name + ".weight"] = 1.0 + 0.2 * T(recipe.normal(name + ".g", (c,), seed))
+        sd[name + ".bias"] = 0.1 * T(recipe.normal(name + ".b", (c,), seed))
+
+    def tower(prefix, n, c, inter):
+        for i in range(n):
+            p = f"{prefix}.encoder.layers.{i}"
+            ln(p + ".layer_norm1", c)
+            ln(p + ".layer_norm2", c)
+            for w in "qkv":
+                lin(p + f".self_attn.{w}_proj", c, c)
+            lin(p + ".self_attn.out_proj", c, c, scale=0.5)
+            lin(p + ".mlp.fc1", inter, c)
+            lin(p + ".mlp.fc2", c, inter, scale=0.5)
+    tower("vision_model", layers_v, 1024, 4096)
+    tower("text_model", layers_t, 768, 3072)
+    sd["vision_model.embeddings.patch_embedding.weight"] = T(recipe.normal("pe.w", (1024, 3, 14, 14), seed)) * (1.0 / np.sqrt(588))
+    sd["vision_model.embeddings.class_embedding"] = T(recipe.normal("cls", (1024,), seed))
+    sd["vision_model.embeddings.position_embedding.weight"] = T(recipe.normal("vpos", (257, 1024), seed)) * 0.5
+    ln("vision_model.pre_layrnorm", 1024)
+    ln("vision_model.post_layernorm", 1024)
+    lin("visual_projection", 768, 1024, bias=False)
+    sd["text_model.embeddings.token_embedding.weight"] = T(recipe.normal("tok", (1000, 768), seed))
+    sd["text_model.embeddings.position_embedding.weight"] = T(recipe.normal("tpos", (77, 768), seed)) * 0.5
+    ln("text_model.final_layer_norm", 768)
+    lin("text_projection", 768, 768, bias=False)
+    return sd
+
+
+@pytest.mark.gpu
+def test_hip_towers_match_transformers_golden():
+    from layoutllm_t2i_amd.clip import ClipTowers
+    z, sd = golden()
+    heads = int(z["heads"])
+    tw = ClipTowers(sd, vision_heads=heads, text_heads=heads)
+    img = tw.get_image_features(T(z["pixel_values"]))
+    txt = tw.get_text_features(T(z["input_ids"]), attention_mask=(T(z["input_ids"]) != 1).long())
+    ri, rt = rel(img, T(z["image_features"])), rel(txt, T(z["text_features"]))
+    print(f"[clip_tiny vs transformers] image rel_l2={ri:.3e} text rel_l2={rt:.3e}")
+    assert img.shape == z["image_features"].shape and txt.dtype == torch.float32
+    assert ri < 3e-3 and rt < 3e-3, (ri, rt)            # fp16 matrix operands incl. fp16-rounded weights, fp32 stream
+
+
+@pytest.mark.gpu
+def test_hip_towers_at_vit_l14_sizes_vs_oracle():
+    """257 vision tokens x 1024 x 16 heads (d = 64) and 77 causal text tokens x 768 x 12 heads, ragged batch sizes; oracle
+    on the fp16-rounded weights (isolates arithmetic from weight quantisation)."""
+    from layoutllm_t2i_amd.clip import ClipTowers
+    sd = vit_l_like_sd()
+    sdh = {k: (v.half().float() if v.dim() >= 2 else v) for k, v in sd.items()}
+    tw = ClipTowers(sd)
+    px = T(recipe.normal("px", (3, 3, 224, 224), 1))
+    ids = torch.randint(1, 998, (5, 77), generator=torch.Generator().manual_seed(3))
+    for b, L in enumerate((76, 10, 33, 5, 50)):
+        ids[b, L] = 999
+        ids[b, L + 1:] = 0
+    img, txt = tw.get_image_features(px), tw.get_text_features(ids)
+    torch.set_num_threads(min(32, max(1, os.cpu_count() or 1)))
+    with torch.no_grad():
+        ri = rel(img, clip_ref.image_features(sdh, px.half().float(), 16))
+        rt = rel(txt, clip_ref.text_features(sdh, ids, 12))
+    print(f"[ViT-L/14-size layers vs oracle] image rel_l2={ri:.3e} text rel_l2={rt:.3e}")
+    assert img.shape == (3, 768) and txt.shape == (5, 768)
+    assert ri < 2e-3 and rt < 2e-3, (ri, rt)
+    # deterministic, and a sample does not depend on its batch neighbours
+    assert torch.equal(img, tw.get_image_features(px))
+    assert rel(tw.get_image_features(px[1:2]), img[1:2]) < 1e-3
