@@ -343,6 +343,38 @@ int gl_conv3x3(const gl_conv_args* a, void* stream);
 int gl_attention(const gl_attn_args* a, void* stream);
 
 /*
+ * VAE decode stage behind a forward-level handle: AutoencoderKL.decode (GLIGEN/ldm/models/autoencoder.py:40-44)
+ * = Decoder.forward (GLIGEN/ldm/modules/diffusionmodules/model.py:535-568) on z / scale_factor after post_quant_conv.
+ * Same contract as the UNet handle: gl_vae_create builds the plan and the LIBRARY-DEFINED flat weight layout (no GPU needed;
+ * gl_vae_num_weights / gl_vae_weight_at / gl_vae_weights_bytes; packed forms: 3x3 convs fp16 [Cout, Cin/64, 3, 3, 64] with the
+ * latent's channels zero-padded to 64, 1x1 convs fp16 [N, K] with C^-0.5 folded into mid.attn_1.q, norm affine / biases /
+ * post_quant_conv fp32), gl_vae_load_weights references a DEVICE buffer in that layout (the caller keeps it alive),
+ * gl_vae_decode runs z fp32 [B, z_channels, side, side] -> out fp32 [B, out_ch, side * 2^(n_mult-1), ...] (device pointers),
+ * as one hipGraph per (B, side) when use_graph != 0.  One handle per device per thread.
+ */
+typedef struct gl_vae_config {
+    int32_t ch;                  /* ddconfig.ch (128) */
+    int32_t ch_mult[8];          /* ddconfig.ch_mult (1, 2, 4, 4) */
+    int32_t n_mult;              /* len(ch_mult) */
+    int32_t num_res_blocks;      /* ddconfig.num_res_blocks (2) */
+    int32_t z_channels;          /* 4 */
+    int32_t out_ch;              /* 3 */
+    int32_t embed_dim;           /* 4 (post_quant_conv input channels) */
+    float scale_factor;          /* 0.18215 */
+} gl_vae_config;
+typedef struct gl_vae gl_vae;
+int gl_vae_create(const gl_vae_config* cfg, gl_vae** out);
+int gl_vae_destroy(gl_vae* v);
+int gl_vae_num_weights(const gl_vae* v);
+int gl_vae_weight_at(const gl_vae* v, int32_t i, gl_weight_info* info);
+int64_t gl_vae_weights_bytes(const gl_vae* v);
+int gl_vae_load_weights(gl_vae* v, const void* packed, int64_t bytes, void* stream);
+int gl_vae_decode(gl_vae* v, const float* z, int32_t B, int32_t side, float* out, int32_t use_graph, void* stream);
+int gl_vae_num_launches(const gl_vae* v);
+int64_t gl_vae_pool_bytes(const gl_vae* v);
+int gl_sizeof_vae_config(void);
+
+/*
  * CLIP towers of the reward stage: transformers.CLIPModel.get_image_features / get_text_features as the
  * reference's Reward_Model calls them (models/policy.py:106-113).  Projections / MLPs / LayerNorms / the vision tower's
  * attention run on gl_gemm / gl_layernorm / gl_attention; these are the tower-specific pieces.

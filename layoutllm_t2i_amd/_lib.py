@@ -85,6 +85,12 @@ class WeightInfo(C.Structure):
     _fields_ = [("name", C.c_char * 160), ("offset", i64), ("nbytes", i64), ("dtype", i32), ("ndim", i32), ("shape", i64 * 4)]
 
 
+class VaeConfigC(C.Structure):
+    """gl_vae_config"""
+    _fields_ = [("ch", i32), ("ch_mult", i32 * 8), ("n_mult", i32), ("num_res_blocks", i32), ("z_channels", i32), ("out_ch", i32),
+                ("embed_dim", i32), ("scale_factor", f32)]
+
+
 class PlmsStepArgs(C.Structure):
     """gl_plms_step_args"""
     _fields_ = [
@@ -158,6 +164,16 @@ PROTOTYPES = {
     "gl_sizeof_ff_args": (i32, []),
     "gl_set_option": (i32, [i32, i32]),
     "gl_debug_read": (i32, [i32, vp, i64]),
+    "gl_vae_create": (i32, [C.POINTER(VaeConfigC), C.POINTER(vp)]),
+    "gl_vae_destroy": (i32, [vp]),
+    "gl_vae_num_weights": (i32, [vp]),
+    "gl_vae_weight_at": (i32, [vp, i32, C.POINTER(WeightInfo)]),
+    "gl_vae_weights_bytes": (i64, [vp]),
+    "gl_vae_load_weights": (i32, [vp, vp, i64, vp]),
+    "gl_vae_decode": (i32, [vp, fp, i32, i32, fp, i32, vp]),
+    "gl_vae_num_launches": (i32, [vp]),
+    "gl_vae_pool_bytes": (i64, [vp]),
+    "gl_sizeof_vae_config": (i32, []),
     "gl_clip_patchify": (i32, [fp, i32, i32, i32, i32, vp, vp]),
     "gl_clip_assemble": (i32, [vp, i32, fp, fp, i32, i32, i32, fp, fp, f32, fp, vp]),
     "gl_clip_embed_tokens": (i32, [vp, fp, fp, i32, i32, i32, i32, fp, vp]),
@@ -197,7 +213,8 @@ def lib() -> C.CDLL:
         raise HipLibraryError(f"ABI version mismatch: lib {l.gl_abi_version()} vs host {ABI_VERSION}")
     for cls, fn in ((GemmArgs, l.gl_sizeof_gemm_args), (ConvArgs, l.gl_sizeof_conv_args), (AttnArgs, l.gl_sizeof_attn_args),
                     (UNetConfigC, l.gl_sizeof_unet_config), (WeightInfo, l.gl_sizeof_weight_info),
-                    (PlmsStepArgs, l.gl_sizeof_plms_step_args), (RewardArgs, l.gl_sizeof_reward_args), (FFArgs, l.gl_sizeof_ff_args)):
+                    (PlmsStepArgs, l.gl_sizeof_plms_step_args), (RewardArgs, l.gl_sizeof_reward_args), (FFArgs, l.gl_sizeof_ff_args),
+                    (VaeConfigC, l.gl_sizeof_vae_config)):
         if C.sizeof(cls) != fn():
             raise HipLibraryError(f"struct size mismatch for {cls.__name__}: host {C.sizeof(cls)} vs lib {fn()}")
     _lib = l
@@ -239,6 +256,28 @@ def create_engine(cfg) -> int:
     cc = unet_config_c(cfg)
     check(lib().gl_create(C.byref(cc), C.byref(h)), "gl_create")
     return h.value
+
+
+def create_vae(cfg) -> int:
+    """gl_vae_create from an arch.VAEConfig: returns the opaque handle.  Needs no GPU."""
+    cc = VaeConfigC()
+    cc.ch, cc.n_mult, cc.num_res_blocks, cc.z_channels, cc.out_ch = cfg.ch, len(cfg.ch_mult), cfg.num_res_blocks, cfg.z_channels, cfg.out_ch
+    for i, m in enumerate(cfg.ch_mult):
+        cc.ch_mult[i] = int(m)
+    cc.embed_dim, cc.scale_factor = cfg.embed_dim, float(cfg.scale_factor)
+    h = vp()
+    check(lib().gl_vae_create(C.byref(cc), C.byref(h)), "gl_vae_create")
+    return h.value
+
+
+def vae_weight_table(handle: int):
+    l = lib()
+    out = []
+    info = WeightInfo()
+    for i in range(l.gl_vae_num_weights(handle)):
+        check(l.gl_vae_weight_at(handle, i, C.byref(info)), "gl_vae_weight_at")
+        out.append((info.name.decode(), int(info.offset), int(info.nbytes), int(info.dtype), tuple(int(info.shape[k]) for k in range(info.ndim))))
+    return out, int(l.gl_vae_weights_bytes(handle))
 
 
 def weight_table(handle: int):

@@ -11,7 +11,10 @@ head of d = 512, beyond the flash kernel's register budget; it runs once per ima
 Q.K^T (GEMM) -> row softmax -> P.V (GEMM against V^T), with 1/sqrt(C) folded into the q weights at
 pack time so the fp16 logits stay small.
 
-``VAEDecoder.decode(z)`` has the reference's contract: z fp32 [B, 4, h, w] -> fp32 [B, 3, 8h, 8w].
+``VAEDecoder.decode(z)`` has the reference's contract: z fp32 [B, 4, h, w] -> fp32 [B, 3, 8h, 8w].  It is a thin caller
+of the C engine (``gl_vae_create`` / ``gl_vae_load_weights`` / ``gl_vae_decode``, csrc/vae_engine.hip: plan, flat weight
+layout, activation pool, one hipGraph per (batch, side)); ``decode_oplevel`` is the same launch sequence issued op by op
+from Python -- the test mirror the C engine must equal bitwise, like tests/engine_pyref.py for the UNet.
 """
 from __future__ import annotations
 
@@ -61,6 +64,40 @@ class VAEDecoder:
                 W[p + ".w"], W[p + ".b"] = _h(w2), b2.contiguous()
         self.W = W
         self._pool: Dict[tuple, torch.Tensor] = {}
+        self._bind_engine()
+
+    def _bind_engine(self):
+        """Moves the packed tensors into the C engine's flat layout (gl_vae_weight_at) and rebinds ``W`` to views of it."""
+        from . import _lib
+        self.handle = _lib.create_vae(self.cfg)
+        table, total = _lib.vae_weight_table(self.handle)
+        flat = torch.zeros(total, dtype=torch.uint8, device=self.device)
+        views = {}
+        for name, off, nbytes, dtype, shape in table:
+            td = F16 if dtype == 0 else F32
+            dst = flat[off:off + nbytes].view(td).view(shape)
+            src = self.W[name]
+            if tuple(src.shape) != tuple(shape) or src.dtype != td:
+                raise ValueError(f"{name}: packed {tuple(src.shape)} {src.dtype} != engine table {shape} {td}")
+            dst.copy_(src)
+            views[name] = dst
+        extra = set(self.W) - set(views)
+        if extra:
+            raise KeyError(f"packer produced tensors the VAE engine does not know: {sorted(extra)[:3]}")
+        self.W, self.flat = views, flat
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().gl_vae_load_weights(self.handle, flat.data_ptr(), flat.numel(), torch.cuda.current_stream(self.device).cuda_stream),
+                       "gl_vae_load_weights")
+        self.use_graphs = True
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            try:
+                from . import _lib
+                _lib.lib().gl_vae_destroy(h)
+            except Exception:
+                pass
 
     @classmethod
     def from_packed(cls, W: Mapping[str, torch.Tensor], cfg: VAEConfig, device="cuda:0") -> "VAEDecoder":
@@ -73,6 +110,7 @@ class VAEDecoder:
         self.cfg, self.device, self.scale_factor = cfg, torch.device(device), cfg.scale_factor
         self.W = {k: v.to(self.device) for k, v in W.items()}
         self._pool = {}
+        self._bind_engine()
         return self
 
     def buf(self, tag, shape, dtype=F16):
@@ -127,6 +165,22 @@ class VAEDecoder:
 
     @torch.no_grad()
     def decode(self, z: torch.Tensor) -> torch.Tensor:
+        """AutoencoderKL.decode through the C engine (one hipGraph replay per call after the first)."""
+        from . import _lib
+        cfg = self.cfg
+        z = z.to(self.device, F32).contiguous()
+        B, zc, side, side_w = z.shape
+        assert side == side_w and zc == cfg.z_channels
+        oside = side * 2 ** (len(cfg.ch_mult) - 1)
+        out = torch.empty(B, cfg.out_ch, oside, oside, dtype=F32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().gl_vae_decode(self.handle, z.data_ptr(), B, side, out.data_ptr(), int(self.use_graphs),
+                                                torch.cuda.current_stream(self.device).cuda_stream), "gl_vae_decode")
+        return out
+
+    @torch.no_grad()
+    def decode_oplevel(self, z: torch.Tensor) -> torch.Tensor:
+        """The engine's launch sequence issued op by op from Python (test mirror; bitwise equal to ``decode``)."""
         cfg, W = self.cfg, self.W
         z = z.to(self.device, F32).contiguous()
         B, zc, side, side_w = z.shape

@@ -126,3 +126,30 @@ def test_hip_towers_at_vit_l14_sizes_vs_oracle():
     # deterministic, and a sample does not depend on its batch neighbours
     assert torch.equal(img, tw.get_image_features(px))
     assert rel(tw.get_image_features(px[1:2]), img[1:2]) < 1e-3
+
+
+@pytest.mark.gpu
+def test_reward_model_forward_vs_oracle_pipeline():
+    """Reward_Model.forward's GPU part end to end (models/policy.py:106-124,135): towers -> F.normalize -> similarities ->
+    aesthetic MLP -> reward, HIP (RewardModel) vs oracle (clip_ref + reward_ref) on the transformers-generated tiny CLIP."""
+    from layoutllm_t2i_amd.reward import RewardModel
+    from oracle import reward_ref
+    z, sd = golden()
+    heads, D = int(z["heads"]), 64
+    shapes = {0: (1024, D), 2: (128, 1024), 4: (64, 128), 6: (16, 64), 7: (1, 16)}
+    aes = {}
+    for li, (n, k) in shapes.items():
+        aes[f"layers.{li}.weight"] = T(recipe.uniform(f"aes.{li}.w", (n, k), 2)) * float(np.sqrt(3.0 / k))
+        aes[f"layers.{li}.bias"] = T(recipe.uniform(f"aes.{li}.b", (n,), 2)) * 0.1
+    rm = RewardModel(sd, aes, vision_heads=heads, text_heads=heads)
+    ids = T(z["input_ids"])[:3]
+    pred, gt = T(z["pixel_values"]), T(recipe.normal("gtpx", (3, 3, 42, 42), 4))
+    miou, laysim = torch.tensor([0.1, 0.5, 0.3]), torch.tensor([0.2, 0.0, 0.9])
+    out = rm(ids, pred, gt, miou=miou, laysim=laysim)
+    with torch.no_grad():
+        ref = reward_ref.reward_scores(aes, clip_ref.text_features(sd, ids, heads), clip_ref.image_features(sd, pred, heads),
+                                       clip_ref.image_features(sd, gt, heads), miou, laysim)
+    for k in ("sims_ti", "sims_ii", "aes_reward", "reward"):
+        d = float((out[k].cpu() - ref[k]).abs().max())
+        print(f"[reward model] {k}: max|diff|={d:.3e} |ref|max={float(ref[k].abs().max()):.3f}")
+        assert d < 5e-3 * max(1.0, float(ref[k].abs().max())), (k, d)
