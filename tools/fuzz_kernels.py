@@ -17,6 +17,10 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 from layoutllm_t2i_amd._lib import init_device  # noqa: E402
 init_device(0)
+# FUZZ_OPTS="30=2,34=2": gl_set_option knobs for the sweep (e.g. force the 8-wave GEMM / conv kernel wherever it applies)
+from layoutllm_t2i_amd import ops as _fz_ops  # noqa: E402
+for _kv in filter(None, os.environ.get("FUZZ_OPTS", "").split(",")):
+    _fz_ops.set_option(int(_kv.split("=")[0]), int(_kv.split("=")[1]))
 
 
 def c64(lo, hi):
