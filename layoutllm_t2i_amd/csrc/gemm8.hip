@@ -148,12 +148,17 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
                     oy = rr / cg.Wout;
                     ox = rr - oy * cg.Wout;
                 }
-                // tap (ky, kx) reads input (oy * s + ky - 1, ox * s + kx - 1): valid rows / columns as 3-bit sets, mask = their product
-                const int iy = oy * cg.stride, ix = ox * cg.stride;
-                const unsigned rb = (iy >= 1 ? 1u : 0u) | 2u | (iy + 1 < cg.Hin ? 4u : 0u);
-                const unsigned cb = (ix >= 1 ? 1u : 0u) | 2u | (ix + 1 < cg.Win ? 4u : 0u);
-                cmask[u] = ((rb & 1u) ? cb : 0u) | (cb << 3) | ((rb & 4u) ? (cb << 6) : 0u);
-                aptr[u] = cg.in + ((size_t)(b * cg.Hin + iy) * cg.Win + ix) * cg.Cin + gc;
+                // tap (ky, kx) reads input (oy * s + ky - 1, ox * s + kx - 1): valid rows / columns as 3-bit sets, mask = their product.
+                // Nearest-2x-upsampled input (openaimodel.py:82-84): the conv runs on the UPSAMPLED grid (bounds Hout x Wout), source pixel
+                // ((oy + dy) >> 1, (ox + dx) >> 1); relative to the centre's source pixel (oy >> 1, ox >> 1) that is a shift of
+                // ((dy + (oy & 1)) >> 1, (dx + (ox & 1)) >> 1) pixels -- per lane, from the two parity bits kept in cmask bits 9 / 10.
+                const int iy = cg.ups ? oy : oy * cg.stride, ix = cg.ups ? ox : ox * cg.stride;
+                const int hlim = cg.ups ? cg.Hout : cg.Hin, wlim = cg.ups ? cg.Wout : cg.Win;
+                const unsigned rb = (iy >= 1 ? 1u : 0u) | 2u | (iy + 1 < hlim ? 4u : 0u);
+                const unsigned cb = (ix >= 1 ? 1u : 0u) | 2u | (ix + 1 < wlim ? 4u : 0u);
+                cmask[u] = ((rb & 1u) ? cb : 0u) | (cb << 3) | ((rb & 4u) ? (cb << 6) : 0u) | ((unsigned)(oy & 1) << 9) | ((unsigned)(ox & 1) << 10);
+                const int sy = cg.ups ? (oy >> 1) : iy, sx = cg.ups ? (ox >> 1) : ix;
+                aptr[u] = cg.in + ((size_t)(b * cg.Hin + sy) * cg.Win + sx) * cg.Cin + gc;
             }
         } else {
             if (rowok) {
@@ -225,7 +230,12 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
             const int u = i;
             if constexpr (CONV) {
                 // masked taps (the halo) read the zero page: branch-free 64-bit select (v_bfi), no exec games
-                const uint64_t a = reinterpret_cast<uint64_t>(aptr[u] + is_off), z = reinterpret_cast<uint64_t>(zsrc);
+                int off = is_off;
+                if (cg.ups) {        // wave-uniform; this runs in the read section, outside the MFMA stream
+                    const int ry = (is_ky - 1 + (int)((cmask[u] >> 9) & 1u)) >> 1, rx = (is_kx - 1 + (int)((cmask[u] >> 10) & 1u)) >> 1;
+                    off = (ry * cg.Win + rx) * cg.Cin + (is_cblk << 6);
+                }
+                const uint64_t a = reinterpret_cast<uint64_t>(aptr[u] + off), z = reinterpret_cast<uint64_t>(zsrc);
                 const uint64_t keep = (uint64_t)0 - (uint64_t)((cmask[u] >> is_tap) & 1u);
                 src = reinterpret_cast<const half_t*>((a & keep) | (z & ~keep));
             } else {
@@ -502,7 +512,6 @@ const half_t* g8_zero_page = nullptr;      // device address of this translation
 template <int BN, bool CONV>
 int launch8(const gl_gemm_args& g, const ConvGeom& cg_in, int zs, int kper, int order_m, hipStream_t st) {
     if (!g8_zero_page) return GL_ERR_BAD_ARG;          // gl_init() was not called
-    if (CONV && cg_in.ups) return GL_ERR_UNSUPPORTED;
     ConvGeom cg = cg_in;
     cg.zero = g8_zero_page;
     const int mt = gl_cdiv(g.M, 256), nt = gl_cdiv(g.N, BN);

@@ -766,7 +766,7 @@ int dispatch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     }
     if (g_opt_g8) {
         int bn = 0;
-        if (!(CONV && cg.ups) && gl8_supported(g, CONV, &bn)) {      // (nearest-2x-upsampled input: 4-wave kernels only)
+        if (gl8_supported(g, CONV, &bn)) {
             const int tiles = gl_cdiv(g.M, 256) * gl_cdiv(g.N, bn);
             const int nk = g.K / 64;
             // One block per CU: when the 256-row grid underfills the chip (32x32 levels and below), K is cut into slices up to ONE

@@ -148,6 +148,11 @@ def cases():
     v("conv 8x16^2 2560->1280", 8, 16, 2560, 1280)
     v("conv 8x16^2 1280->1280 res f32", 8, 16, 1280, 1280, epi="res", f32=True)
     v("conv 8x8^2 2560->1280", 8, 8, 2560, 1280)
+    v("conv 8x8^2 1280->1280 up", 8, 8, 1280, 1280, up=True)
+    v("conv 8x16^2 1280->1280 up", 8, 16, 1280, 1280, up=True)
+    v("conv 4x128^2 256->256 up (VAE)", 4, 128, 256, 256, up=True)
+    v("conv 4x256^2 128->128 (VAE)", 4, 256, 128, 128)
+    v("conv 3x10^2 128->320 up (ragged)", 3, 10, 128, 320, up=True)
     g("gemm 8192x640x1920 a2 bias", 8192, 640, 1920, a2=True)
     g("gemm 2048x1280x2560 a2 bias", 2048, 1280, 2560, a2=True)
     g("gemm 512x1280x5120 res f32", 512, 1280, 5120, "res", f32=True)
