@@ -386,6 +386,45 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
     if (splitk == 1 && epi == GL_EPI_GATE_RES) gate = p.gate[0];
     const int nbase = n0 + PW * grp;
     half_t* outp = reinterpret_cast<half_t*>(p.out);
+    // Every global LOAD of the epilogue (bias, residual, row bias) is issued HERE, before the first store: vmcnt counts loads and
+    // stores in one in-order queue, so a load issued after a store cannot be waited for without waiting for that store's round trip
+    // too -- measured 12.2 k cycles for the fp16 epilogue of ONE block on an idle chip (independent of the grid size: per-block
+    // latency, not bandwidth), 5 serialised store + load round trips per pass.
+    constexpr int NQ = ITEMS / 64;
+    const bool vt_wave = p.vt != nullptr && nbase >= p.vt_col0;
+    const bool generic = splitk == 1 && !vt_wave && epi != GL_EPI_GEGLU;
+    Fin8Aux aux[2][NQ];
+    if (generic) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int idx = lane + 64 * q;
+                const int r = idx / CG8, c = (idx - r * CG8) * 8;
+                const int m = m0 + 64 * wm + 32 * h + r, n = nbase + c;
+                if (m < M && n < N) fin8_load(p, m, n, aux[h][q]);
+            }
+    }
+    float vt_bias[2] = {0.0f, 0.0f};
+    if (splitk == 1 && vt_wave && bias) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = 64 * j + lane;
+            if (col < PW && nbase + col < N) vt_bias[j] = bias[nbase + col];
+        }
+    }
+    float gg_bias[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) gg_bias[j] = 0.0f;
+    if constexpr (PW == 64) {
+        if (splitk == 1 && epi == GL_EPI_GEGLU && bias) {
+            const int nx = nbase + (lane & 3) * 8;
+            if (nx < N) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { gg_bias[j] = bias[nx + j]; gg_bias[8 + j] = bias[nx + 32 + j]; }
+            }
+        }
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int mbase = m0 + 64 * wm + 32 * h;
@@ -413,7 +452,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
                     *reinterpret_cast<float4*>(o + 4) = *reinterpret_cast<const float4*>(stage + r * EPS + c + 4);
                 }
             }
-        } else if (p.vt != nullptr && nbase >= p.vt_col0) {
+        } else if (vt_wave) {
             // V^T tail of a fused QKV projection: lane = one channel column, 8 consecutive tokens per 16-byte store
             half_t* vtp = reinterpret_cast<half_t*>(p.vt);
 #pragma unroll
@@ -424,7 +463,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
                     const int nv = n - p.vt_col0;
                     const int hh = nv / p.vt_d;
                     const int cc = nv - hh * p.vt_d;
-                    const float bv = bias ? bias[n] : 0.0f;
+                    const float bv = vt_bias[c0 / 64];
 #pragma unroll
                     for (int tg = 0; tg < 4; ++tg) {
                         const int m = mbase + tg * 8;
@@ -470,8 +509,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
                         half8_t o;
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
-                            float a = xv[j], b = gv[j];
-                            if (bias) { a += bias[nx + j]; b += bias[nx + 32 + j]; }
+                            const float a = xv[j] + gg_bias[j], b = gv[j] + gg_bias[8 + j];
                             o[j] = (half_t)(a * gelu_erf_f(b));
                         }
                         st16(outp + (size_t)m * p.ldc + (nbase >> 1) + pc, *reinterpret_cast<uint4*>(&o));
@@ -479,10 +517,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
                 }
             }
         } else {
-            // (issuing all the pass's bias / residual loads ahead of the first store was measured: 11.0 k -> 12.3 k cycles -- the
-            //  epilogue is bound by the chip's write bandwidth, all 256 blocks store their tiles at the same time)
 #pragma unroll
-            for (int q = 0; q < ITEMS / 64; ++q) {
+            for (int q = 0; q < NQ; ++q) {
                 const int idx = lane + 64 * q;
                 const int r = idx / CG8, c = (idx - r * CG8) * 8;
                 const int m = mbase + r, n = nbase + c;
@@ -490,7 +526,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
                     const float4 a0 = *reinterpret_cast<const float4*>(stage + r * EPS + c);
                     const float4 a1 = *reinterpret_cast<const float4*>(stage + r * EPS + c + 4);
                     float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-                    finish8(p, gate, m, n, v);
+                    fin8_store(p, gate, m, n, v, aux[h][q]);
                 }
             }
         }

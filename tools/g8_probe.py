@@ -110,6 +110,11 @@ def cases():
         for cin in (64, 128, 320, 640, 960):
             v(f"conv 8x64^2 {cin}->320", 8, 64, cin, 320)
         return c
+    if os.environ.get("G8_EPI"):
+        for M in (1024, 4096, 16384, 32768, 65536):
+            g(f"gemm {M}x320x320 bias", M, 320, 320)
+            g(f"gemm {M}x320x320 res f32+o16", M, 320, 320, "res", f32=True, out16=True)
+        return c
     if os.environ.get("G8_QUICK"):
         g("gemm 4096x320x320 bias", 4096, 320, 320)
         v("conv 2x32^2 320->320", 2, 32, 320, 320)
@@ -237,7 +242,8 @@ def main():
         import numpy as np
         from layoutllm_t2i_amd import _lib
         print("== stamps (cycles @100 MHz-or-shader clock, per block): prologue | main loop | epilogue | total ; spread of block start/end")
-        ops.set_option(30, 1)
+        ops.set_option(30, 2 if os.environ.get("G8_FORCE") else 1)
+        ops.set_option(34, 1000 if os.environ.get("G8_FORCE") else 11)      # (forced: no split-K)
         for name, alloc, launch, fl in cs:
             o = alloc()
             row = []
