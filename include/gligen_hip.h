@@ -420,7 +420,8 @@ int gl_sizeof_attn_args(void);
 int gl_set_option(int key, int value);
 /* measurement hook (tools/g8_probe.py): what = 8 copies the per-block cycle stamps [entry, prologue done, main loop done,
  * epilogue done] (4 x uint64 per block, up to 4096 blocks) that the timestamping instantiation of the 8-wave GEMM / conv
- * kernel writes while gl_set_option(32, 1) is in effect.  Synchronous device-to-host copy. */
+ * kernel writes while gl_set_option(32, 1) is in effect (synchronous device-to-host copy); what = 9 copies one uint64: the
+ * number of gl_gemm / gl_conv3x3 calls this process has served with the 8-wave kernel (the tests of that kernel assert it moved). */
 int gl_debug_read(int what, void* dst, int64_t bytes);
 /* one-time per-process setup (raises dynamic-LDS limits of the tiled kernels); idempotent */
 int gl_init(void);

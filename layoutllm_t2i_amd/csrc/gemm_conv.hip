@@ -25,6 +25,8 @@
 //
 // Residual stream: with res_f32 / GL_OUT_F32_ROWMAJOR the residual is read and the sum written in fp32 (plus an
 // optional fp16 copy for matrix-core consumers), so chained residual adds are never rounded to fp16.
+#include <atomic>
+#include <cstring>
 #include "common.h"
 #include "gligen_hip.h"
 #include "gemm_shared.h"
@@ -47,6 +49,7 @@ int g_opt_g8_tiles = 200;    // auto: at least this many 256-row tiles (x K slic
 int g_opt_g8_tapmajor = 0;   // conv K order of the 8-wave kernel: 1 = (tap, channel block), 0 = (channel block, tap); measured equal in time,
                              // tap-major re-fetches the input 9x from beyond L2 once a level's slab outgrows the 4 MiB L2 (r3 PMC)
 int g_opt_g8_minkt = 11;     // split-K of the 8-wave kernel: at least this many K-tiles per slice
+std::atomic<uint64_t> g8_launches{0};   // launches that went to the 8-wave kernel (tests read it: gl_debug_read(9))
 int g_opt_g8_minnk = 5;      // 8-wave kernel only for K >= 64 * this
 
 template <int BM, int BN, int BKT, int NW = 4>
@@ -789,6 +792,7 @@ int dispatch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
                 const int order_m = g_opt_order == 1 ? ((CONV ? 9L : 1L) * g.N > (long)g.M) : (g_opt_order == 2);
                 const int e = gl8_launch(g, cg, CONV, bn, zs, kper, order_m | (CONV && g_opt_g8_tapmajor ? 2 : 0), st);
                 if (e) return e;
+                g8_launches.fetch_add(1, std::memory_order_relaxed);
                 if (zs > 1) {
                     const size_t total = (size_t)g.M * (g.N / 8);
                     int nblk = (int)((total + 255) / 256);
@@ -881,5 +885,11 @@ extern "C" int gl_set_option_gemm(int key, int value) {
 // measurement hook: per-block cycle stamps of the timestamping 8-wave kernel (gl_set_option(32, 1)); 4 x uint64 per block
 extern "C" int gl_debug_read(int what, void* dst, int64_t bytes) {
     if (what == 8) return gl8_read_stamps(dst, bytes);
+    if (what == 9) {
+        if (!dst || bytes < (int64_t)sizeof(uint64_t)) return GL_ERR_BAD_ARG;
+        const uint64_t n = g8_launches.load(std::memory_order_relaxed);
+        memcpy(dst, &n, sizeof n);
+        return 0;
+    }
     return GL_ERR_BAD_ARG;
 }

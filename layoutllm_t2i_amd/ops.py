@@ -426,6 +426,15 @@ def set_option(key: int, value: int) -> None:
     check(_lib.lib().gl_set_option(key, value), "gl_set_option")
 
 
+def gemm8_launch_count() -> int:
+    """gl_gemm / gl_conv3x3 calls this process has served with the 8-wave kernel (gl_debug_read(9)); the tests of that kernel
+    assert it moved, so a dispatcher that quietly stopped choosing it cannot pass them."""
+    import ctypes
+    n = ctypes.c_uint64(0)
+    check(_lib.lib().gl_debug_read(9, ctypes.byref(n), 8), "gl_debug_read")
+    return int(n.value)
+
+
 # ------------------------------------------------------------------------------------------- CLIP towers (reward stage)
 def clip_patchify(pixel_values: torch.Tensor, patch: int, Kpad: int, out: torch.Tensor) -> torch.Tensor:
     """pixel_values fp32 [B, 3, S, S] -> fp16 [B * (S/patch)^2, Kpad] patch rows (K index (c, i, j), zero-padded)."""

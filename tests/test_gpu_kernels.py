@@ -89,8 +89,7 @@ def test_gemm_epilogues():
 
 
 @pytest.mark.parametrize("C", [64, 320])
-def test_gemm_geglu(C):
-    M = 200
+def test_gemm_geglu(C, M=200):
     a, ad = h16(rnd("ga", (M, C)))
     w, _ = h16(rnd("gw", (8 * C, C), 1 / math.sqrt(C)))
     b = rnd("gb", (8 * C,), 0.1)
@@ -233,6 +232,55 @@ def test_gemm_conv_256row_variant():
         test_conv3x3_epilogues()
     finally:
         ops.set_option(7, 300)      # library default
+        ops.set_option(24, 64)
+
+
+def test_gemm_conv_8wave_variant():
+    """the 8-wave deep-pipelined kernel (gemm8.hip: 256 x {160, 128} tiles, LDS-DMA ring, split-K up to one round of blocks)
+    forced wherever it applies via gl_set_option(30, 2) -- by default it serves the 64x64 / 32x32 levels of the full-size UNet,
+    shapes too large for a CPU reference here.  Every epilogue it has: bias / SiLU / residual (fp16 and fp32 stream, with the
+    fp16 copy) / gate / row bias / GEGLU / V^T tail / two-source A / split-K partials; convs stride 1, stride 2, nearest-2x;
+    ragged M and N tails.  gl_debug_read(9) proves the launches went to it."""
+    ops.set_option(30, 2)
+    ops.set_option(24, 0)
+
+    def on8(n, fn, *a):
+        ops.set_option(24, 0)          # (some of the called tests restore the skinny-GEMM default on exit)
+        c0 = ops.gemm8_launch_count()
+        fn(*a)
+        got = ops.gemm8_launch_count() - c0
+        assert got == n, f"{fn.__name__}{a}: {got} launches on the 8-wave kernel, expected {n}"
+
+    try:
+        on8(1, test_gemm_bias, 512, 1280, 640)          # BN 160
+        on8(1, test_gemm_bias, 300, 320, 320)           # ragged M tail
+        on8(1, test_gemm_bias, 1024, 960, 320)
+        on8(1, test_gemm_bias, 700, 512, 832)           # BN 128, K = 13 tiles
+        on8(1, test_gemm_bias, 257, 200, 128)           # N tail (200 = 128 + 72), one row in the second M tile
+        on8(1, test_gemm_bias, 512, 320, 64)            # a single K-tile: prologue and tail only
+        on8(5, test_gemm_epilogues)
+        on8(1, test_gemm_geglu, 320, 700)
+        on8(1, test_gemm_geglu, 64, 256)
+        on8(1, test_gemm_two_source)
+        on8(1, test_gemm_split_k, 512, 1280, 5120, "res")
+        on8(1, test_gemm_split_k, 2048, 1280, 5120, "gate")
+        on8(1, test_gemm_split_k, 512, 1280, 2560, "bias")
+        on8(5, test_gemm_residual_stream_fp32, 700, 320, 640)
+        on8(5, test_gemm_residual_stream_fp32, 512, 1280, 5120)
+        on8(5, test_gemm_residual_stream_fp32, 8192, 640, 640)
+        on8(2, test_gemm_qkv_writes_v_transposed, 2, 256, 320, 8)
+        on8(2, test_gemm_qkv_writes_v_transposed, 1, 1054, 640, 8)
+        on8(2, test_gemm_qkv_writes_v_transposed, 2, 286, 64, 4)
+        on8(2, test_gemm_qkv_writes_v_transposed, 1, 4126, 320, 8)
+        on8(1, test_conv3x3, "s1", 320, 320, 16)
+        on8(1, test_conv3x3, "s2", 320, 320, 32)
+        on8(1, test_conv3x3, "up", 64, 128, 8)
+        on8(1, test_conv3x3, "up", 320, 320, 8)
+        on8(1, test_conv3x3, "s1", 1280, 1280, 16)      # split-K conv (few tiles, 180 K-tiles)
+        on8(1, test_conv3x3, "s1", 64, 128, 24)         # 1152 rows: ragged last tile; K = 9 tiles
+        on8(2, test_conv3x3_epilogues, 16)
+    finally:
+        ops.set_option(30, 1)
         ops.set_option(24, 64)
 
 
@@ -405,8 +453,8 @@ def test_conv3x3_first_and_last():
     check(eps, F.conv2d(h, w2, b2, padding=1), "conv_last_nchw_f32", rtol=1e-4, atol=1e-5)
 
 
-def test_conv3x3_epilogues():
-    B, C, hw = 2, 128, 8
+def test_conv3x3_epilogues(hw=8):
+    B, C = 2, 128
     x, _ = h16(rnd("cex", (B, C, hw, hw)))
     w, _ = h16(rnd("cew", (C, C, 3, 3), 1 / math.sqrt(9 * C)))
     b = rnd("ceb", (C,), 0.1)
