@@ -203,14 +203,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
                 const int off = ((ky - 1) * cg.Win + (kx - 1)) * cg.Cin + ci0;    // wave-uniform
 #pragma unroll
                 for (int i = 0; i < APASS; ++i) {
-                    if (RPP * i + wave * RPW >= BM) continue;      // wave-uniform: pass has no rows for this wave
+                    if ((BM % RPP) != 0 && RPP * i + wave * RPW >= BM) continue;      // wave-uniform: pass has no rows for this wave
                     const half_t* src = ((cmask[i] >> tap) & 1u) ? (aptr[i] + off) : zsrc;
                     glds16(src, As + (size_t)(buf * BM + RPP * i + wave * RPW) * BKT);
                 }
             } else {
 #pragma unroll
                 for (int i = 0; i < APASS; ++i) {
-                    if (RPP * i + wave * RPW >= BM) continue;
+                    if ((BM % RPP) != 0 && RPP * i + wave * RPW >= BM) continue;
                     const int r = srow + RPP * i;
                     const int gc = (skc ^ swz(r)) << 3;
                     const half_t* src = zsrc;
@@ -235,14 +235,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
             }
 #pragma unroll
             for (int i = 0; i < APASS; ++i) {
-                if (RPP * i + wave * RPW >= BM) continue;
+                if ((BM % RPP) != 0 && RPP * i + wave * RPW >= BM) continue;
                 glds16(aptr[i], As + (size_t)(buf * BM + RPP * i + wave * RPW) * BKT);
                 aptr[i] += ((amask >> i) & 1u) ? BKT : 0;
             }
         }
 #pragma unroll
         for (int i = 0; i < BPASS; ++i) {
-            if (RPP * i + wave * RPW >= BN) continue;
+            if ((BN % RPP) != 0 && RPP * i + wave * RPW >= BN) continue;
             glds16(bptr[i], Bs + (size_t)(buf * BN + RPP * i + wave * RPW) * BKT);
             bptr[i] += ((bmask >> i) & 1u) ? BKT : 0;
         }
