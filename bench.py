@@ -90,6 +90,8 @@ def parse():
     ap.add_argument("--no-vae", action="store_true", help="stop at the final latent (exclude the VAE decode stage from the step)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
                     help="gl_set_option tuning knob for same-box A/B runs (see include/gligen_hip.h), repeatable")
+    ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path (process group, bundle broadcast, barriers, max-over-ranks) "
+                    "even at WORLD_SIZE=1: runs the RCCL calls on a 1-GPU box")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to smoke-test the path on one GPU)")
     return ap.parse_args()
 
@@ -108,8 +110,12 @@ def main():
     dev_index = local_rank % max(ndev, 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -158,7 +164,7 @@ def main():
     if rank == 0 and want_vae:
         vae = VAEDecoder(random_vae_state_dict(VAEConfig(), dev, seed=1), VAEConfig(), dev)
     bcast_ms = None
-    if world > 1:
+    if multi:
         from layoutllm_t2i_amd.dist import broadcast_bundle
         torch.cuda.synchronize()
         dist.barrier()
@@ -264,7 +270,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -280,7 +286,7 @@ def main():
     sync()
     elapsed = time.time() - t1
     assert torch.isfinite(out).all(), "non-finite latents"
-    if world > 1:
+    if multi:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -436,7 +442,7 @@ def main():
                                                             "images_per_s": round(1.0 / t_c1, 6)}
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

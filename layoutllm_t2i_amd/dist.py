@@ -10,6 +10,8 @@ bytes straight to gl_load_weights and carves its tensor views out of them by the
 """
 from __future__ import annotations
 
+import contextlib
+
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -106,11 +108,14 @@ def broadcast_bundle(P: Optional[PackedWeights], vae_w: Optional[Dict[str, torch
         box = [head]
     else:
         flat, box = None, [None]
-    dist.broadcast_object_list(box, src=src)
-    head = box[0]
-    if rank != src:
-        flat = torch.empty(head["total"], dtype=torch.uint8, device=device)
-    dist.broadcast(flat.view(torch.int64) if flat.numel() % 8 == 0 else flat, src=src)      # the one collective
+    # RCCL stages object collectives on the CURRENT device: make that this rank's GPU even if the caller never set it
+    d = torch.device(device)
+    with (torch.cuda.device(d) if d.type == "cuda" else contextlib.nullcontext()):
+        dist.broadcast_object_list(box, src=src)
+        head = box[0]
+        if rank != src:
+            flat = torch.empty(head["total"], dtype=torch.uint8, device=device)
+        dist.broadcast(flat.view(torch.int64) if flat.numel() % 8 == 0 else flat, src=src)      # the one collective
     if rank == src:
         return P, vae_w, extra                  # the sender keeps its own objects (the staging buffer is dropped)
     usz = head["unet_bytes"]

@@ -415,6 +415,14 @@ def load_all_models_sharded(ckpt, device, src=0):
 
 
 @torch.no_grad()
+def _collective_device(device):
+    """Object collectives of the RCCL backend stage their bytes on the CURRENT device: make that this rank's GPU even when the
+    caller never called torch.cuda.set_device (all ranks staging on GPU 0 is an RCCL 'duplicate GPU' error)."""
+    import contextlib
+    d = torch.device(device)
+    return torch.cuda.device(d) if d.type == "cuda" else contextlib.nullcontext()
+
+
 def prepare_conditioning(all_models, captions, labels, bboxes, clip_model, clip_processor, device):
     """Everything ``run_batch_images`` feeds the sampler (interface.py:486-535), per prompt row, on the CPU: context / uc
     [n, 77, 768], relations [n, R, 768], boxes / masks / text_embeddings [n, 30, ...].  Rows are independent, so any subset of
@@ -474,9 +482,12 @@ def generate_batch_images_sharded(all_models, captions=None, labels=None, bboxes
         n = len(captions)
         seeds = list(range(n)) if seeds is None else [int(s_) for s_ in seeds]
         assert len(seeds) == n
+        # prepare_conditioning returns HOST tensors: object collectives pickle tensors with their device, and rank r must not
+        # receive rank 0's "cuda:0" tensors
         box = [dict(cond=prepare_conditioning(all_models, captions, labels, bboxes, clip_model, clip_processor, device), seeds=seeds)]
     if multi:
-        dist.broadcast_object_list(box, src=src)
+        with _collective_device(device):
+            dist.broadcast_object_list(box, src=src)
     cond, seeds = box[0]["cond"], box[0]["seeds"]
     n = len(seeds)
     mine = shard_indices(n, rank, world)
@@ -485,7 +496,8 @@ def generate_batch_images_sharded(all_models, captions=None, labels=None, bboxes
     if not multi:
         return [Image.fromarray(a) for a in imgs]
     parts = [None] * world if rank == src else None
-    dist.gather_object((mine, imgs), parts, dst=src)
+    with _collective_device(device):
+        dist.gather_object((mine, imgs), parts, dst=src)
     if rank != src:
         return None
     out = [None] * n

@@ -116,3 +116,21 @@ def test_product_entry_two_ranks_equal_single_process_bitwise(tmp_path):
                                              seeds=W.SEEDS, steps=W.STEPS, latent=W.LATENT)
     solo = np.stack([np.asarray(im) for im in solo])
     assert solo.shape == got.shape and np.mean(np.abs(solo.astype(int) - got.astype(int)) <= 3) > 0.97
+
+
+def test_rccl_path_of_the_bench_at_world_1():
+    """The multi-rank code path of bench.py (RCCL process group bound to the device, bundle broadcast of UNet + VAE, barriers,
+    max-over-ranks all-reduce) launched exactly as the driver launches N > 1, with ONE rank: every collective goes through
+    RCCL on the GPU, which the gloo tests cannot show.  The JSON line must come out and carry the broadcast time."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--tiny", "--steps", "1",
+           "--warmup", "1", "--plms-steps", "4", "--no-cpu-baseline", "--no-hot-kernel"]
+    p = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    line = next(l for l in p.stdout.splitlines() if l.startswith("{"))
+    doc = json.loads(line)
+    assert doc["n_gpus"] == 1 and doc["value"] > 0 and doc.get("weight_broadcast_ms") is not None, doc
