@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GL_ABI_VERSION 9
+#define GL_ABI_VERSION 10
 
 /* error codes (negative; positive values are hipError_t) */
 #define GL_ERR_BAD_ARG (-1)
@@ -418,6 +418,14 @@ int gl_sizeof_attn_args(void);
  * key 30 = 8-wave deep-pipelined 256-row GEMM / conv kernel (0 off, 1 default: problems with at least key-31 (200) such tiles,
  * 2 wherever it applies, with split-K); key 32 = (measurement) its timestamping instantiation, see gl_debug_read. */
 int gl_set_option(int key, int value);
+/* gl_set_option writes the PROCESS defaults (op-level calls and every handle without an override see them).  A handle can
+ * override individual keys for itself: while one of ITS entry points (gl_set_conditioning / gl_unet_forward / gl_plms_step,
+ * gl_vae_decode) runs, lookups on that thread see the defaults with the handle's overrides applied, so two hosts in one
+ * process tune independently.  A change drops only that handle's captured graphs.  Same keys and value normalisation as
+ * gl_set_option; -1 for an unknown key. */
+int gl_set_handle_option(gl_engine* e, int key, int value);
+int gl_clear_handle_options(gl_engine* e);
+int gl_vae_set_option(gl_vae* v, int key, int value);
 /* measurement hook (tools/g8_probe.py): what = 8 copies the per-block cycle stamps [entry, prologue done, main loop done,
  * epilogue done] (4 x uint64 per block, up to 4096 blocks) that the timestamping instantiation of the 8-wave GEMM / conv
  * kernel writes while gl_set_option(32, 1) is in effect (synchronous device-to-host copy); what = 9 copies one uint64: the

@@ -20,12 +20,13 @@
 // of V^T (32 per MFMA tile).
 #include "common.h"
 #include "gligen_hip.h"
+#include "opts.h"
 
 namespace {
 
-int g_attn_qt2 = 0;          // block shape: 0 auto, 3 always 8 waves, 4 always 4 waves
-int g_attn_padmax = 1;       // running max carried in the operands' padding column where the head dim has one (gl_set_option 29; 0 = FMA path)
-int g_attn_setprio = -1;     // s_setprio(1) around the MFMA clusters: -1 auto (head dim <= 48: +6 %; d = 80: -4 %), 0 off, 1 on
+#define g_attn_qt2 gl_opt(3)  // default 0;          // block shape: 0 auto, 3 always 8 waves, 4 always 4 waves
+#define g_attn_padmax gl_opt(29)  // default 1;       // running max carried in the operands' padding column where the head dim has one (gl_set_option 29; 0 = FMA path)
+#define g_attn_setprio gl_opt(10)  // default -1;     // s_setprio(1) around the MFMA clusters: -1 auto (head dim <= 48: +6 %; d = 80: -4 %), 0 off, 1 on
 constexpr int KT = 64;          // keys per tile
 constexpr int VSTR2 = KT + 8;   // main kernel: 144 B rows = 9 x 16 B, conflict-free 16-byte fragment reads
 
@@ -450,13 +451,6 @@ extern "C" int gl_attention(const gl_attn_args* a, void* stream) {
     if (d <= 80) return launch_attn_auto<80>(*a, st);
     if (d <= 128) return launch_attn_auto<128>(*a, st);
     return launch_attn_auto<160>(*a, st);
-}
-
-extern "C" int gl_set_option_attn(int key, int value) {
-    if (key == 3) { g_attn_qt2 = value; return 0; }
-    if (key == 10) { g_attn_setprio = value; return 0; }
-    if (key == 29) { g_attn_padmax = value; return 0; }
-    return GL_ERR_BAD_ARG;
 }
 
 extern "C" int gl_transpose_v(const void* v, int64_t v_bstride, int32_t ldv, void* vt, int32_t ldvt, int32_t B,

@@ -35,7 +35,7 @@ def _newer(a: str, b: str) -> bool:
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = _hipcc()
     os.makedirs(OBJDIR, exist_ok=True)
-    deps = [os.path.join(HERE, "common.h"), os.path.join(HERE, "gemm_shared.h"), os.path.join(REPO, "include", "gligen_hip.h")]
+    deps = [os.path.join(HERE, "common.h"), os.path.join(HERE, "gemm_shared.h"), os.path.join(HERE, "opts.h"), os.path.join(REPO, "include", "gligen_hip.h")]
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(REPO, "include"), "-I" + HERE]
 
     # per-file extras: attention keeps MFMA results in VGPRs (no v_accvgpr_read/write round trips in the

@@ -12,6 +12,7 @@
 //   * one hipGraph per (shape, fuser on/off, first-conv variant), replayed per step.
 #include "common.h"
 #include "gligen_hip.h"
+#include "opts.h"
 
 #include <cmath>
 #include <cstring>
@@ -21,16 +22,15 @@
 #include <unordered_map>
 #include <vector>
 
-extern int g_gl_option_epoch;      // misc.hip: bumped by every gl_set_option call
 
 namespace {
 
 constexpr int CIN_PAD = 64;              // the 4-channel latent is zero-padded to one 64-channel K block
 constexpr int64_t ALIGN = 256;
 constexpr int64_t WS_BYTES = 96ll << 20; // split-K fp32 partial tiles
-int g_fuse_merge_ln = 1;                 // A/B knob (gl_set_option 25): rela_merge also writes LayerNorm(norm2) of its rows
-int g_fuse_vt = 1;                       // A/B knob (gl_set_option 21): V^T written by the QKV GEMM epilogue (1) or by gl_transpose_v (0)
-int g_force_fuser = 0;                   // test knob (gl_set_option 20): execute the fuser even at scale 0 (zero gates)
+#define g_fuse_merge_ln gl_opt(25)  // default 1;                 // A/B knob (gl_set_option 25): rela_merge also writes LayerNorm(norm2) of its rows
+#define g_fuse_vt gl_opt(21)  // default 1;                       // A/B knob (gl_set_option 21): V^T written by the QKV GEMM epilogue (1) or by gl_transpose_v (0)
+#define g_force_fuser gl_opt(20)  // default 0;                   // test knob (gl_set_option 20): execute the fuser even at scale 0 (zero gates)
 
 enum Kind { CONV_IN = 0, RES = 1, ST = 2, DOWN = 3, UP = 4 };
 struct LayerD {
@@ -136,6 +136,8 @@ struct gl_engine {
     int gate_pin_next = 0;
     int launches = 0;
     int opt_epoch = 0;                 // gl_set_option generation the captured graphs were built under
+    int ovr_epoch = 0;                 // ... and the generation of this handle's own overrides
+    gl_opt_overrides ovr;              // per-handle option overrides (gl_set_handle_option)
     std::string err;
     hipStream_t cap_stream = nullptr;  // graphs are captured on an engine-owned stream (the caller's may be the legacy
                                        // default stream, which cannot be captured) and launched on the caller's
@@ -838,6 +840,7 @@ extern "C" int gl_load_weights(gl_engine* e, const void* packed, int64_t bytes, 
 extern "C" int gl_set_conditioning(gl_engine* e, const float* context, const float* relations, const float* boxes, const float* masks,
                                    const float* pos_emb, int32_t Bn, int32_t Lc, int32_t R, int32_t hw, void* stream) {
     if (!e || !e->wbase || !context || !relations || !boxes || !masks || !pos_emb || Bn <= 0 || Lc <= 0 || R <= 0 || hw <= 0) return GL_ERR_BAD_ARG;
+    gl_opts_scope opts_scope(e->ovr);       // this handle's option overrides are in effect for the call
     const gl_unet_config& cfg = e->cfg;
     hipStream_t st = (hipStream_t)stream;
     const int mo = cfg.max_objs, ctx = cfg.context_dim, H = cfg.num_heads;
@@ -916,6 +919,7 @@ extern "C" int gl_set_conditioning(gl_engine* e, const float* context, const flo
 extern "C" int gl_unet_forward(gl_engine* e, const float* x, const float* t_dev, float t_host, int32_t reps, float fuser_scale, int32_t sd_conv,
                                float* eps, int32_t use_graph, void* stream) {
     if (!e || !e->cond_set || !x || !eps || reps < 1 || (e->Bn % reps) != 0) return GL_ERR_BAD_ARG;
+    gl_opts_scope opts_scope(e->ovr);       // this handle's option overrides are in effect for the call
     if (sd_conv && !e->has_sd) return GL_ERR_BAD_ARG;
     const gl_unet_config& cfg = e->cfg;
     hipStream_t st = (hipStream_t)stream;
@@ -936,9 +940,10 @@ extern "C" int gl_unet_forward(gl_engine* e, const float* x, const float* t_dev,
     }
     CK(set_fuser_scale(e, fuser_scale, st));
     const bool fuser_on = fuser_scale != 0.0f || g_force_fuser != 0;
-    if (e->opt_epoch != g_gl_option_epoch) {       // a tuning knob changed: the captured launch sequences may be stale
+    if (e->opt_epoch != g_gl_option_epoch || e->ovr_epoch != e->ovr.epoch) {       // a tuning knob changed: the captured launch sequences may be stale
         e->drop_graphs();
         e->opt_epoch = g_gl_option_epoch;
+        e->ovr_epoch = e->ovr.epoch;
     }
     const auto key = std::make_tuple(Bn, side, e->R, e->Lc, (int)fuser_on, (int)(sd_conv != 0), (int)reps);
     auto it = e->graphs.find(key);
@@ -976,6 +981,7 @@ extern "C" int gl_unet_forward(gl_engine* e, const float* x, const float* t_dev,
 
 extern "C" int gl_plms_step(gl_engine* e, const gl_plms_step_args* a, void* stream) {
     if (!e || !a || !a->x_eval || !a->x_base || !a->x_out || !a->e_out || a->n_terms < 1 || a->n_terms > 4) return GL_ERR_BAD_ARG;
+    gl_opts_scope opts_scope(e->ovr);       // this handle's option overrides are in effect for the call
     if (a->reps != 1 && a->reps != 2) return GL_ERR_BAD_ARG;
     const gl_unet_config& cfg = e->cfg;
     if (cfg.in_channels != cfg.out_channels) return GL_ERR_UNSUPPORTED;
@@ -999,11 +1005,20 @@ extern "C" int gl_plms_step(gl_engine* e, const gl_plms_step_args* a, void* stre
                           (int64_t)n, a->x_out, st);
 }
 
-extern "C" int gl_set_option_engine(int key, int value) {
-    if (key == 20) { g_force_fuser = value; return 0; }
-    if (key == 21) { g_fuse_vt = value; return 0; }
-    if (key == 25) { g_fuse_merge_ln = value; return 0; }
-    return GL_ERR_BAD_ARG;
+extern "C" int gl_set_handle_option(gl_engine* e, int key, int value) {
+    gl_opts probe{};
+    if (!e || key < 0 || key >= GL_OPT_MAX || !gl_opts_store(probe, key, value)) return GL_ERR_BAD_ARG;
+    e->ovr.mask |= (uint64_t)1 << key;
+    e->ovr.v[key] = value;
+    ++e->ovr.epoch;
+    return 0;
+}
+
+extern "C" int gl_clear_handle_options(gl_engine* e) {
+    if (!e) return GL_ERR_BAD_ARG;
+    e->ovr.mask = 0;
+    ++e->ovr.epoch;
+    return 0;
 }
 
 extern "C" int64_t gl_pool_bytes(const gl_engine* e) {

@@ -20,6 +20,7 @@
 #include "common.h"
 #include <atomic>
 #include "gligen_hip.h"
+#include "opts.h"
 
 namespace {
 
@@ -33,7 +34,7 @@ __device__ __forceinline__ f32x16 ff_mfma(half8_t a, half8_t b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
-int g_ff_enable = 1;   // gl_set_option 27: 0 = gl_ff_fused_applicable answers no (two-launch FeedForward everywhere)
+#define g_ff_enable gl_opt(27)  // default 1;   // gl_set_option 27: 0 = gl_ff_fused_applicable answers no (two-launch FeedForward everywhere)
 
 template <int C>
 struct FFGeom {
@@ -301,11 +302,6 @@ extern "C" int gl_init_ff(void) {
     if ((e = ff_set_attr<192>())) return e;
     if ((e = ff_set_attr<256>())) return e;
     return ff_set_attr<320>();
-}
-
-extern "C" int gl_set_option_ff(int key, int value) {
-    if (key == 27) { g_ff_enable = value; return 0; }
-    return GL_ERR_BAD_ARG;
 }
 
 extern "C" int gl_ff_fused_supported(int32_t C) { return C == 64 || C == 128 || C == 192 || C == 256 || C == 320; }

@@ -27,6 +27,7 @@
 #include "common.h"
 #include "gligen_hip.h"
 #include "gemm_shared.h"
+#include "opts.h"
 #include <type_traits>
 
 namespace {
@@ -541,7 +542,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
     }
 }
 
-int g8_dbg = 0;
+#define g8_dbg gl_opt(32)   // measurement instantiation selector (process default 0)
 
 const half_t* g8_zero_page = nullptr;      // device address of this translation unit's zero page (gl8_init)
 
@@ -614,7 +615,6 @@ int gl8_init(void) {
 }
 
 // measurement hooks (tools/g8_probe.py): option 32 selects the timestamping instantiation of the 160-wide kernel
-int gl8_set_debug(int v) { g8_dbg = v; return 0; }
 int gl8_read_stamps(void* dst, int64_t bytes) {
     if (bytes > (int64_t)sizeof(unsigned long long) * 4 * 4096) return GL_ERR_BAD_ARG;
     hipError_t e = hipMemcpyFromSymbol(dst, HIP_SYMBOL(g8_stamps), (size_t)bytes, 0, hipMemcpyDeviceToHost);

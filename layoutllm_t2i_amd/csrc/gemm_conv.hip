@@ -30,27 +30,28 @@
 #include "common.h"
 #include "gligen_hip.h"
 #include "gemm_shared.h"
+#include "opts.h"
 
 namespace {
 
-int g_opt_ksplit = 3;        // intra-block K-split variants (64-row wave tiles): 0 off, 1 convs + long-K GEMMs, 2 always, 3 convs only
+#define g_opt_ksplit gl_opt(13)  // default 3;        // intra-block K-split variants (64-row wave tiles): 0 off, 1 convs + long-K GEMMs, 2 always, 3 convs only
                              // (default: same-box full-forward A/B, profiles/r2_ab_dispatch_knobs.txt: the plain-GEMM use costs 0.1 ms), 4 GEMMs only
-int g_opt_geglu32 = 1;       // 1 = short-K GEGLU GEMMs use the 4-blocks/CU BK 32 variant
-int g_opt_big = 300;         // problems with >= this many 256-row tiles use the 256-row variant (B=4: neutral; B=16: +5-7 %); 0 = off
-int g_opt_small = 400;       // use 64x128 tiles when the 128-row grid has fewer tiles than this (0 = never)
-int g_opt_splitk_tiles = 300; // split K only below this many tiles (plain GEMM) ...
-int g_opt_splitk_tiles_conv = 450; // ... (conv)
-int g_opt_splitk_nk = 16;    // ... and at least this many 64-wide K tiles
-int g_opt_skinny = 64;       // skinny-GEMM kernel while its operand re-reads stay below this many MiB (0 = off)
-int g_opt_order = 1;         // tile order: 0 = N-tiles fastest, 1 = M-tiles fastest when the weights are the larger operand, 2 = always M
-int g_opt_tile = 0;          // 0 = auto; 1 = force 128x128 (N >= 256); 2 = prefer 128x160 whenever N % 160 == 0
-int g_opt_g8 = 1;            // 8-wave deep-pipelined 256-row kernel (gemm8.hip): 0 off, 1 auto (enough tiles), 2 whenever it applies
-int g_opt_g8_tiles = 200;    // auto: at least this many 256-row tiles (x K slices)
-int g_opt_g8_tapmajor = 0;   // conv K order of the 8-wave kernel: 1 = (tap, channel block), 0 = (channel block, tap); measured equal in time,
+#define g_opt_geglu32 gl_opt(8)  // default 1;       // 1 = short-K GEGLU GEMMs use the 4-blocks/CU BK 32 variant
+#define g_opt_big gl_opt(7)  // default 300;         // problems with >= this many 256-row tiles use the 256-row variant (B=4: neutral; B=16: +5-7 %); 0 = off
+#define g_opt_small gl_opt(4)  // default 400;       // use 64x128 tiles when the 128-row grid has fewer tiles than this (0 = never)
+#define g_opt_splitk_tiles gl_opt(5)  // default 300; // split K only below this many tiles (plain GEMM) ...
+#define g_opt_splitk_tiles_conv gl_opt(GL_OPT_SPLITK_TILES_CONV)  // default 450; // ... (conv)
+#define g_opt_splitk_nk gl_opt(6)  // default 16;    // ... and at least this many 64-wide K tiles
+#define g_opt_skinny gl_opt(24)  // default 64;       // skinny-GEMM kernel while its operand re-reads stay below this many MiB (0 = off)
+#define g_opt_order gl_opt(23)  // default 1;         // tile order: 0 = N-tiles fastest, 1 = M-tiles fastest when the weights are the larger operand, 2 = always M
+#define g_opt_tile gl_opt(2)  // default 0;          // 0 = auto; 1 = force 128x128 (N >= 256); 2 = prefer 128x160 whenever N % 160 == 0
+#define g_opt_g8 gl_opt(30)  // default 1;            // 8-wave deep-pipelined 256-row kernel (gemm8.hip): 0 off, 1 auto (enough tiles), 2 whenever it applies
+#define g_opt_g8_tiles gl_opt(31)  // default 200;    // auto: at least this many 256-row tiles (x K slices)
+#define g_opt_g8_tapmajor gl_opt(33)  // default 0;   // conv K order of the 8-wave kernel: 1 = (tap, channel block), 0 = (channel block, tap); measured equal in time,
                              // tap-major re-fetches the input 9x from beyond L2 once a level's slab outgrows the 4 MiB L2 (r3 PMC)
-int g_opt_g8_minkt = 11;     // split-K of the 8-wave kernel: at least this many K-tiles per slice
+#define g_opt_g8_minkt gl_opt(34)  // default 11;     // split-K of the 8-wave kernel: at least this many K-tiles per slice
 std::atomic<uint64_t> g8_launches{0};   // launches that went to the 8-wave kernel (tests read it: gl_debug_read(9))
-int g_opt_g8_minnk = 5;      // 8-wave kernel only for K >= 64 * this
+#define g_opt_g8_minnk gl_opt(35)  // default 5;      // 8-wave kernel only for K >= 64 * this
 
 template <int BM, int BN, int BKT, int NW = 4>
 constexpr int lds_bytes() {
@@ -861,25 +862,6 @@ extern "C" int gl_init_gemm(void) {
     if ((e = set_lds_attr<128, 128, 2, 2, false, 32>())) return e;
     if ((e = gl8_init())) return e;
     return 0;
-}
-
-extern "C" int gl_set_option_gemm(int key, int value) {
-    if (key == 2) { g_opt_tile = value; return 0; }
-    if (key == 4) { g_opt_small = value; return 0; }
-    if (key == 7) { g_opt_big = value; return 0; }
-    if (key == 8) { g_opt_geglu32 = value; return 0; }
-    if (key == 13) { g_opt_ksplit = value; return 0; }
-    if (key == 23) { g_opt_order = value; return 0; }
-    if (key == 24) { g_opt_skinny = value; return 0; }
-    if (key == 30) { g_opt_g8 = value; return 0; }
-    if (key == 31) { g_opt_g8_tiles = value; return 0; }
-    if (key == 32) return gl8_set_debug(value);
-    if (key == 33) { g_opt_g8_tapmajor = value; return 0; }
-    if (key == 34) { g_opt_g8_minkt = value < 1 ? 1 : value; return 0; }
-    if (key == 35) { g_opt_g8_minnk = value; return 0; }
-    if (key == 5) { g_opt_splitk_tiles = value < 0 ? 300 : value; g_opt_splitk_tiles_conv = value < 0 ? 450 : value; return 0; }   // < 0: defaults
-    if (key == 6) { g_opt_splitk_nk = value; return 0; }
-    return GL_ERR_BAD_ARG;
 }
 
 // measurement hook: per-block cycle stamps of the timestamping 8-wave kernel (gl_set_option(32, 1)); 4 x uint64 per block

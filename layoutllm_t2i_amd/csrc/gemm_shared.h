@@ -109,5 +109,4 @@ __device__ __forceinline__ void finish8(const gl_gemm_args& p, float gate, int m
 int gl8_supported(const gl_gemm_args& g, bool conv, int* bn_out);
 int gl8_launch(const gl_gemm_args& g, const ConvGeom& cg, bool conv, int bn, int zs, int kper, int order_m, hipStream_t st);
 int gl8_init(void);
-int gl8_set_debug(int v);
 int gl8_read_stamps(void* dst, int64_t bytes);

@@ -2,6 +2,7 @@
 // sinusoidal timestep embedding, SiLU, the PLMS/CFG latent update, latent packing, ABI introspection.
 #include "common.h"
 #include "gligen_hip.h"
+#include "opts.h"
 
 namespace {
 
@@ -236,18 +237,40 @@ extern "C" int gl_latent_affine_pack(const float* z, const float* w, const float
 
 extern "C" int gl_init_gemm(void);
 extern "C" int gl_init_ff(void);
-extern "C" int gl_set_option_gemm(int key, int value);
-extern "C" int gl_set_option_attn(int key, int value);
-extern "C" int gl_set_option_norm(int key, int value);
-extern "C" int gl_set_option_engine(int key, int value);
-extern "C" int gl_set_option_ff(int key, int value);
+// ---- option table (opts.h): process defaults, per-thread effective table of the running handle
+static gl_opts make_default_opts() {
+    gl_opts o{};
+    o.v[2] = 0;    o.v[3] = 0;    o.v[4] = 400;  o.v[5] = 300;  o.v[GL_OPT_SPLITK_TILES_CONV] = 450;
+    o.v[6] = 16;   o.v[7] = 300;  o.v[8] = 1;    o.v[10] = -1;  o.v[13] = 3;
+    o.v[16] = 16;  o.v[17] = 1;   o.v[20] = 0;   o.v[21] = 1;   o.v[23] = 1;
+    o.v[24] = 64;  o.v[25] = 1;   o.v[27] = 1;   o.v[29] = 1;   o.v[30] = 1;
+    o.v[31] = 200; o.v[32] = 0;   o.v[33] = 0;   o.v[34] = 11;  o.v[35] = 5;
+    return o;
+}
+gl_opts g_gl_opts = make_default_opts();
+thread_local const gl_opts* tl_gl_opts = nullptr;
 int g_gl_option_epoch = 0;
+
+bool gl_opts_store(gl_opts& t, int key, int value) {
+    switch (key) {
+        case 2: case 3: case 4: case 6: case 7: case 8: case 10: case 13: case 17: case 20: case 21: case 23: case 24: case 25:
+        case 27: case 29: case 30: case 31: case 32: case 33: case 35:
+            t.v[key] = value;
+            return true;
+        case 5:                                  // < 0: the built-in thresholds (plain GEMM 300 tiles, conv 450)
+            t.v[5] = value < 0 ? 300 : value;
+            t.v[GL_OPT_SPLITK_TILES_CONV] = value < 0 ? 450 : value;
+            return true;
+        case 16: t.v[16] = value > 0 ? value : 16; return true;
+        case 34: t.v[34] = value < 1 ? 1 : value; return true;
+        default: return false;
+    }
+}
+
 extern "C" int gl_set_option(int key, int value) {
+    if (key < 0 || key >= GL_OPT_MAX || !gl_opts_store(g_gl_opts, key, value)) return GL_ERR_BAD_ARG;
     ++g_gl_option_epoch;
-    if (key == 16 || key == 17) return gl_set_option_norm(key, value);
-    if (key == 27) return gl_set_option_ff(key, value);
-    if (key == 20 || key == 21 || key == 25) return gl_set_option_engine(key, value);
-    return (key == 3 || key == 10 || key == 29) ? gl_set_option_attn(key, value) : gl_set_option_gemm(key, value);   // 1,2,4-9: GEMM knobs
+    return 0;
 }
 
 extern "C" int gl_abi_version(void) { return GL_ABI_VERSION; }

@@ -10,6 +10,7 @@
 // (bitwise reproducible, no atomics).
 #include "common.h"
 #include "gligen_hip.h"
+#include "opts.h"
 
 namespace {
 
@@ -517,16 +518,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
     }
 }
 
-int g_gn_ppb = 16;  // GroupNorm apply: pixels per pixel-lane per block (A/B knob 16)
-int g_gn_fused = 1; // A/B knob 17: single-launch GroupNorm for small maps
+#define g_gn_ppb gl_opt(16)  // default 16;  // GroupNorm apply: pixels per pixel-lane per block (A/B knob 16)
+#define g_gn_fused gl_opt(17)  // default 1; // A/B knob 17: single-launch GroupNorm for small maps
 
 }  // namespace
-
-extern "C" int gl_set_option_norm(int key, int value) {
-    if (key == 16) { g_gn_ppb = value > 0 ? value : 16; return 0; }
-    if (key == 17) { g_gn_fused = value; return 0; }
-    return GL_ERR_BAD_ARG;
-}
 
 extern "C" int gl_groupnorm_stats(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t B, int32_t HW,
                                   float* partial, int32_t nchunk, void* stream) {

@@ -11,6 +11,7 @@
 // through the 8-wave deep-pipelined kernel wherever its dispatch applies).
 #include "common.h"
 #include "gligen_hip.h"
+#include "opts.h"
 
 #include <cstring>
 #include <map>
@@ -41,6 +42,8 @@ struct gl_vae {
     hipStream_t cap_stream = nullptr;
     int launches = 0;
     int opt_epoch = 0;
+    int ovr_epoch = 0;
+    gl_opt_overrides ovr;              // per-handle option overrides (gl_vae_set_option)
 
     void add(const std::string& n, int dtype, std::initializer_list<int64_t> shp) {
         VW w{};
@@ -78,7 +81,6 @@ struct gl_vae {
     }
 };
 
-extern int g_gl_option_epoch;      // misc.hip
 
 namespace {
 
@@ -337,6 +339,7 @@ extern "C" int gl_vae_load_weights(gl_vae* v, const void* packed, int64_t bytes,
 
 extern "C" int gl_vae_decode(gl_vae* v, const float* z, int32_t B, int32_t side, float* out, int32_t use_graph, void* stream) {
     if (!v || !z || !out || B <= 0 || side <= 0 || !v->wbase) return GL_ERR_BAD_ARG;
+    gl_opts_scope opts_scope(v->ovr);
     const gl_vae_config& c = v->cfg;
     hipStream_t st = (hipStream_t)stream;
     const size_t nz = (size_t)B * c.z_channels * side * side;
@@ -348,7 +351,11 @@ extern "C" int gl_vae_decode(gl_vae* v, const float* z, int32_t B, int32_t side,
     float* obuf = v->f32("out", no);
     VCKP(zin); VCKP(obuf);
     if (hipMemcpyAsync(zin, z, nz * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return GL_ERR_BAD_ARG;
-    if (v->opt_epoch != g_gl_option_epoch) { v->drop_graphs(); v->opt_epoch = g_gl_option_epoch; }
+    if (v->opt_epoch != g_gl_option_epoch || v->ovr_epoch != v->ovr.epoch) {
+        v->drop_graphs();
+        v->opt_epoch = g_gl_option_epoch;
+        v->ovr_epoch = v->ovr.epoch;
+    }
     const auto key = std::make_pair((int)B, (int)side);
     auto it = v->graphs.find(key);
     if (use_graph && it == v->graphs.end()) {
@@ -377,6 +384,15 @@ extern "C" int gl_vae_decode(gl_vae* v, const float* z, int32_t B, int32_t side,
         if (v->pool_changed) { v->drop_graphs(); v->pool_changed = false; }
     }
     if (hipMemcpyAsync(out, obuf, no * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return GL_ERR_BAD_ARG;
+    return 0;
+}
+
+extern "C" int gl_vae_set_option(gl_vae* v, int key, int value) {
+    gl_opts probe{};
+    if (!v || key < 0 || key >= GL_OPT_MAX || !gl_opts_store(probe, key, value)) return GL_ERR_BAD_ARG;
+    v->ovr.mask |= (uint64_t)1 << key;
+    v->ovr.v[key] = value;
+    ++v->ovr.epoch;
     return 0;
 }
 

@@ -58,6 +58,14 @@ class UNetEngine:
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.dev).cuda_stream
 
+    def set_option(self, key: int, value: int) -> None:
+        """Override one gl_set_option knob for THIS engine only (gl_set_handle_option): in effect while its entry points run,
+        invisible to other engines and to op-level calls; its captured graphs are rebuilt on the next forward."""
+        check(self._lib.gl_set_handle_option(self.handle, int(key), int(value)), "gl_set_handle_option")
+
+    def clear_options(self) -> None:
+        check(self._lib.gl_clear_handle_options(self.handle), "gl_clear_handle_options")
+
     # ------------------------------------------------------------------ torch-side scratch (sampler state, outputs)
     def buf(self, tag: str, shape, dtype=F16, zero: bool = False) -> torch.Tensor:
         key = (tag, tuple(shape), dtype)

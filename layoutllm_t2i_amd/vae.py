@@ -90,6 +90,10 @@ class VAEDecoder:
                        "gl_vae_load_weights")
         self.use_graphs = True
 
+    def set_option(self, key: int, value: int) -> None:
+        """Override one gl_set_option knob for THIS decoder only (gl_vae_set_option)."""
+        _lib.check(_lib.lib().gl_vae_set_option(self.handle, int(key), int(value)), "gl_vae_set_option")
+
     def __del__(self):
         h, self.handle = getattr(self, "handle", None), None
         if h:

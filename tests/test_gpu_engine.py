@@ -204,3 +204,59 @@ def test_two_engines_interleaved_and_option_toggles():
     del ea
     torch.cuda.synchronize()
     assert torch.equal(eb.forward(xb, 481.0, 1.0, False, 1), solo_b[0])
+
+
+def test_handle_option_overrides_are_per_engine():
+    """gl_set_handle_option: a knob overridden on ONE engine is in effect only while that engine's entry points run -- the
+    other engine of the process, and op-level calls, keep the process defaults ('two hosts in one process still
+    share tuning state').  Checked with the knob that moves GEMMs / convs to the 8-wave kernel (a different fp32 summation
+    order, so outputs differ in the last bits and the launch counter moves) and with one that changes the launch sequence."""
+    cfg = UNetConfig(image_size=16, model_channels=128, num_heads=8, channel_mult=(1, 2), attention_resolutions=(1, 2), num_res_blocks=1,
+                     context_dim=128, pos_in_dim=64, pos_out_dim=128)
+    dev = torch.device(DEV)
+    P = pack_state_dict(recipe.state_dict(cfg, 3), cfg, dev, recipe.sd_first_conv(cfg, 3))
+    e1, e2 = UNetEngine(P), UNetEngine(P)
+    inp = {k: T(v) for k, v in recipe.synth_inputs(cfg, 3, 24, n_boxes=9, n_rel=4, seed=5).items()}
+    x = inp["x"].to(DEV)
+    for e in (e1, e2):
+        e.set_conditioning(inp["context"], inp["relations"], inp["boxes"], inp["masks"], inp["positive_embeddings"], 24)
+    base = e1.forward(x, 481.0, 1.0, False, 1).clone()
+    assert torch.equal(e2.forward(x, 481.0, 1.0, False, 1), base)
+    # reference for "8-wave kernel wherever it applies": the PROCESS default flipped, then restored
+    ops.set_option(30, 2)
+    try:
+        c0 = ops.gemm8_launch_count()
+        forced = e1.forward(x, 481.0, 1.0, False, 1).clone()
+        n_forced = ops.gemm8_launch_count() - c0
+    finally:
+        ops.set_option(30, 1)
+    assert n_forced > 0 and not torch.equal(forced, base)
+    assert torch.equal(e1.forward(x, 481.0, 1.0, False, 1), base)
+    # the same knob as an override of e2 alone
+    e2.set_option(30, 2)
+    c0 = ops.gemm8_launch_count()
+    e2.use_graphs = False                      # eager: every forward launches (and counts) its kernels
+    assert torch.equal(e2.forward(x, 481.0, 1.0, False, 1), forced)
+    assert ops.gemm8_launch_count() - c0 > 0             # (n_forced counted a warm-up pass + a capture pass)
+    c1 = ops.gemm8_launch_count()
+    e1.use_graphs = False
+    assert torch.equal(e1.forward(x, 481.0, 1.0, False, 1), base)            # e1 still sees the defaults ...
+    a = torch.randn(512, 256, device=DEV).half()
+    w = torch.randn(320, 256, device=DEV).half()
+    ops.gemm(a, w, torch.empty(512, 320, dtype=torch.float16, device=DEV), None)     # ... and so does an op-level call
+    assert ops.gemm8_launch_count() == c1
+    e1.use_graphs = e2.use_graphs = True
+    assert torch.equal(e2.forward(x, 481.0, 1.0, False, 1), forced)           # graph captured under the override
+    assert torch.equal(e1.forward(x, 481.0, 1.0, False, 1), base)
+    # a knob that changes the launch sequence, on e2 only
+    n1 = e1.num_launches()
+    e2.clear_options()
+    assert torch.equal(e2.forward(x, 481.0, 1.0, False, 1), base)
+    assert e2.num_launches() == n1
+    e2.set_option(25, 0)
+    assert torch.equal(e2.forward(x, 481.0, 1.0, False, 1), base) and e2.num_launches() > n1
+    assert torch.equal(e1.forward(x, 481.0, 1.0, False, 1), base) and e1.num_launches() == n1
+    with pytest.raises(Exception):
+        e2.set_option(99, 1)
+    with pytest.raises(Exception):
+        e2.set_option(1, 1)                     # not a knob
