@@ -259,5 +259,11 @@ def test_gligen_inference_run_with_injected_clip(loaded, tmp_path):
     imgs = gi.run(meta, cfg, clip_model=clip, clip_processor=proc)
     assert len(imgs) == 1 and imgs[0].size == (128, 128)
     assert os.path.exists(tmp_path / "t" / "0.png")
+    # the cached model's first_conv_type flips to "SD" during a run (restore_first_conv_from_SD at the first
+    # scale-0 step); run() must reset it, or every later image uses the SD conv from step 0 on.  Same seed -> same image.
+    assert am[0].first_conv_type == "SD"
+    torch.manual_seed(1)
+    again = gi.run(meta, cfg, clip_model=clip, clip_processor=proc)
+    assert np.array_equal(np.asarray(again[0]), np.asarray(imgs[0])), "second run() on the cached model differs from the first"
     with pytest.raises(NotImplementedError):
         gi.run(meta, dict(cfg, no_plms=True), clip_model=clip, clip_processor=proc)
