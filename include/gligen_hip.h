@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GL_ABI_VERSION 10
+#define GL_ABI_VERSION 11
 
 /* error codes (negative; positive values are hipError_t) */
 #define GL_ERR_BAD_ARG (-1)
@@ -397,6 +397,26 @@ int gl_clip_embed_tokens(const int32_t* ids, const float* tok_emb, const float* 
 int gl_clip_gather_rows(const float* x, int32_t ldx, const int32_t* rows, int32_t B, int32_t C, float* out, void* stream);
 int gl_attention_small(const void* q, const void* k, const void* v, int32_t ld, int32_t B, int32_t T, int32_t H, int32_t d,
                        float scale, int32_t causal, void* out, int32_t ldo, void* stream);
+
+/* ---- image preprocessing of the reward stage (models/policy.py:108-111: self.processor(images=...), the HuggingFace CLIP
+ * feature extractor on PIL images; transformers 4.19.2 image_utils + Pillow) -- on the GPU, so rollout images stay in HBM
+ * between the VAE decoder and the CLIP vision tower.
+ *   gl_image_to_u8      decoded image fp32 [B, 3, H, W] in [-1, 1] -> uint8 [B, H, W, 3] with the arithmetic of
+ *                       GLIGEN/interface.py:543-547 (clamp, * 0.5 + 0.5, * 255, truncation): the pixels of the PIL image there
+ *   gl_resample_h_u8    Pillow's horizontal BICUBIC pass (src/libImaging/Resample.c ImagingResampleHorizontal_8bpc), bit-exact:
+ *                       out[b, y, xx, c] = clip8((2^21 + sum_{k < bounds[xx][1]} in[b, y, bounds[xx][0] + k, c] * coeffs[xx][k]) >> 22);
+ *                       bounds int32 [Wout, 2] and coeffs int32 [Wout, ksize] are DEVICE arrays built by the host
+ *                       (layoutllm_t2i_amd/preprocess.py: Pillow's precompute_coeffs + normalize_coeffs_8bpc in float64)
+ *   gl_resample_v_norm  Pillow's vertical pass on that 8-bit intermediate, restricted to the centre-crop window
+ *                       [top, top + crop_h) x [left, left + crop_w) of the resized image, followed by the feature extractor's
+ *                       float32(u8) / 255 -> (x - mean) / std -> channels first: fp32 [B, 3, crop_h, crop_w] (out_nchw) and / or the
+ *                       cropped uint8 pixels [B, crop_h, crop_w, 3] (out_u8_hwc, for tests); mean3 / std3 are HOST pointers (3 floats). */
+int gl_image_to_u8(const float* img_nchw, int32_t B, int32_t H, int32_t W, uint8_t* out_hwc, void* stream);
+int gl_resample_h_u8(const uint8_t* in, int32_t B, int32_t H, int32_t W, const int32_t* bounds, const int32_t* coeffs, int32_t ksize,
+                     int32_t Wout, uint8_t* out, void* stream);
+int gl_resample_v_norm(const uint8_t* in, int32_t B, int32_t H, int32_t W, const int32_t* bounds, const int32_t* coeffs, int32_t ksize,
+                       int32_t Hout, int32_t top, int32_t left, int32_t crop_h, int32_t crop_w, const float* mean3, const float* std3,
+                       float* out_nchw, uint8_t* out_u8_hwc, void* stream);
 
 /* introspection: ABI version and struct sizes (checked by the host loader) */
 int gl_abi_version(void);

@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgligen_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 # enum gl_epilogue / gl_out_mode
 EPI_BIAS, EPI_SILU, EPI_GEGLU, EPI_RES, EPI_GATE_RES, EPI_ROWBIAS = range(6)
@@ -162,6 +162,9 @@ PROTOTYPES = {
     "gl_ff_fused_supported": (i32, [i32]),
     "gl_ff_fused_applicable": (i32, [i32, i32]),
     "gl_sizeof_ff_args": (i32, []),
+    "gl_image_to_u8": (i32, [vp, i32, i32, i32, vp, vp]),
+    "gl_resample_h_u8": (i32, [vp, i32, i32, i32, vp, vp, i32, i32, vp, vp]),
+    "gl_resample_v_norm": (i32, [vp, i32, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     "gl_set_option": (i32, [i32, i32]),
     "gl_set_handle_option": (i32, [vp, i32, i32]),
     "gl_clear_handle_options": (i32, [vp]),

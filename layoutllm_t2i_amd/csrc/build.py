@@ -16,7 +16,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 REPO = os.path.dirname(PKG)
-SOURCES = ["gemm_conv.hip", "gemm8.hip", "attention.hip", "norms.hip", "rela.hip", "misc.hip", "engine.hip", "reward.hip", "ff_fused.hip", "clip.hip", "vae_engine.hip"]
+SOURCES = ["gemm_conv.hip", "gemm8.hip", "attention.hip", "norms.hip", "rela.hip", "misc.hip", "engine.hip", "reward.hip", "ff_fused.hip", "clip.hip", "preprocess.hip", "vae_engine.hip"]
 LIB = os.path.join(PKG, "libgligen_hip.so")
 OBJDIR = os.path.join(HERE, "build")
 

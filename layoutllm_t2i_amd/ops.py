@@ -486,3 +486,58 @@ def attention_small(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, ld: int, 
     check(_lib.lib().gl_attention_small(q.data_ptr(), k.data_ptr(), v.data_ptr(), ld, B, T, H, d, scale, int(causal), out.data_ptr(),
                                         _rows(out, "out")[2], _stream()), "gl_attention_small")
     return out
+
+
+# ------------------------------------------------------------------------------------------- reward-stage image preprocessing
+def image_to_u8(img: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """decoded image fp32 [B, 3, H, W] -> uint8 [B, H, W, 3] (interface.py:543-547 arithmetic)."""
+    _req(img, F32, "img")
+    B, c3, H, W = img.shape
+    if c3 != 3 or not img.is_contiguous() or out.dtype != torch.uint8 or tuple(out.shape) != (B, H, W, 3) or not out.is_contiguous():
+        raise ValueError("img must be contiguous fp32 [B, 3, H, W] and out contiguous uint8 [B, H, W, 3]")
+    check(_lib.lib().gl_image_to_u8(img.data_ptr(), B, H, W, out.data_ptr(), _stream()), "gl_image_to_u8")
+    return out
+
+
+def _req_tables(bounds: torch.Tensor, coeffs: torch.Tensor, n_out: int, ksize: int) -> None:
+    if bounds.dtype != torch.int32 or coeffs.dtype != torch.int32 or not bounds.is_cuda or not coeffs.is_cuda:
+        raise ValueError("bounds / coeffs must be int32 tensors on the GPU")
+    if tuple(bounds.shape) != (n_out, 2) or tuple(coeffs.shape) != (n_out, ksize) or not bounds.is_contiguous() or not coeffs.is_contiguous():
+        raise ValueError("bounds must be [n_out, 2] and coeffs [n_out, ksize], contiguous")
+
+
+def resample_h_u8(x: torch.Tensor, bounds: torch.Tensor, coeffs: torch.Tensor, ksize: int, out: torch.Tensor) -> torch.Tensor:
+    """Pillow's horizontal 8-bit resampling pass: uint8 [B, H, W, 3] -> uint8 [B, H, Wout, 3]."""
+    if x.dtype != torch.uint8 or out.dtype != torch.uint8 or not x.is_cuda or not out.is_cuda or not x.is_contiguous() or not out.is_contiguous():
+        raise ValueError("x / out must be contiguous uint8 tensors on the GPU")
+    B, H, W, _ = x.shape
+    Wout = out.shape[2]
+    if tuple(out.shape) != (B, H, Wout, 3):
+        raise ValueError("out must be [B, H, Wout, 3]")
+    _req_tables(bounds, coeffs, Wout, ksize)
+    check(_lib.lib().gl_resample_h_u8(x.data_ptr(), B, H, W, bounds.data_ptr(), coeffs.data_ptr(), ksize, Wout, out.data_ptr(), _stream()),
+          "gl_resample_h_u8")
+    return out
+
+
+def resample_v_norm(x: torch.Tensor, bounds: torch.Tensor, coeffs: torch.Tensor, ksize: int, Hout: int, top: int, left: int, crop_h: int,
+                    crop_w: int, mean, std, out: Optional[torch.Tensor], out_u8: Optional[torch.Tensor] = None):
+    """Pillow's vertical pass inside the centre-crop window + /255, (x - mean) / std, channels first."""
+    import ctypes
+
+    import numpy as np
+    if x.dtype != torch.uint8 or not x.is_cuda or not x.is_contiguous():
+        raise ValueError("x must be a contiguous uint8 tensor on the GPU")
+    B, H, W, _ = x.shape
+    _req_tables(bounds, coeffs, Hout, ksize)
+    if out is not None and (out.dtype != F32 or tuple(out.shape) != (B, 3, crop_h, crop_w) or not out.is_contiguous()):
+        raise ValueError("out must be contiguous fp32 [B, 3, crop_h, crop_w]")
+    if out_u8 is not None and (out_u8.dtype != torch.uint8 or tuple(out_u8.shape) != (B, crop_h, crop_w, 3) or not out_u8.is_contiguous()):
+        raise ValueError("out_u8 must be contiguous uint8 [B, crop_h, crop_w, 3]")
+    m = np.ascontiguousarray(mean, dtype=np.float32)
+    s_ = np.ascontiguousarray(std, dtype=np.float32)
+    check(_lib.lib().gl_resample_v_norm(x.data_ptr(), B, H, W, bounds.data_ptr(), coeffs.data_ptr(), ksize, Hout, top, left, crop_h, crop_w,
+                                        m.ctypes.data_as(ctypes.c_void_p), s_.ctypes.data_as(ctypes.c_void_p),
+                                        out.data_ptr() if out is not None else None, out_u8.data_ptr() if out_u8 is not None else None,
+                                        _stream()), "gl_resample_v_norm")
+    return out
