@@ -209,11 +209,14 @@ def main():
 
     vae_events = []
     # configs[4] (train_rl rollout): the reward stage runs after the decode, as Reward_Model.forward does (models/policy.py:106-135):
-    # decoded images -> uint8 -> the HF CLIP image processor on the HOST (PIL bicubic resize 512 -> 224, crop, normalise: the
-    # reference's own CPU step) -> CLIP ViT-L/14 vision tower (HIP) on the 16 predictions and the 16 ground-truth images, text tower
-    # (HIP) on the 16 captions -> similarities + AestheticMLP (gl_reward_score).  Random-init towers of the ViT-L/14 architecture.
+    # decoded images -> uint8 (interface.py:543-547) -> the CLIP feature extractor's PIL-bicubic resize 512 -> 224, crop, normalise ON THE
+    # GPU (preprocess.py: Pillow's fixed-point algorithm bit for bit; the 16 ground-truth images arrive as host uint8 480 x 640 arrays,
+    # like dataset images, and take the same kernels after one upload) -> CLIP ViT-L/14 vision tower (HIP) on the 16 predictions and the
+    # 16 ground-truth images, text tower (HIP) on the 16 captions -> similarities + AestheticMLP (gl_reward_score).  Random-init towers
+    # of the ViT-L/14 architecture.  The first step also runs the reference's host path (HF processor on the CPU) once: the GPU
+    # pixel_values must equal it bitwise, and its time is reported beside the GPU one.
     scorer, score_events, score_in = None, [], None
-    reward_stage_ms = {"processor_cpu": [], "clip_towers": [], "score": []}
+    reward_stage_ms = {"processor_cpu": [], "preprocess_equal": []}
     if cnum == 5 and not args.tiny:
         from layoutllm_t2i_amd.reward import RewardModel
         gsc = torch.Generator(device=dev)
@@ -229,14 +232,15 @@ def main():
             processor = CLIPImageProcessor()
         except Exception as e:                                   # pragma: no cover
             raise SystemExit(f"--config 5 needs transformers' CLIPImageProcessor for the host-side preprocessing step: {e}")
-        gt_pixels = torch.randn(B, 3, 224, 224, device=dev, generator=gsc)              # processed ground-truth images
+        import numpy as _np
+        gt_u8 = _np.random.default_rng(7 + rank).integers(0, 256, (B, 480, 640, 3), dtype=_np.uint8)       # ground-truth images (host, dataset-like)
         cap_ids = torch.randint(1, 49406, (B, 77), device=dev, generator=gsc)
         cap_ids[:, 0] = 49406
         for b_ in range(B):
             L_ = 8 + (b_ * 5) % 40
             cap_ids[b_, L_] = 49407
             cap_ids[b_, L_ + 1:] = 49407
-        score_in = (cap_ids, gt_pixels, processor)
+        score_in = (cap_ids, gt_u8, processor)
 
     def one_step():
         model.first_conv_type = "GLIGEN"
@@ -250,13 +254,11 @@ def main():
         e1.record()
         vae_events.append((e0, e1))
         if scorer is not None:
-            cap_ids, gt_pixels, processor = score_in
-            torch.cuda.synchronize()        # (the .cpu() below would wait for the queued denoise + decode anyway; keep it out of the host timer)
-            tc = time.time()
-            u8 = ((torch.clamp(img, -1, 1) * 0.5 + 0.5).cpu().numpy().transpose(0, 2, 3, 1) * 255).astype("uint8")     # interface.py:543-547
-            px = processor(images=[u for u in u8], return_tensors="pt")["pixel_values"].to(dev)
-            reward_stage_ms["processor_cpu"].append((time.time() - tc) * 1e3)
-            s0, s1, s2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            cap_ids, gt_u8, processor = score_in
+            sp, s0, s1, s2 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
+            sp.record()
+            px = scorer.preprocess.from_decoded(img)
+            gt_pixels = scorer.preprocess(torch.from_numpy(gt_u8).to(dev))
             s0.record()
             txt = scorer.towers.get_text_features(cap_ids)
             fp = scorer.towers.get_image_features(px)
@@ -264,7 +266,7 @@ def main():
             s1.record()
             sc = scorer.scorer.score(txt, fp, fg)
             s2.record()
-            score_events.append((s0, s1, s2))
+            score_events.append((sp, s0, s1, s2))
             assert sc["reward"].shape == (B,) and bool(torch.isfinite(sc["reward"]).all())
         return img
 
@@ -286,6 +288,18 @@ def main():
     sync()
     elapsed = time.time() - t1
     assert torch.isfinite(out).all(), "non-finite latents"
+    if scorer is not None:
+        # outside the timed region: the reference's host path (HF processor on the CPU) once on the last batch -- the GPU
+        # pixel_values must equal it bitwise; its time is reported beside the GPU preprocessing time
+        cap_ids, gt_u8, processor = score_in
+        torch.cuda.synchronize()
+        tc = time.time()
+        u8 = ((torch.clamp(out, -1, 1) * 0.5 + 0.5).cpu().numpy().transpose(0, 2, 3, 1) * 255).astype("uint8")     # interface.py:543-547
+        px_host = processor(images=[u for u in u8] + [g for g in gt_u8], return_tensors="pt")["pixel_values"]
+        reward_stage_ms["processor_cpu"].append((time.time() - tc) * 1e3)
+        px_gpu = torch.cat([scorer.preprocess.from_decoded(out), scorer.preprocess(torch.from_numpy(gt_u8).to(dev))], 0)
+        reward_stage_ms["preprocess_equal"].append(bool(torch.equal(px_gpu.cpu(), px_host)))
+        assert reward_stage_ms["preprocess_equal"][-1], "GPU image preprocessing differs from the host CLIP processor"
     if multi:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -355,14 +369,17 @@ def main():
         "step_includes": f"PLMS denoise ({args.plms_steps + 1} x gl_plms_step: 2B UNet forward + CFG + update)" + (" + VAE decode to fp32 images" if vae is not None else "") + (" + reward scoring (gl_reward_score)" if scorer is not None else ""),
         "launches_per_forward": eng.num_launches(),
         "images_per_sec_per_gpu": round(value / world, 4),
-        "reward_score_ms_per_batch": (round(sum(a.elapsed_time(c) for a, b, c in score_events) / max(len(score_events), 1), 3) if score_events else None),
-        "reward_stage_ms": ({"clip_towers(text 16 + vision 2x16, HIP)": round(sum(a.elapsed_time(b) for a, b, c in score_events) / len(score_events), 3),
-                             "similarities+aesthetic (gl_reward_score)": round(sum(b.elapsed_time(c) for a, b, c in score_events) / len(score_events), 3),
-                             "image processor (host CPU, PIL, as the reference)": round(sum(reward_stage_ms["processor_cpu"][-len(score_events):]) / len(score_events), 1)}
+        "reward_score_ms_per_batch": (round(sum(a.elapsed_time(d) for a, b, c, d in score_events) / max(len(score_events), 1), 3) if score_events else None),
+        "reward_stage_ms": ({"image preprocessing (HIP: uint8 + PIL-exact bicubic 512->224 of 16 predictions; upload + 480x640->224 of 16 ground-truth images)":
+                             round(sum(a.elapsed_time(b) for a, b, c, d in score_events) / len(score_events), 3),
+                             "clip_towers(text 16 + vision 2x16, HIP)": round(sum(b.elapsed_time(c) for a, b, c, d in score_events) / len(score_events), 3),
+                             "similarities+aesthetic (gl_reward_score)": round(sum(c.elapsed_time(d) for a, b, c, d in score_events) / len(score_events), 3),
+                             "reference host path of the preprocessing (HF CLIP processor, PIL, CPU; once, outside the timed region)": round(reward_stage_ms["processor_cpu"][-1], 1),
+                             "gpu_pixel_values_equal_host_processor_bitwise": reward_stage_ms["preprocess_equal"][-1]}
                             if score_events else None),
-        "reward_score_note": ("Reward_Model.forward's GPU part on the decoded images: host image processor -> CLIP ViT-L/14 towers (random-init, "
-                              "HIP) on 16 predictions + 16 ground-truth images + 16 captions -> similarities + AestheticMLP; the CPU layout "
-                              "rewards (IoU / DocSim, policy.py:126-133) are the caller's and not timed" if score_events else None),
+        "reward_score_note": ("Reward_Model.forward's GPU part on the decoded images: uint8 + CLIP feature-extractor preprocessing (HIP) -> CLIP "
+                              "ViT-L/14 towers (random-init, HIP) on 16 predictions + 16 ground-truth images + 16 captions -> similarities + "
+                              "AestheticMLP; the CPU layout rewards (IoU / DocSim, policy.py:126-133) are the caller's and not timed" if score_events else None),
         "roofline": roofline,
         "setup_s": round(setup_s, 1),
     }

@@ -74,11 +74,14 @@ class RewardModel:
     similarities + aesthetic score -> reward.  ``clip_state_dict`` = ``transformers.CLIPModel.state_dict()`` of the model
     policy.py:40 loads, ``aesthetic_state_dict`` = the AestheticMLP checkpoint (policy.py:44-46)."""
 
-    def __init__(self, clip_state_dict, aesthetic_state_dict, device="cuda:0", vision_heads: int = 16, text_heads: int = 12):
+    def __init__(self, clip_state_dict, aesthetic_state_dict, device="cuda:0", vision_heads: int = 16, text_heads: int = 12, image_size: int = 224):
         from .clip import ClipTowers
         self.towers = ClipTowers(clip_state_dict, vision_heads, text_heads, device)
         self.scorer = RewardScorer(aesthetic_state_dict, device, input_size=int(self.towers.vproj.shape[0]))
         self.device = self.towers.device
+        from .preprocess import ClipImagePreprocessor
+        # self.processor(images=...) of policy.py:109,111, on the GPU (image_size = the checkpoint's vision_config.image_size)
+        self.preprocess = ClipImagePreprocessor(size=image_size, crop_size=image_size, device=self.device)
 
     @torch.no_grad()
     def forward(self, input_ids, pixel_values_pred, pixel_values_gt, attention_mask=None, miou=None, laysim=None) -> dict:
@@ -90,5 +93,23 @@ class RewardModel:
         out = self.scorer.score(txt, pred, gt, miou, laysim)
         out.update(txt_features=txt, img_pred_features=pred, img_gt_features=gt)
         return out
+
+    @torch.no_grad()
+    def forward_images(self, input_ids, images_pred, images_gt, attention_mask=None, miou=None, laysim=None) -> dict:
+        """``forward`` from IMAGES, as the reference's takes them (policy.py:106-111): ``images_pred`` is the VAE decoder's fp32
+        output [B, 3, H, W] still on the GPU (converted to the uint8 pixels of interface.py:543-547 there), a uint8 [B, H, W, 3]
+        GPU tensor, or a list of PIL images; ``images_gt`` a list of PIL images / uint8 arrays of any sizes, or ready
+        ``pixel_values``.  The CLIP feature extractor's resize / crop / normalise runs on the GPU (preprocess.py), bit-identical
+        to the PIL path."""
+        def px(im):
+            if torch.is_tensor(im) and im.dtype == torch.float32 and im.dim() == 4 and im.shape[1] == 3 and im.shape[-1] == self.preprocess.crop \
+                    and im.shape[-2] == self.preprocess.crop:
+                return im                                           # already pixel_values
+            if torch.is_tensor(im) and im.dtype == torch.uint8:
+                return self.preprocess(im.to(self.device))
+            if torch.is_tensor(im):
+                return self.preprocess.from_decoded(im)
+            return self.preprocess.from_pil(im)
+        return self.forward(input_ids, px(images_pred), px(images_gt), attention_mask, miou, laysim)
 
     __call__ = forward

@@ -153,3 +153,30 @@ def test_reward_model_forward_vs_oracle_pipeline():
         d = float((out[k].cpu() - ref[k]).abs().max())
         print(f"[reward model] {k}: max|diff|={d:.3e} |ref|max={float(ref[k].abs().max()):.3f}")
         assert d < 5e-3 * max(1.0, float(ref[k].abs().max())), (k, d)
+
+
+@pytest.mark.gpu
+def test_reward_model_from_images_equals_the_pixel_values_path():
+    """forward_images: decoded fp32 predictions (GPU) and mixed-size ground-truth images go through the HIP preprocessing
+    (uint8 conversion, Pillow-exact bicubic resize, crop, normalise) -- the rewards must equal, BITWISE, forward() on the
+    pixel_values the CPU restatement of the reference's feature extractor produces for the same images."""
+    from layoutllm_t2i_amd.reward import RewardModel
+    from oracle import clip_preprocess_ref as ppref
+    z, sd = golden()
+    heads, D = int(z["heads"]), 64
+    shapes = {0: (1024, D), 2: (128, 1024), 4: (64, 128), 6: (16, 64), 7: (1, 16)}
+    aes = {}
+    for li, (n, k) in shapes.items():
+        aes[f"layers.{li}.weight"] = T(recipe.uniform(f"aes.{li}.w", (n, k), 2)) * float(np.sqrt(3.0 / k))
+        aes[f"layers.{li}.bias"] = T(recipe.uniform(f"aes.{li}.b", (n,), 2)) * 0.1
+    rm = RewardModel(sd, aes, vision_heads=heads, text_heads=heads, image_size=42)
+    ids = T(z["input_ids"])[:3]
+    dec = T(recipe.normal("decoded", (3, 3, 96, 96), 9)) * 0.8
+    rng = np.random.default_rng(5)
+    gts = [rng.integers(0, 256, s_, dtype=np.uint8) for s_ in ((60, 80, 3), (96, 96, 3), (60, 80, 3))]
+    out = rm.forward_images(ids, dec.to("cuda:0"), gts)
+    px_pred = np.stack([ppref.clip_feature_extractor(u, 42, 42)[0] for u in ppref.decoded_to_u8(dec)])
+    px_gt = np.stack([ppref.clip_feature_extractor(g, 42, 42)[0] for g in gts])
+    want = rm(ids, T(px_pred), T(px_gt))
+    for k in ("sims_ti", "sims_ii", "aes_reward", "reward"):
+        assert torch.equal(out[k], want[k]), k
