@@ -261,8 +261,8 @@ def main():
             gt_pixels = scorer.preprocess(torch.from_numpy(gt_u8).to(dev))
             s0.record()
             txt = scorer.towers.get_text_features(cap_ids)
-            fp = scorer.towers.get_image_features(px)
-            fg = scorer.towers.get_image_features(gt_pixels)
+            fboth = scorer.towers.get_image_features(torch.cat([px, gt_pixels], 0))      # one pass over predictions + ground truth, as RewardModel.forward
+            fp, fg = fboth[:B], fboth[B:]
             s1.record()
             sc = scorer.scorer.score(txt, fp, fg)
             s2.record()

@@ -83,22 +83,28 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
     for (int c = threadIdx.x; c < C; c += blockDim.x) out[(size_t)b * C + c] = x[r * ldx + c];
 }
 
-// One block per (batch, head): K and V of the head staged in LDS as fp32, one thread per query row, fp32 scores.
-// T <= 128, d <= 64: 2 * 128 * 64 * 4 = 64 KiB of LDS at most.  The text tower runs 77 tokens x 12 heads x 12 layers of this
-// per caption -- microseconds; exactness (fp32 softmax, fp32 accumulation) matters more than speed here.
+// One block per (batch, head): K and V of the head staged in LDS as fp32 rows of DS = d rounded up to 4 floats (zero-filled),
+// one thread per query row, fp32 scores.  Every lane reads the SAME K / V row (an LDS broadcast, no bank conflicts), as
+// 16-byte ds_read_b128 with four independent partial sums per dot product: the first version read one float per FMA in one
+// dependent chain and ran at LDS latency (650 us per launch at T = 77, d = 64; this form: see DESIGN.md).
+// T <= 128, d <= 64: 2 * 128 * 64 * 4 = 64 KiB of LDS at most.  Exactness (fp32 softmax, fp32 accumulation, two passes so no
+// rescaling) matters more than speed here.
 constexpr int AS_MAXT = 128, AS_MAXD = 64;
 __global__ __launch_bounds__(128) void attention_small_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k,
                                                               const half_t* __restrict__ v, int ld, int T, int H, int d, float scale,
                                                               int causal, half_t* __restrict__ out, int ldo) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* Ks = sm;                 // [T][d + 1]
-    float* Vs = sm + T * (d + 1);   // [T][d + 1]
+    const int DS = (d + 3) & ~3;
+    const int n4 = DS >> 2;
+    float* Ks = sm;                 // [T][DS]
+    float* Vs = sm + T * DS;        // [T][DS]
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
     const size_t base = (size_t)b * T * ld + (size_t)h * d;
-    for (int i = threadIdx.x; i < T * d; i += blockDim.x) {
-        const int t = i / d, c = i - t * d;
-        Ks[t * (d + 1) + c] = (float)k[base + (size_t)t * ld + c];
-        Vs[t * (d + 1) + c] = (float)v[base + (size_t)t * ld + c];
+    for (int i = threadIdx.x; i < T * DS; i += blockDim.x) {
+        const int t = i / DS, c = i - t * DS;
+        const bool in = c < d;
+        Ks[i] = in ? (float)k[base + (size_t)t * ld + c] : 0.0f;
+        Vs[i] = in ? (float)v[base + (size_t)t * ld + c] : 0.0f;
     }
     __syncthreads();
     const int tq = threadIdx.x;
@@ -107,29 +113,40 @@ __global__ __launch_bounds__(128) void attention_small_kernel(const half_t* __re
 #pragma unroll
     for (int c = 0; c < AS_MAXD; ++c) qr[c] = (c < d) ? (float)q[base + (size_t)tq * ld + c] * scale : 0.0f;
     const int nk = causal ? tq + 1 : T;
+    auto dot = [&](int j) -> float {
+        const float4* kr = reinterpret_cast<const float4*>(Ks + j * DS);
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+#pragma unroll
+        for (int c4 = 0; c4 < AS_MAXD / 4; ++c4)
+            if (c4 < n4) {
+                const float4 kv = kr[c4];
+                s0 = fmaf(qr[4 * c4], kv.x, s0);
+                s1 = fmaf(qr[4 * c4 + 1], kv.y, s1);
+                s2 = fmaf(qr[4 * c4 + 2], kv.z, s2);
+                s3 = fmaf(qr[4 * c4 + 3], kv.w, s3);
+            }
+        return (s0 + s1) + (s2 + s3);
+    };
     // pass 1: row max; pass 2: exp / sum / weighted V (scores are recomputed: 2 x T x d FMAs per thread, nothing to store)
     float m = -INFINITY;
-    for (int j = 0; j < nk; ++j) {
-        float s = 0.0f;
-#pragma unroll
-        for (int c = 0; c < AS_MAXD; ++c)
-            if (c < d) s = fmaf(qr[c], Ks[j * (d + 1) + c], s);
-        m = fmaxf(m, s);
-    }
+    for (int j = 0; j < nk; ++j) m = fmaxf(m, dot(j));
     float acc[AS_MAXD];
 #pragma unroll
     for (int c = 0; c < AS_MAXD; ++c) acc[c] = 0.0f;
     float l = 0.0f;
     for (int j = 0; j < nk; ++j) {
-        float s = 0.0f;
-#pragma unroll
-        for (int c = 0; c < AS_MAXD; ++c)
-            if (c < d) s = fmaf(qr[c], Ks[j * (d + 1) + c], s);
-        const float p = __expf(s - m);
+        const float p = __expf(dot(j) - m);
         l += p;
+        const float4* vr = reinterpret_cast<const float4*>(Vs + j * DS);
 #pragma unroll
-        for (int c = 0; c < AS_MAXD; ++c)
-            if (c < d) acc[c] = fmaf(p, Vs[j * (d + 1) + c], acc[c]);
+        for (int c4 = 0; c4 < AS_MAXD / 4; ++c4)
+            if (c4 < n4) {
+                const float4 vv = vr[c4];
+                acc[4 * c4] = fmaf(p, vv.x, acc[4 * c4]);
+                acc[4 * c4 + 1] = fmaf(p, vv.y, acc[4 * c4 + 1]);
+                acc[4 * c4 + 2] = fmaf(p, vv.z, acc[4 * c4 + 2]);
+                acc[4 * c4 + 3] = fmaf(p, vv.w, acc[4 * c4 + 3]);
+            }
     }
     const float inv = 1.0f / l;
     half_t* o = out + (size_t)(b * T + tq) * ldo + (size_t)h * d;
@@ -176,9 +193,9 @@ extern "C" int gl_clip_gather_rows(const float* x, int32_t ldx, const int32_t* r
 extern "C" int gl_attention_small(const void* q, const void* k, const void* v, int32_t ld, int32_t B, int32_t T, int32_t H, int32_t d,
                                   float scale, int32_t causal, void* out, int32_t ldo, void* stream) {
     if (!q || !k || !v || !out || B <= 0 || H <= 0 || T <= 0 || T > AS_MAXT || d <= 0 || d > AS_MAXD) return GL_ERR_BAD_ARG;
-    const size_t lds = (size_t)2 * T * (d + 1) * sizeof(float);
+    const size_t lds = (size_t)2 * T * ((d + 3) & ~3) * sizeof(float);
     if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)attention_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                2 * AS_MAXT * (AS_MAXD + 1) * (int)sizeof(float)) != hipSuccess) return GL_ERR_UNSUPPORTED;
+                                                2 * AS_MAXT * AS_MAXD * (int)sizeof(float)) != hipSuccess) return GL_ERR_UNSUPPORTED;
     attention_small_kernel<<<dim3(B * H), dim3(128), lds, (hipStream_t)stream>>>(
         reinterpret_cast<const half_t*>(q), reinterpret_cast<const half_t*>(k), reinterpret_cast<const half_t*>(v), ld, T, H, d, scale, causal,
         reinterpret_cast<half_t*>(out), ldo);

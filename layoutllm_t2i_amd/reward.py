@@ -88,8 +88,14 @@ class RewardModel:
         """``input_ids`` [B, T] (tokenizer output), ``pixel_values_*`` [B, 3, S, S] (processor output); returns the dict of
         RewardScorer.score plus the three feature tensors."""
         txt = self.towers.get_text_features(input_ids, attention_mask)
-        pred = self.towers.get_image_features(pixel_values_pred)
-        gt = self.towers.get_image_features(pixel_values_gt)
+        pp_, pg_ = torch.as_tensor(pixel_values_pred), torch.as_tensor(pixel_values_gt)
+        if pp_.shape[1:] == pg_.shape[1:]:
+            # one pass of the vision tower over predictions + ground truth (rows are independent; twice the rows per GEMM)
+            both = self.towers.get_image_features(torch.cat([pp_.to(self.device), pg_.to(self.device)], 0))
+            pred, gt = both[:pp_.shape[0]], both[pp_.shape[0]:]
+        else:
+            pred = self.towers.get_image_features(pp_)
+            gt = self.towers.get_image_features(pg_)
         out = self.scorer.score(txt, pred, gt, miou, laysim)
         out.update(txt_features=txt, img_pred_features=pred, img_gt_features=gt)
         return out

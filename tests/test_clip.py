@@ -100,6 +100,15 @@ def test_hip_towers_match_transformers_golden():
     print(f"[clip_tiny vs transformers] image rel_l2={ri:.3e} text rel_l2={rt:.3e}")
     assert img.shape == z["image_features"].shape and txt.dtype == torch.float32
     assert ri < 3e-3 and rt < 3e-3, (ri, rt)            # fp16 matrix operands incl. fp16-rounded weights, fp32 stream
+    # captured-graph replays (the default) == the eager launch sequence, bitwise, also on new inputs of the same shape
+    px2 = T(z["pixel_values"]).flip(0) * 0.5
+    ids2 = T(z["input_ids"]).flip(0)
+    g_img, g_txt, g_img2, g_txt2 = img, txt, tw.get_image_features(px2), tw.get_text_features(ids2)
+    assert ("v", px2.shape[0], px2.shape[-1]) in tw._graphs and ("t",) + tuple(ids2.shape) in tw._graphs
+    tw.use_graphs = False
+    assert torch.equal(tw.get_image_features(T(z["pixel_values"])), g_img) and torch.equal(tw.get_text_features(T(z["input_ids"])), g_txt)
+    assert torch.equal(tw.get_image_features(px2), g_img2) and torch.equal(tw.get_text_features(ids2), g_txt2)
+    assert not torch.equal(g_img, g_img2)
 
 
 @pytest.mark.gpu
