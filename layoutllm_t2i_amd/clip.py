@@ -136,6 +136,8 @@ class ClipTowers:
         buffer) and captures it on a side stream; later calls copy the input into the static buffer and replay."""
         g = self._graphs.get(key)
         if g is None:
+            if len(self._graphs) >= 16:                         # a host that keeps changing batch sizes: do not hoard graphs
+                self._graphs.clear()
             buf = static_in.clone()
             fn(buf)                                             # warm-up: pool allocations, LDS attributes
             torch.cuda.synchronize(self.device)

@@ -136,6 +136,9 @@ class ClipImagePreprocessor:
     def from_pil(self, images) -> torch.Tensor:
         """list of PIL images / uint8 HWC arrays of ANY sizes (ground-truth images): grouped by size, order preserved."""
         arrs = [np.asarray(im.convert("RGB") if hasattr(im, "convert") else im, dtype=np.uint8) for im in images]
+        for a in arrs:
+            if a.ndim != 3 or a.shape[2] != 3:
+                raise ValueError(f"images must be RGB (PIL images are converted; arrays must be uint8 [H, W, 3]), got {a.shape}")
         out = torch.empty(len(arrs), 3, self.crop, self.crop, dtype=torch.float32, device=self.device)
         groups: Dict[Tuple[int, int], list] = {}
         for i, a in enumerate(arrs):
