@@ -436,7 +436,8 @@ int gl_sizeof_attn_args(void);
  * also writes the following LayerNorm (1, default) or a separate gl_layernorm launch does (0); key 27 = fused FeedForward where applicable (1, default) or never (0); key 29 =
  * attention keeps the running max in the padding column of Q / K where the head dim leaves one (d % 16 == 8; 1 default, 0 off);
  * key 30 = 8-wave deep-pipelined 256-row GEMM / conv kernel (0 off, 1 default: problems with at least key-31 (200) such tiles,
- * 2 wherever it applies, with split-K); key 32 = (measurement) its timestamping instantiation, see gl_debug_read. */
+ * 2 wherever it applies, with split-K); key 32 = (measurement) its timestamping instantiation, see gl_debug_read; keys 33-35, 37 = its K order
+ * / split-K slice length / minimum K / use on short-K multi-round grids that fill >= 80 % of their rounds (1 default). */
 int gl_set_option(int key, int value);
 /* gl_set_option writes the PROCESS defaults (op-level calls and every handle without an override see them).  A handle can
  * override individual keys for itself: while one of ITS entry points (gl_set_conditioning / gl_unet_forward / gl_plms_step,

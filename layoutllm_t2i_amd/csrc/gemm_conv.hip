@@ -51,6 +51,7 @@ namespace {
                              // tap-major re-fetches the input 9x from beyond L2 once a level's slab outgrows the 4 MiB L2 (r3 PMC)
 #define g_opt_g8_minkt gl_opt(34)  // default 11;     // split-K of the 8-wave kernel: at least this many K-tiles per slice
 std::atomic<uint64_t> g8_launches{0};   // launches that went to the 8-wave kernel (tests read it: gl_debug_read(9))
+#define g_opt_g8_shortk gl_opt(37)  // default 1: 8-wave kernel also for short-K multi-round grids that fill >= 80 % of their rounds
 #define g_opt_g8_minnk gl_opt(35)  // default 5;      // 8-wave kernel only for K >= 64 * this
 
 template <int BM, int BN, int BKT, int NW = 4>
@@ -786,7 +787,16 @@ int dispatch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
             // (several resident blocks hide each other's prologue / epilogue), split-K slices need >= 20 K-tiles to pay for the reduction
             if (!CONV && splitk > 1 && nk / splitk < 20) splitk = nk / 20 > 0 ? nk / 20 : 1;
             bool enough = tiles * splitk >= g_opt_g8_tiles && nk >= g_opt_g8_minnk;
-            if (!CONV && enough) enough = nk >= 16 || tiles * splitk <= 256 || (g.epi == GL_EPI_GEGLU && nk >= 10);
+            if (!CONV && enough) {
+                // multi-round grids with a short K: nothing hides a block's prologue / epilogue at one block per CU, so the last, partly
+                // filled round must not cost more than the deeper loop wins -- only grids that fill >= 80 % of their rounds (measured
+                // with the hoisted-load epilogue, tools/g8_probe.py time with G8_SHORTK=1, profiles/r3_g8_shortk.txt: GEGLU
+                // 32768x2560x320 104 -> 84 us, QKV 32768x960x320 49 -> 41 us, 9216x1920x640 55 -> 34 us; the ragged fuser QKV, 774 blocks =
+                // 3.02 rounds, loses 5 %); plain GEMMs beyond 2048 blocks lose 3 % (131072 rows) and stay on the 4-wave kernels
+                const int blocks = tiles * splitk;
+                const bool full_rounds = g_opt_g8_shortk && blocks * 5 >= ((blocks + 255) / 256) * 256 * 4;
+                enough = nk >= 16 || blocks <= 256 || (g.epi == GL_EPI_GEGLU && (nk >= 10 || full_rounds)) || (full_rounds && blocks >= 512 && blocks <= 2048);
+            }
             if (g_opt_g8 == 2 || enough) {
                 const int kper = gl_cdiv(nk, splitk);
                 const int zs = gl_cdiv(nk, kper);

@@ -110,6 +110,15 @@ def cases():
         for cin in (64, 128, 320, 640, 960):
             v(f"conv 8x64^2 {cin}->320", 8, 64, cin, 320)
         return c
+    if os.environ.get("G8_SHORTK"):
+        # short-K, multi-round grids (level-0 QKV / GEGLU) at the row counts of configs[1] / [2] / [4] and ragged fuser rows
+        for M in (32768, 33008, 36864, 37104, 65536, 131072, 132032):
+            g(f"gemm {M}x960x320 qkv", M, 960, 320)
+            g(f"gemm {M}x2560x320 geglu", M, 2560, 320, "geglu")
+        for M in (8192, 9216, 16384, 32768):
+            g(f"gemm {M}x1920x640 qkv", M, 1920, 640)
+            g(f"gemm {M}x5120x640 geglu", M, 5120, 640, "geglu")
+        return c
     if os.environ.get("G8_EPI"):
         for M in (1024, 4096, 16384, 32768, 65536):
             g(f"gemm {M}x320x320 bias", M, 320, 320)
@@ -216,7 +225,8 @@ def main():
             print(f"  {'ok  ' if same else 'FAIL'} {name}")
             allok &= same
     if "time" in which:
-        cfgs = [("4-wave", {30: 0}), ("auto", {30: 1, 34: 11}), ("auto minkt 20", {30: 1, 34: 20}), ("auto minkt 6", {30: 1, 34: 6}), ("forced", {30: 2, 34: 11})]
+        cfgs = [("4-wave", {30: 0, 37: 1}), ("auto", {30: 1, 34: 11, 37: 1}), ("auto minkt 20", {30: 1, 34: 20, 37: 1}), ("auto, short-K rule off", {30: 1, 34: 11, 37: 0}),
+                ("forced", {30: 2, 34: 11, 37: 1})]
         print("== time (us, TF/s): " + " | ".join(c[0] for c in cfgs))
         iters = int(os.environ.get("G8_ITERS", "10"))
 
@@ -236,7 +246,7 @@ def main():
                     ts[i].append(timeit(run, iters))
             med = [sorted(v)[len(v) // 2] for v in ts]
             print(f"  {name:44s} " + " | ".join(f"{m * 1e6:8.1f} {fl / m / 1e12:7.1f}" for m in med) + f"   x{med[0] / min(med[1:4]):.2f}")
-        setopts({30: 1, 34: 11})
+        setopts({30: 1, 34: 11, 37: 1})
     if "stamps" in which:
         import ctypes
         import numpy as np
