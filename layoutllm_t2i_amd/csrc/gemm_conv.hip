@@ -795,7 +795,7 @@ int dispatch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
                 // 3.02 rounds, loses 5 %); plain GEMMs beyond 2048 blocks lose 3 % (131072 rows) and stay on the 4-wave kernels
                 const int blocks = tiles * splitk;
                 const bool full_rounds = g_opt_g8_shortk && blocks * 5 >= ((blocks + 255) / 256) * 256 * 4;
-                enough = nk >= 16 || blocks <= 256 || (g.epi == GL_EPI_GEGLU && (nk >= 10 || full_rounds)) || (full_rounds && blocks >= 512 && blocks <= 2048);
+                enough = nk >= 16 || blocks <= 256 || (g.epi == GL_EPI_GEGLU && (nk >= 10 || full_rounds)) || (full_rounds && blocks <= 2048);
             }
             if (g_opt_g8 == 2 || enough) {
                 const int kper = gl_cdiv(nk, splitk);
