@@ -544,13 +544,16 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
 
 #define g8_dbg gl_opt(32)   // measurement instantiation selector (process default 0)
 
-const half_t* g8_zero_page = nullptr;      // device address of this translation unit's zero page (gl8_init)
+constexpr int G8_MAX_DEVICES = 64;
+const half_t* g8_zero_page[G8_MAX_DEVICES] = {};   // per DEVICE: address of this translation unit's zero page on that device (gl8_init; __device__ symbols are per device)
 
 template <int BN, bool CONV>
 int launch8(const gl_gemm_args& g, const ConvGeom& cg_in, int zs, int kper, int order_m, hipStream_t st) {
-    if (!g8_zero_page) return GL_ERR_BAD_ARG;          // gl_init() was not called
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= G8_MAX_DEVICES) return GL_ERR_BAD_ARG;
+    if (!g8_zero_page[dev]) return GL_ERR_BAD_ARG;     // gl_init() was not called on this device
     ConvGeom cg = cg_in;
-    cg.zero = g8_zero_page;
+    cg.zero = g8_zero_page[dev];
     const int mt = gl_cdiv(g.M, 256), nt = gl_cdiv(g.N, BN);
     dim3 grid(mt * nt, 1, zs);
     bool done = false;
@@ -605,8 +608,10 @@ int gl8_launch(const gl_gemm_args& g, const ConvGeom& cg, bool conv, int bn, int
 int gl8_init(void) {
     int e;
     void* zp = nullptr;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= G8_MAX_DEVICES) return GL_ERR_BAD_ARG;
     if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero16)) != hipSuccess) return GL_ERR_BAD_ARG;
-    g8_zero_page = reinterpret_cast<const half_t*>(zp);
+    g8_zero_page[dev] = reinterpret_cast<const half_t*>(zp);
     if ((e = set_attr8<160, false>())) return e;
     if ((e = set_attr8<160, true>())) return e;
     if ((e = set_attr8<128, false>())) return e;

@@ -375,12 +375,12 @@ def generate_batch_images(all_models, captions, labels, bboxes, clip_model=None,
 # per-PROMPT seeds make a sample's result independent of the rank that ran it, and the uint8 images are gathered on rank 0.
 # One process per GPU under torch.distributed ("nccl" = RCCL over xGMI on ROCm; "gloo" in the tests).
 # ------------------------------------------------------------------------------------------------------------------
-def _unet_facade(packed, cfg, device):
+def _unet_facade(packed, cfg, device, allow_missing_sd_conv=False):
     from .engine import UNetEngine
     m = UNetModel.__new__(UNetModel)
     m.cfg, m.device = cfg, torch.device(device)
     m.image_size, m.in_channels, m.out_channels, m.model_channels = cfg.image_size, cfg.in_channels, cfg.out_channels, cfg.model_channels
-    m.first_conv_restorable, m.allow_missing_sd_conv, m.first_conv_type = bool(packed.has_sd_conv), False, "GLIGEN"
+    m.first_conv_restorable, m.allow_missing_sd_conv, m.first_conv_type = bool(packed.has_sd_conv), bool(allow_missing_sd_conv), "GLIGEN"
     m.grounding_tokenizer_input = GroundingNetInput()
     m.fuser_scale, m.training, m._cond_key = 1.0, False, None
     m.engine = UNetEngine(packed)
@@ -404,17 +404,17 @@ def load_all_models_sharded(ckpt, device, src=0):
             raise NotImplementedError("the sharded entry broadcasts the HIP VAE decoder's packed weights (unset GLIGEN_REFERENCE_VAE)")
         dcfg = dict(linear_start=diffusion.linear_start, linear_end=diffusion.linear_end, timesteps=diffusion.num_timesteps)
         broadcast_bundle(model.engine.P, autoencoder.W, model.cfg, device, src,
-                         extra=dict(config=config, vcfg=autoencoder.cfg, diffusion=dcfg))
+                         extra=dict(config=config, vcfg=autoencoder.cfg, diffusion=dcfg,
+                                    allow_missing_sd_conv=bool(getattr(model, "allow_missing_sd_conv", False))))
         return am
     P, vw, extra = broadcast_bundle(None, None, None, device, src)
-    model = _unet_facade(P, P.cfg, device)
+    model = _unet_facade(P, P.cfg, device, extra.get("allow_missing_sd_conv", False))     # src's GLIGEN_ALLOW_NO_SD_CONV applies to every rank
     autoencoder = VAEDecoder.from_packed(vw, extra["vcfg"], device)
     d = extra["diffusion"]
     diffusion = LatentDiffusion(linear_start=d["linear_start"], linear_end=d["linear_end"], timesteps=d["timesteps"], device=device)
     return model, autoencoder, None, diffusion, extra["config"]
 
 
-@torch.no_grad()
 def _collective_device(device):
     """Object collectives of the RCCL backend stage their bytes on the CURRENT device: make that this rank's GPU even when the
     caller never called torch.cuda.set_device (all ranks staging on GPU 0 is an RCCL 'duplicate GPU' error)."""
@@ -423,6 +423,7 @@ def _collective_device(device):
     return torch.cuda.device(d) if d.type == "cuda" else contextlib.nullcontext()
 
 
+@torch.no_grad()
 def prepare_conditioning(all_models, captions, labels, bboxes, clip_model, clip_processor, device):
     """Everything ``run_batch_images`` feeds the sampler (interface.py:486-535), per prompt row, on the CPU: context / uc
     [n, 77, 768], relations [n, R, 768], boxes / masks / text_embeddings [n, 30, ...].  Rows are independent, so any subset of
@@ -466,6 +467,7 @@ def run_shard(all_models, cond, noise, device, alpha_type=(0.3, 0.0, 0.7), guida
     return (img.cpu().numpy().transpose(0, 2, 3, 1) * 255).astype(np.uint8)
 
 
+@torch.no_grad()
 def generate_batch_images_sharded(all_models, captions=None, labels=None, bboxes=None, clip_model=None, clip_processor=None,
                                   device=None, seeds=None, src=0, steps=PLMS_STEPS, latent=64):
     """``generate_batch_images`` (interface.py:551-570) across the ranks of a torch.distributed job.  Rank ``src`` passes the
@@ -492,16 +494,29 @@ def generate_batch_images_sharded(all_models, captions=None, labels=None, bboxes
     n = len(seeds)
     mine = shard_indices(n, rank, world)
     sub = {k: v[mine] for k, v in cond.items()}
-    imgs = run_shard(all_models, sub, prompt_noise([seeds[i] for i in mine], latent), device, steps=steps)
+    # a rank whose shard fails still takes part in the gather (with the error as its payload): the others must not block
+    # forever in gather_object, and src re-raises
+    err = None
+    try:
+        imgs = run_shard(all_models, sub, prompt_noise([seeds[i] for i in mine], latent), device, steps=steps)
+    except Exception as ex:          # noqa: BLE001
+        if not multi:
+            raise
+        imgs, err = None, f"rank {rank}: {type(ex).__name__}: {ex}"
     if not multi:
         return [Image.fromarray(a) for a in imgs]
     parts = [None] * world if rank == src else None
     with _collective_device(device):
-        dist.gather_object((mine, imgs), parts, dst=src)
+        dist.gather_object((mine, imgs, err), parts, dst=src)
     if rank != src:
+        if err is not None:
+            raise RuntimeError(err)
         return None
+    errors = [e_ for _, _, e_ in parts if e_ is not None]
+    if errors:
+        raise RuntimeError("generate_batch_images_sharded failed on " + "; ".join(errors))
     out = [None] * n
-    for idx, arr in parts:
+    for idx, arr, _ in parts:
         for j, i in enumerate(idx):
             out[i] = Image.fromarray(arr[j])
     return out

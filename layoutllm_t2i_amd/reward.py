@@ -101,21 +101,25 @@ class RewardModel:
         return out
 
     @torch.no_grad()
-    def forward_images(self, input_ids, images_pred, images_gt, attention_mask=None, miou=None, laysim=None) -> dict:
+    def forward_images(self, input_ids, images_pred, images_gt, attention_mask=None, miou=None, laysim=None,
+                       pred_is_pixel_values: bool = False, gt_is_pixel_values: bool = False) -> dict:
         """``forward`` from IMAGES, as the reference's takes them (policy.py:106-111): ``images_pred`` is the VAE decoder's fp32
-        output [B, 3, H, W] still on the GPU (converted to the uint8 pixels of interface.py:543-547 there), a uint8 [B, H, W, 3]
-        GPU tensor, or a list of PIL images; ``images_gt`` a list of PIL images / uint8 arrays of any sizes, or ready
-        ``pixel_values``.  The CLIP feature extractor's resize / crop / normalise runs on the GPU (preprocess.py), bit-identical
-        to the PIL path."""
-        def px(im):
-            if torch.is_tensor(im) and im.dtype == torch.float32 and im.dim() == 4 and im.shape[1] == 3 and im.shape[-1] == self.preprocess.crop \
-                    and im.shape[-2] == self.preprocess.crop:
-                return im                                           # already pixel_values
+        output [B, 3, H, W] in [-1, 1] still on the GPU (converted to the uint8 pixels of interface.py:543-547 there), a uint8
+        [B, H, W, 3] GPU tensor, or a list of PIL images; ``images_gt`` a list of PIL images / uint8 arrays of any sizes.
+        The CLIP feature extractor's resize / crop / normalise runs on the GPU (preprocess.py), bit-identical to the PIL path.
+        Ready ``pixel_values`` (processor output) are passed through ONLY when the caller says so with ``*_is_pixel_values``:
+        an fp32 [B, 3, S, S] tensor is otherwise always taken as decoded images (a VAE output of the crop size is not
+        pixel_values)."""
+        def px(im, ready):
+            if ready:
+                if not (torch.is_tensor(im) and im.dtype == torch.float32 and im.dim() == 4 and im.shape[1] == 3):
+                    raise TypeError("pixel_values must be an fp32 [B, 3, S, S] tensor")
+                return im
             if torch.is_tensor(im) and im.dtype == torch.uint8:
                 return self.preprocess(im.to(self.device))
             if torch.is_tensor(im):
                 return self.preprocess.from_decoded(im)
             return self.preprocess.from_pil(im)
-        return self.forward(input_ids, px(images_pred), px(images_gt), attention_mask, miou, laysim)
+        return self.forward(input_ids, px(images_pred, pred_is_pixel_values), px(images_gt, gt_is_pixel_values), attention_mask, miou, laysim)
 
     __call__ = forward

@@ -92,6 +92,7 @@ class VAEDecoder:
 
     def set_option(self, key: int, value: int) -> None:
         """Override one gl_set_option knob for THIS decoder only (gl_vae_set_option)."""
+        from . import _lib
         _lib.check(_lib.lib().gl_vae_set_option(self.handle, int(key), int(value)), "gl_vae_set_option")
 
     def __del__(self):

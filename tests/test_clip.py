@@ -189,3 +189,12 @@ def test_reward_model_from_images_equals_the_pixel_values_path():
     want = rm(ids, T(px_pred), T(px_gt))
     for k in ("sims_ti", "sims_ii", "aes_reward", "reward"):
         assert torch.equal(out[k], want[k]), k
+    # a decoded fp32 batch that happens to have the crop size is still an IMAGE batch (it used to be taken for ready
+    # pixel_values by its shape); ready pixel_values are passed through only when the caller says so
+    dec42 = T(recipe.normal("decoded42", (3, 3, 42, 42), 9)) * 0.8
+    out42 = rm.forward_images(ids, dec42.to("cuda:0"), gts)
+    px42 = np.stack([ppref.clip_feature_extractor(u, 42, 42)[0] for u in ppref.decoded_to_u8(dec42)])
+    want42 = rm(ids, T(px42), T(px_gt))
+    ready = rm.forward_images(ids, T(px42), T(px_gt), pred_is_pixel_values=True, gt_is_pixel_values=True)
+    for k in ("sims_ti", "sims_ii", "aes_reward", "reward"):
+        assert torch.equal(out42[k], want42[k]) and torch.equal(ready[k], want42[k]), k
