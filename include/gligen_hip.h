@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GL_ABI_VERSION 11
+#define GL_ABI_VERSION 12
 
 /* error codes (negative; positive values are hipError_t) */
 #define GL_ERR_BAD_ARG (-1)
@@ -45,7 +45,12 @@ enum gl_out_mode {
     GL_OUT_F32_ROWMAJOR = 2  /* out[m * ldc + n] fp32: the RESIDUAL STREAM (ResBlock / transformer-block sums,
                                 openaimodel.py:231, attention.py:395-402,446) is kept in fp32 so that ~100 chained
                                 residual adds are not rounded to fp16 each; out2 (optional) gets an fp16 copy for
-                                consumers that feed it to the matrix cores (GroupNorm -> conv, 1x1 skip conv)      */
+                                consumers that feed it to the matrix cores (down / up convs)                        */
+    ,
+    GL_OUT_F16_HILO = 3      /* split-fp16 operand for a following 1x1 product: out[m * ldc + n] = hi = fp16(v) and
+                                out[m * ldc + N + n] = lo = fp16(v - hi)  (ldc >= 2N).  The consumer runs gl_gemm with
+                                K = 2N against the weight stored twice, [W | W]: x.W = hi.W + lo.W restores ~22 mantissa
+                                bits of the activation operand (proj_out of attention.py:444-446)            */
 };
 
 /*
@@ -80,6 +85,11 @@ typedef struct gl_gemm_args {
      * out but as gl_attention's V^T operand, vt[((b * vt_H + h) * vt_d + c) * vt_ld + key] with b = m / vt_rows,
      * key = m % vt_rows, (h, c) = divmod(n - vt_col0, vt_d).  fp16 row-major out, epi BIAS only, vt_col0 % 64 == 0. */
     void* vt;           int32_t vt_col0, vt_rows, vt_d, vt_ld, vt_H;
+    /* weight reuse along K (split-fp16 activations): with kwrap != 0 the weight is [N, kwrap] (row stride ldw) and
+     * column k of the product reads w[n * ldw + (k mod kwrap)], i.e. A = [hi | lo] (K = 2 * kwrap) is multiplied against
+     * [W | W] without storing W twice.  kwrap % 64 == 0, kwrap < K <= 2 * kwrap.  ldw == 0: the row stride is K (kwrap == 0)
+     * or kwrap.  gl_gemm only (ignored by gl_conv3x3). */
+    int32_t ldw, kwrap;
 } gl_gemm_args;
 
 /*
@@ -168,6 +178,27 @@ int gl_groupnorm_apply(const void* x1, int32_t C1, const void* x2, int32_t C2, i
 int gl_groupnorm(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t B, int32_t HW, const float* gamma,
                  const float* beta, float eps, int32_t silu, void* out, float* partial, int32_t nchunk, void* stream);
 int gl_groupnorm_launches(int32_t C, int32_t HW);
+
+/* gl_groupnorm_ex: gl_groupnorm with the inputs optionally in fp32 (the residual stream: GroupNorm32 of openaimodel.py:155,
+ * Normalize of attention.py:440 read the block input itself, not an fp16 copy of it) and two optional extra outputs that
+ * feed split-fp16 1x1 products:
+ *   out_lo : fp16 residual of the normalised rows, out_lo[m * ldo + c] = fp16(y - fp16(y))       (proj_in, attention.py:440)
+ *   raw    : the INPUT concat itself as [hi | lo], raw[m * ldraw + c] = fp16(x), raw[m * ldraw + C + c] = fp16(x - fp16(x))
+ *            (ResBlock skip_connection reads x, openaimodel.py:190-194,231), ldraw >= 2 (C1 + C2)
+ * ldo = row stride of out / out_lo in elements (0: C1 + C2).  partial / nchunk as for gl_groupnorm. */
+typedef struct gl_gn_args {
+    const void* x1;     int32_t C1;
+    const void* x2;     int32_t C2;       /* second source of the channel concat, or NULL */
+    int32_t x_f32;                        /* != 0: x1 / x2 are fp32, else fp16 */
+    int32_t B, HW;
+    const float* gamma; const float* beta; float eps; int32_t silu;
+    void* out;          int32_t ldo;
+    void* out_lo;
+    void* raw;          int32_t ldraw;
+    float* partial;     int32_t nchunk;
+} gl_gn_args;
+int gl_groupnorm_ex(const gl_gn_args* args, void* stream);
+int gl_groupnorm_launches_ex(int32_t C, int32_t HW, int32_t x_f32);
 
 /*
  * gl_layernorm: row LayerNorm eps 1e-5 over C (attention.py:216-217,292-294,369-371), fp32 statistics (two-pass).
@@ -423,6 +454,7 @@ int gl_abi_version(void);
 int gl_sizeof_gemm_args(void);
 int gl_sizeof_conv_args(void);
 int gl_sizeof_attn_args(void);
+int gl_sizeof_gn_args(void);
 /* tuning knobs for A/B measurements (results do not depend on them beyond fp32 summation order in split-K):
  * key 2 = GEMM tile shape policy (0 auto, 1 force 128x128, 2 prefer 128x160); key 3 = attention block shape (0 auto,
  * 3 always 8 waves, 4 always 4 waves); keys 4-7 = small-tile / split-K / 256-row-tile thresholds; key 8 = short-K GEGLU
@@ -437,7 +469,11 @@ int gl_sizeof_attn_args(void);
  * attention keeps the running max in the padding column of Q / K where the head dim leaves one (d % 16 == 8; 1 default, 0 off);
  * key 30 = 8-wave deep-pipelined 256-row GEMM / conv kernel (0 off, 1 default: problems with at least key-31 (200) such tiles,
  * 2 wherever it applies, with split-K); key 32 = (measurement) its timestamping instantiation, see gl_debug_read; keys 33-35, 37 = its K order
- * / split-K slice length / minimum K / use on short-K multi-round grids that fill >= 80 % of their rounds (1 default). */
+ * / split-K slice length / minimum K / use on short-K multi-round grids that fill >= 80 % of their rounds (1 default).
+ * Keys that DO change results (precision): key 41 = the engine's 1x1 convs (ResBlock skip_connection, proj_in, proj_out)
+ * take split-fp16 activations ([hi | lo] against the same weight) and every GroupNorm that reads a residual-stream tensor reads it
+ * in fp32 (1 default; 0 = round-3 behaviour: fp16 copies); key 42 = the ResBlock's first conv writes its output in fp32 for the
+ * following GroupNorm (1 default, 0 = fp16). */
 int gl_set_option(int key, int value);
 /* gl_set_option writes the PROCESS defaults (op-level calls and every handle without an override see them).  A handle can
  * override individual keys for itself: while one of ITS entry points (gl_set_conditioning / gl_unet_forward / gl_plms_step,

@@ -11,11 +11,11 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgligen_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 # enum gl_epilogue / gl_out_mode
 EPI_BIAS, EPI_SILU, EPI_GEGLU, EPI_RES, EPI_GATE_RES, EPI_ROWBIAS = range(6)
-OUT_F16_ROWMAJOR, OUT_F32_NCHW, OUT_F32_ROWMAJOR = 0, 1, 2
+OUT_F16_ROWMAJOR, OUT_F32_NCHW, OUT_F32_ROWMAJOR, OUT_F16_HILO = 0, 1, 2, 3
 
 vp = C.c_void_p
 i32 = C.c_int32
@@ -42,6 +42,22 @@ class GemmArgs(C.Structure):
         ("res_f32", i32),
         ("out2", vp), ("ldc2", i32),
         ("vt", vp), ("vt_col0", i32), ("vt_rows", i32), ("vt_d", i32), ("vt_ld", i32), ("vt_H", i32),
+        ("ldw", i32), ("kwrap", i32),
+    ]
+
+
+class GnArgs(C.Structure):
+    """gl_gn_args"""
+    _fields_ = [
+        ("x1", vp), ("C1", i32),
+        ("x2", vp), ("C2", i32),
+        ("x_f32", i32),
+        ("B", i32), ("HW", i32),
+        ("gamma", vp), ("beta", vp), ("eps", f32), ("silu", i32),
+        ("out", vp), ("ldo", i32),
+        ("out_lo", vp),
+        ("raw", vp), ("ldraw", i32),
+        ("partial", vp), ("nchunk", i32),
     ]
 
 
@@ -126,6 +142,9 @@ PROTOTYPES = {
     "gl_groupnorm_apply": (i32, [vp, i32, vp, i32, i32, i32, fp, i32, fp, fp, f32, i32, vp, vp]),
     "gl_groupnorm": (i32, [vp, i32, vp, i32, i32, i32, fp, fp, f32, i32, vp, fp, i32, vp]),
     "gl_groupnorm_launches": (i32, [i32, i32]),
+    "gl_groupnorm_ex": (i32, [C.POINTER(GnArgs), vp]),
+    "gl_groupnorm_launches_ex": (i32, [i32, i32, i32]),
+    "gl_sizeof_gn_args": (i32, []),
     "gl_layernorm": (i32, [vp, i32, i32, vp, i32, fp, fp, i32, i32, i32, i32, i32, f32, fp, vp, i32, i32, vp]),
     "gl_rela_pool": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, fp, fp, vp, vp]),
     "gl_rela_merge": (i32, [vp, i32, vp, fp, fp, fp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, fp, fp, vp, vp]),
@@ -220,7 +239,7 @@ def lib() -> C.CDLL:
     for cls, fn in ((GemmArgs, l.gl_sizeof_gemm_args), (ConvArgs, l.gl_sizeof_conv_args), (AttnArgs, l.gl_sizeof_attn_args),
                     (UNetConfigC, l.gl_sizeof_unet_config), (WeightInfo, l.gl_sizeof_weight_info),
                     (PlmsStepArgs, l.gl_sizeof_plms_step_args), (RewardArgs, l.gl_sizeof_reward_args), (FFArgs, l.gl_sizeof_ff_args),
-                    (VaeConfigC, l.gl_sizeof_vae_config)):
+                    (VaeConfigC, l.gl_sizeof_vae_config), (GnArgs, l.gl_sizeof_gn_args)):
         if C.sizeof(cls) != fn():
             raise HipLibraryError(f"struct size mismatch for {cls.__name__}: host {C.sizeof(cls)} vs lib {fn()}")
     _lib = l

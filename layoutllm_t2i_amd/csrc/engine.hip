@@ -31,6 +31,8 @@ constexpr int64_t WS_BYTES = 96ll << 20; // split-K fp32 partial tiles
 #define g_fuse_merge_ln gl_opt(25)  // default 1;                 // A/B knob (gl_set_option 25): rela_merge also writes LayerNorm(norm2) of its rows
 #define g_fuse_vt gl_opt(21)  // default 1;                       // A/B knob (gl_set_option 21): V^T written by the QKV GEMM epilogue (1) or by gl_transpose_v (0)
 #define g_force_fuser gl_opt(20)  // default 0;                   // test knob (gl_set_option 20): execute the fuser even at scale 0 (zero gates)
+#define g_precise gl_opt(41)      // default 1;                   // split-fp16 activations for the 1x1 convs + GroupNorm on the fp32 stream
+#define g_h1_f32 gl_opt(42)       // default 1;                   // with key 41: the ResBlock's first conv writes fp32 for out_layers' GroupNorm
 
 enum Kind { CONV_IN = 0, RES = 1, ST = 2, DOWN = 3, UP = 4 };
 struct LayerD {
@@ -362,7 +364,8 @@ struct Run {
 
     int gemm(const void* a, int lda, const std::string& w, int M, void* out, int ldc, int out_mode = GL_OUT_F16_ROWMAJOR,
              const std::string& bias = "", int epi = GL_EPI_BIAS, const void* res = nullptr, int ldres = 0, int res_f32 = 0,
-             const float* gate = nullptr, void* out2 = nullptr, int ldc2 = 0, const void* a2 = nullptr, int lda2 = 0, int ksplit = 0) {
+             const float* gate = nullptr, void* out2 = nullptr, int ldc2 = 0, const void* a2 = nullptr, int lda2 = 0, int ksplit = 0,
+             bool hilo_a = false) {
         const WInfo* wi = e->wi(w);
         if (!wi) return GL_ERR_BAD_ARG;
         gl_gemm_args g{};
@@ -370,6 +373,9 @@ struct Run {
         g.w = e->W(w);
         g.bias = bias.empty() ? nullptr : e->Wf(bias);
         g.M = M; g.N = (int)wi->shape[0]; g.K = (int)wi->shape[1];
+        if (hilo_a) {           // A = [hi | lo] of the activation, both halves against the same weight (gl_gemm_args.kwrap)
+            g.kwrap = g.K; g.ldw = g.K; g.K = 2 * g.K;
+        }
         g.epi = epi; g.out_mode = out_mode; g.out = out; g.ldc = ldc;
         g.res = res; g.ldres = ldres; g.res_f32 = res_f32; g.gate = gate;
         g.out2 = out2; g.ldc2 = ldc2;
@@ -415,12 +421,19 @@ struct Run {
         return gl_layernorm(x, ldx, x_f32, y, ldy, e->Wf(p + ".g"), e->Wf(p + ".b"), B, rows_in, rows_out, row_off, C, 1e-5f, stats, x2, C, rows2,
                             st);
     }
-    int gn(const half_t* x1, int C1, const half_t* x2, int C2, int B, int HW, const std::string& p, float eps, int silu, half_t* out) {
+    // x_f32: the sources are fp32 stream tensors; out_lo / raw: the split-fp16 side outputs of gl_groupnorm_ex
+    int gn(const void* x1, int C1, const void* x2, int C2, int x_f32, int B, int HW, const std::string& p, float eps, int silu, half_t* out,
+           int ldo = 0, half_t* out_lo = nullptr, half_t* raw = nullptr, int ldraw = 0) {
         const int nchunk = gn_nchunk(HW);
         float* partial = e->f32("gn.partial", (size_t)B * nchunk * 64);
         CKP(partial);
-        launches += gl_groupnorm_launches(C1 + C2, HW);
-        return gl_groupnorm(x1, C1, x2, C2, B, HW, e->Wf(p + ".g"), e->Wf(p + ".b"), eps, silu, out, partial, nchunk, st);
+        launches += gl_groupnorm_launches_ex(C1 + C2, HW, x_f32);
+        gl_gn_args a{};
+        a.x1 = x1; a.C1 = C1; a.x2 = x2; a.C2 = C2; a.x_f32 = x_f32; a.B = B; a.HW = HW;
+        a.gamma = e->Wf(p + ".g"); a.beta = e->Wf(p + ".b"); a.eps = eps; a.silu = silu;
+        a.out = out; a.ldo = ldo; a.out_lo = out_lo; a.raw = raw; a.ldraw = ldraw;
+        a.partial = partial; a.nchunk = nchunk;
+        return gl_groupnorm_ex(&a, st);
     }
     int attn(const half_t* q, int64_t qb, int ldq, const half_t* k, int64_t kb, int ldk, const half_t* vt, int ldvt, half_t* out,
              int64_t ob, int ldo, int B, int H, int d, int Nq, int Nk) {
@@ -506,6 +519,7 @@ int self_attention(Run& r, const half_t* src, int rows_per_b, int Nq, int Nk, in
 }
 
 int feed_forward(Run& r, const half_t* xn, const float* res, const std::string& p, int M, int C, void* out, int out_mode, const float* gate) {
+    const int ldc = out_mode == GL_OUT_F16_HILO ? 2 * C : C;       // [hi | lo] rows for a split-fp16 consumer
     if (gl_ff_fused_applicable(C, M)) {
         // narrow / long level: the whole FeedForward in one launch, the [M, 4C] GEGLU intermediate never leaves the CU
         gl_ff_args a{};
@@ -515,7 +529,7 @@ int feed_forward(Run& r, const half_t* xn, const float* res, const std::string& 
         if (!a.w1 || !a.b1 || !a.w2 || !a.b2) return GL_ERR_BAD_ARG;
         a.res = res; a.ldres = C; a.res_f32 = 1;
         a.gate = gate;
-        a.out = out; a.ldc = C; a.out_mode = out_mode;
+        a.out = out; a.ldc = ldc; a.out_mode = out_mode;
         a.M = M; a.C = C;
         ++r.launches;
         return gl_ff_fused(&a, r.st);
@@ -523,44 +537,62 @@ int feed_forward(Run& r, const half_t* xn, const float* res, const std::string& 
     half_t* hg = r.e->h16("ff.h", (size_t)M * 4 * C);
     CKP(hg);
     CK(r.gemm(xn, C, p + ".ff1.w", M, hg, 4 * C, GL_OUT_F16_ROWMAJOR, p + ".ff1.b", GL_EPI_GEGLU));
-    return r.gemm(hg, 4 * C, p + ".ff2.w", M, out, C, out_mode, p + ".ff2.b", gate ? GL_EPI_GATE_RES : GL_EPI_RES, res, C, 1, gate);
+    return r.gemm(hg, 4 * C, p + ".ff2.w", M, out, ldc, out_mode, p + ".ff2.b", gate ? GL_EPI_GATE_RES : GL_EPI_RES, res, C, 1, gate);
 }
 
-// ResBlock._forward (openaimodel.py:211-231); skip = the popped skip-stack tensor of an output block (th.cat folded in)
+// ResBlock._forward (openaimodel.py:211-231); skip = the popped skip-stack tensor of an output block (th.cat folded in).
+// need_h: the output also gets an fp16 copy (its consumer is a down / up conv, or the round-3 fp16-copy mode is on).
 int res_block(Run& r, const LayerD& l, Stream2 h, const Stream2* skip, int skip_c, int side, const half_t* emb_out, const std::string& tag,
-              Stream2* out) {
+              bool need_h, Stream2* out) {
     gl_engine* e = r.e;
     const int Bn = e->Bn, HW = side * side, M = Bn * HW;
     const std::string& p = l.prefix;
     const int c1 = l.cin - skip_c;
+    const bool precise = g_precise != 0, h1f = precise && g_h1_f32 != 0, has_skip_conv = l.cin != l.cout;
     half_t* t = e->h16("rb.gn1", (size_t)M * l.cin);
-    half_t* h1 = e->h16("rb.h1", (size_t)M * l.cout);
     half_t* t2 = e->h16("rb.gn2", (size_t)M * l.cout);
-    CKP(t); CKP(h1); CKP(t2);
-    CK(r.gn(h.h, c1, skip ? skip->h : nullptr, skip_c, Bn, HW, p + ".in_layers.0", 1e-5f, 1, t));
+    CKP(t); CKP(t2);
+    // in_layers GroupNorm + SiLU.  precise: reads the fp32 stream itself and, for a block with a 1x1 skip_connection, also writes
+    // the raw input concat as [hi | lo] fp16 -- the split-fp16 operand of that 1x1 conv (its input IS the block input, :231)
+    half_t* split = nullptr;
+    if (precise) {
+        if (has_skip_conv) { split = e->h16("rb.split", (size_t)M * 2 * l.cin); CKP(split); }
+        CK(r.gn(h.f, c1, skip ? skip->f : nullptr, skip_c, 1, Bn, HW, p + ".in_layers.0", 1e-5f, 1, t, 0, nullptr, split, 2 * l.cin));
+    } else {
+        CKP(h.h);
+        CK(r.gn(h.h, c1, skip ? skip->h : nullptr, skip_c, 0, Bn, HW, p + ".in_layers.0", 1e-5f, 1, t));
+    }
     const int off = e->emb_off[p];
-    CK(r.conv(t, p + ".in_layers.2.w", p + ".in_layers.2.b", Bn, side, side, l.cin, 1, 0, h1, GL_OUT_F16_ROWMAJOR, GL_EPI_ROWBIAS, nullptr, 0, 0,
-              emb_out + off, e->emb_total, HW));
-    CK(r.gn(h1, l.cout, nullptr, 0, Bn, HW, p + ".out_layers.0", 1e-5f, 1, t2));
+    void* h1 = h1f ? (void*)e->f32("rb.h1f", (size_t)M * l.cout) : (void*)e->h16("rb.h1", (size_t)M * l.cout);
+    CKP(h1);
+    CK(r.conv(t, p + ".in_layers.2.w", p + ".in_layers.2.b", Bn, side, side, l.cin, 1, 0, h1, h1f ? GL_OUT_F32_ROWMAJOR : GL_OUT_F16_ROWMAJOR,
+              GL_EPI_ROWBIAS, nullptr, 0, 0, emb_out + off, e->emb_total, HW));
+    CK(r.gn(h1, l.cout, nullptr, 0, h1f ? 1 : 0, Bn, HW, p + ".out_layers.0", 1e-5f, 1, t2));
     const float* sk = h.f;
-    if (l.cin != l.cout) {
+    if (has_skip_conv) {
         float* skb = e->f32("rb.skip.f32", (size_t)M * l.cout);
         CKP(skb);
-        CK(r.gemm(h.h, c1, p + ".skip_connection.w", M, skb, l.cout, GL_OUT_F32_ROWMAJOR, p + ".skip_connection.b", GL_EPI_BIAS, nullptr, 0, 0, nullptr,
-                  nullptr, 0, skip ? skip->h : nullptr, skip_c, skip ? c1 : 0));
+        if (precise) {
+            CK(r.gemm(split, 2 * l.cin, p + ".skip_connection.w", M, skb, l.cout, GL_OUT_F32_ROWMAJOR, p + ".skip_connection.b", GL_EPI_BIAS, nullptr, 0, 0,
+                      nullptr, nullptr, 0, nullptr, 0, 0, true));
+        } else {
+            CK(r.gemm(h.h, c1, p + ".skip_connection.w", M, skb, l.cout, GL_OUT_F32_ROWMAJOR, p + ".skip_connection.b", GL_EPI_BIAS, nullptr, 0, 0, nullptr,
+                      nullptr, 0, skip ? skip->h : nullptr, skip_c, skip ? c1 : 0));
+        }
         sk = skb;
     } else if (skip) {
         return GL_ERR_BAD_ARG;
     }
     out->f = e->f32(tag + ".f32", (size_t)M * l.cout);
-    out->h = e->h16(tag, (size_t)M * l.cout);
-    CKP(out->f); CKP(out->h);
+    out->h = need_h ? e->h16(tag, (size_t)M * l.cout) : nullptr;
+    CKP(out->f);
+    if (need_h) CKP(out->h);
     return r.conv(t2, p + ".out_layers.3.w", p + ".out_layers.3.b", Bn, side, side, l.cout, 1, 0, out->f, GL_OUT_F32_ROWMAJOR, GL_EPI_RES, sk, l.cout, 1,
                   nullptr, 0, 0, out->h);
 }
 
 // SpatialTransformer.forward + BasicTransformerBlock._forward (attention.py:436-446, :394-402)
-int spatial_transformer(Run& r, const LayerD& l, int li, Stream2 xin, int side, bool fuser_on, const std::string& tag, Stream2* out) {
+int spatial_transformer(Run& r, const LayerD& l, int li, Stream2 xin, int side, bool fuser_on, const std::string& tag, bool need_h, Stream2* out) {
     gl_engine* e = r.e;
     const gl_unet_config& cfg = e->cfg;
     const std::string& p = l.prefix;
@@ -570,14 +602,23 @@ int spatial_transformer(Run& r, const LayerD& l, int li, Stream2 xin, int side, 
     const std::string sl = std::to_string(li);
     float* xa = e->f32("st.xa", (size_t)M * C);
     float* xb = e->f32("st.xb", (size_t)M * C);
-    half_t* g0 = e->h16("st.gn", (size_t)M * C);
+    const bool precise = g_precise != 0;
+    half_t* g0 = e->h16("st.gn", (size_t)M * C * (precise ? 2 : 1));
     half_t* lnb = e->h16("st.ln", (size_t)M * C);
     CKP(xa); CKP(xb); CKP(g0); CKP(lnb);
     const float* gates = e->f32("gates", e->st_layers.size() * 4) + (size_t)li * 4;
-    CK(r.gn(xin.h, C, nullptr, 0, Bn, N, p + ".norm", 1e-6f, 0, g0));
     float* x = xa;
     auto nxt = [&](float* cur) { return cur == xa ? xb : xa; };
-    CK(r.gemm(g0, C, p + ".proj_in.w", M, x, C, GL_OUT_F32_ROWMAJOR, p + ".proj_in.b"));
+    if (precise) {
+        // Normalize on the fp32 stream, rows written as [hi | lo]; proj_in takes both halves against the same weight
+        CK(r.gn(xin.f, C, nullptr, 0, 1, Bn, N, p + ".norm", 1e-6f, 0, g0, 2 * C, g0 + C));
+        CK(r.gemm(g0, 2 * C, p + ".proj_in.w", M, x, C, GL_OUT_F32_ROWMAJOR, p + ".proj_in.b", GL_EPI_BIAS, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, 0, 0,
+                  true));
+    } else {
+        CKP(xin.h);
+        CK(r.gn(xin.h, C, nullptr, 0, 0, Bn, N, p + ".norm", 1e-6f, 0, g0));
+        CK(r.gemm(g0, C, p + ".proj_in.w", M, x, C, GL_OUT_F32_ROWMAJOR, p + ".proj_in.b"));
+    }
     // --- attn1 (attention.py:395)
     half_t* att = nullptr;
     CK(r.ln(x, C, 1, lnb, C, t + ".norm1", Bn, N, N, 0, C));
@@ -663,15 +704,18 @@ int spatial_transformer(Run& r, const LayerD& l, int li, Stream2 xin, int side, 
         x = y;
     }
     // --- GEGLU feed-forward (attention.py:401): the sum is only consumed by proj_out's matrix product -> fp16
-    half_t* x16 = e->h16("st.x6", (size_t)M * C);
+    // (precise: as [hi | lo] rows, proj_out takes both halves against the same weight)
+    half_t* x16 = e->h16("st.x6", (size_t)M * C * (precise ? 2 : 1));
     CKP(x16);
     CK(r.ln(x, C, 1, lnb, C, t + ".norm3", Bn, N, N, 0, C));
-    CK(feed_forward(r, lnb, x, t + ".ff", M, C, x16, GL_OUT_F16_ROWMAJOR, nullptr));
+    CK(feed_forward(r, lnb, x, t + ".ff", M, C, x16, precise ? GL_OUT_F16_HILO : GL_OUT_F16_ROWMAJOR, nullptr));
     // --- proj_out + residual (attention.py:444-446)
     out->f = e->f32(tag + ".f32", (size_t)M * C);
-    out->h = e->h16(tag, (size_t)M * C);
-    CKP(out->f); CKP(out->h);
-    return r.gemm(x16, C, p + ".proj_out.w", M, out->f, C, GL_OUT_F32_ROWMAJOR, p + ".proj_out.b", GL_EPI_RES, xin.f, C, 1, nullptr, out->h, C);
+    out->h = need_h ? e->h16(tag, (size_t)M * C) : nullptr;
+    CKP(out->f);
+    if (need_h) CKP(out->h);
+    return r.gemm(x16, precise ? 2 * C : C, p + ".proj_out.w", M, out->f, C, GL_OUT_F32_ROWMAJOR, p + ".proj_out.b", GL_EPI_RES, xin.f, C, 1, nullptr, out->h,
+                  C, nullptr, 0, 0, precise);
 }
 
 int launch_forward(gl_engine* e, int reps, bool fuser_on, bool sd_conv, hipStream_t st, int* n_launches) {
@@ -701,41 +745,49 @@ int launch_forward(gl_engine* e, int reps, bool fuser_on, bool sd_conv, hipStrea
     ++r.launches;
     CK(gl_pack_latent(x_lat, Bn / reps, cfg.in_channels, side * side, CIN_PAD, reps, xin, st));
     const std::string fc = sd_conv ? "sd_first_conv" : "input_blocks.0.0";
+    // fp16 copies of stream tensors: only where a down / up conv consumes the tensor (precise mode: every GroupNorm and 1x1 conv
+    // reads the fp32 stream), or everywhere in the round-3 fp16-copy mode
+    const bool precise = g_precise != 0;
+    auto first_kind = [&](const BlockD* b) { return b && !b->layers.empty() ? b->layers[0].kind : -1; };
+    auto wants_h = [&](int next_kind) { return !precise || next_kind == DOWN || next_kind == UP; };
     Stream2 h;
     h.f = e->f32("skip.0.f32", (size_t)Bn * side * side * mc);
-    h.h = e->h16("skip.0", (size_t)Bn * side * side * mc);
-    CKP(h.f); CKP(h.h);
+    h.h = wants_h(first_kind(e->input_blocks.size() > 1 ? &e->input_blocks[1] : nullptr)) ? e->h16("skip.0", (size_t)Bn * side * side * mc) : nullptr;
+    CKP(h.f);
     CK(r.conv(xin, fc + ".w", fc + ".b", Bn, side, side, CIN_PAD, 1, 0, h.f, GL_OUT_F32_ROWMAJOR, GL_EPI_BIAS, nullptr, 0, 0, nullptr, 0, 0, h.h));
     struct Skip { Stream2 s; int side, c; };
     std::vector<Skip> skips{{h, side, mc}};
     int st_idx = 0;
     int h_c = mc;
 
-    auto run_block = [&](const BlockD& b, const std::string& bi, const Skip* skip) -> int {
+    auto run_block = [&](const BlockD& b, const std::string& bi, const Skip* skip, const BlockD* next) -> int {
         const Stream2* sk = skip ? &skip->s : nullptr;
         int sk_c = skip ? skip->c : 0;
         for (size_t j = 0; j < b.layers.size(); ++j) {
             const LayerD& l = b.layers[j];
             const std::string tag = bi + "." + std::to_string(j);
+            const bool need_h = wants_h(j + 1 < b.layers.size() ? b.layers[j + 1].kind : first_kind(next));
             Stream2 o;
             if (l.kind == RES) {
-                CK(res_block(r, l, h, sk, sk_c, side, emb_out, tag, &o));
+                CK(res_block(r, l, h, sk, sk_c, side, emb_out, tag, need_h, &o));
                 sk = nullptr; sk_c = 0;
             } else if (l.kind == ST) {
-                CK(spatial_transformer(r, l, st_idx++, h, side, fuser_on, tag, &o));
+                CK(spatial_transformer(r, l, st_idx++, h, side, fuser_on, tag, need_h, &o));
             } else if (l.kind == DOWN) {
                 const int so = side / 2;
                 o.f = e->f32(tag + ".f32", (size_t)Bn * so * so * l.cout);
-                o.h = e->h16(tag, (size_t)Bn * so * so * l.cout);
-                CKP(o.f); CKP(o.h);
+                o.h = need_h ? e->h16(tag, (size_t)Bn * so * so * l.cout) : nullptr;
+                CKP(o.f); CKP(h.h);
+                if (need_h) CKP(o.h);
                 CK(r.conv(h.h, l.prefix + ".w", l.prefix + ".b", Bn, side, side, l.cin, 2, 0, o.f, GL_OUT_F32_ROWMAJOR, GL_EPI_BIAS, nullptr, 0, 0, nullptr,
                           0, 0, o.h));
                 side = so;
             } else if (l.kind == UP) {
                 const int so = side * 2;
                 o.f = e->f32(tag + ".f32", (size_t)Bn * so * so * l.cout);
-                o.h = e->h16(tag, (size_t)Bn * so * so * l.cout);
-                CKP(o.f); CKP(o.h);
+                o.h = need_h ? e->h16(tag, (size_t)Bn * so * so * l.cout) : nullptr;
+                CKP(o.f); CKP(h.h);
+                if (need_h) CKP(o.h);
                 CK(r.conv(h.h, l.prefix + ".w", l.prefix + ".b", Bn, side, side, l.cin, 1, 1, o.f, GL_OUT_F32_ROWMAJOR, GL_EPI_BIAS, nullptr, 0, 0, nullptr,
                           0, 0, o.h));
                 side = so;
@@ -749,19 +801,24 @@ int launch_forward(gl_engine* e, int reps, bool fuser_on, bool sd_conv, hipStrea
     };
 
     for (size_t i = 1; i < e->input_blocks.size(); ++i) {
-        CK(run_block(e->input_blocks[i], "skip." + std::to_string(i), nullptr));
+        CK(run_block(e->input_blocks[i], "skip." + std::to_string(i), nullptr, i + 1 < e->input_blocks.size() ? &e->input_blocks[i + 1] : &e->middle));
         skips.push_back({h, side, h_c});
     }
-    CK(run_block(e->middle, "mid", nullptr));
+    CK(run_block(e->middle, "mid", nullptr, e->output_blocks.empty() ? nullptr : &e->output_blocks[0]));
     for (size_t i = 0; i < e->output_blocks.size(); ++i) {
         const Skip sk = skips.back();
         skips.pop_back();
         if (sk.side != side) return GL_ERR_BAD_ARG;
-        CK(run_block(e->output_blocks[i], "out." + std::to_string(i), &sk));
+        CK(run_block(e->output_blocks[i], "out." + std::to_string(i), &sk, i + 1 < e->output_blocks.size() ? &e->output_blocks[i + 1] : nullptr));
     }
     half_t* g = e->h16("fin.gn", (size_t)Bn * side * side * e->out_channels_last);
     CKP(g);
-    CK(r.gn(h.h, e->out_channels_last, nullptr, 0, Bn, side * side, "out.0", 1e-5f, 1, g));
+    if (precise) {
+        CK(r.gn(h.f, e->out_channels_last, nullptr, 0, 1, Bn, side * side, "out.0", 1e-5f, 1, g));
+    } else {
+        CKP(h.h);
+        CK(r.gn(h.h, e->out_channels_last, nullptr, 0, 0, Bn, side * side, "out.0", 1e-5f, 1, g));
+    }
     CK(r.conv(g, "out.2.w", "out.2.b", Bn, side, side, e->out_channels_last, 1, 0, eps, GL_OUT_F32_NCHW, GL_EPI_BIAS, nullptr, 0, 0, nullptr, 0, 0, nullptr,
               side * side));
     if (n_launches) *n_launches = r.launches;

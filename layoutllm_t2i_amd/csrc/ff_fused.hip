@@ -274,6 +274,12 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(gl_ff_args p) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) o[q] = (half_t)v[q];
                 *reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(p.out) + (size_t)m * p.ldc + n) = o;
+                if (p.out_mode == GL_OUT_F16_HILO) {        // fp16 residual C columns to the right (split-fp16 operand of proj_out)
+                    half4_t l;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) l[q] = (half_t)(v[q] - (float)o[q]);
+                    *reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(p.out) + (size_t)m * p.ldc + C + n) = l;
+                }
             }
         }
 }
@@ -330,7 +336,8 @@ extern "C" int gl_ff_fused_applicable(int32_t C, int32_t M) {
 extern "C" int gl_ff_fused(const gl_ff_args* a, void* stream) {
     if (!a || !a->x || !a->w1 || !a->b1 || !a->w2 || !a->b2 || !a->res || !a->out || a->M <= 0) return GL_ERR_BAD_ARG;
     if ((a->ldx % 8) != 0 || (a->ldres % 4) != 0 || (a->ldc % 4) != 0) return GL_ERR_BAD_ARG;
-    if (a->out_mode != GL_OUT_F16_ROWMAJOR && a->out_mode != GL_OUT_F32_ROWMAJOR) return GL_ERR_BAD_ARG;
+    if (a->out_mode != GL_OUT_F16_ROWMAJOR && a->out_mode != GL_OUT_F32_ROWMAJOR && a->out_mode != GL_OUT_F16_HILO) return GL_ERR_BAD_ARG;
+    if (a->out_mode == GL_OUT_F16_HILO && a->ldc < 2 * a->C) return GL_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     switch (a->C) {
         case 64: return ff_launch<64>(*a, st);

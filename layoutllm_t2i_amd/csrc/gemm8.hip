@@ -180,7 +180,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
         const int gc = (sslot ^ ((r >> 1) & 7)) << 3;
         const int n = n0 + r;
         const bool ok = (j < nb) && (r < BN) && (n < N);
-        bptr[j] = ok ? (Wg + (size_t)n * K + gc) : zsrc;       // + the K-tile's offset at issue time
+        bptr[j] = ok ? (Wg + (size_t)n * (CONV ? K : p.ldw) + gc) : zsrc;       // + the K-tile's offset at issue time
         if (ok) bmask |= 1u << j;
     }
 
@@ -211,6 +211,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
             is_boff = (is_cblk * 9 + is_tap) << 6;
         } else {
             is_boff = is_kt << 6;
+            if (p.kwrap != 0 && is_boff >= p.kwrap) is_boff -= p.kwrap;      // weight reuse along K ([hi | lo] activations, same W)
             if (A2g != nullptr && is_kt * 64 == p.ksplit && is_kt != kt_begin) {
                 // two-source A: crossing into the second matrix, once per block, before the first unit of that K-tile
 #pragma unroll

@@ -186,7 +186,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
         const int gc = (skc ^ swz(r)) << 3;
         const int n = n0 + r;
         const bool ok = (r < BN) && (n < N);
-        bptr[i] = ok ? (Wg + (size_t)n * K + k_first + gc) : zsrc;
+        if constexpr (CONV) bptr[i] = ok ? (Wg + (size_t)n * K + k_first + gc) : zsrc;
+        else bptr[i] = ok ? (Wg + (size_t)n * p.ldw + (p.kwrap != 0 && k_first >= p.kwrap ? k_first - p.kwrap : k_first) + gc) : zsrc;
         if (ok) bmask |= 1u << i;
     }
 
@@ -240,6 +241,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
                 if ((BM % RPP) != 0 && RPP * i + wave * RPW >= BM) continue;
                 glds16(aptr[i], As + (size_t)(buf * BM + RPP * i + wave * RPW) * BKT);
                 aptr[i] += ((amask >> i) & 1u) ? BKT : 0;
+            }
+        }
+        if constexpr (!CONV) {
+            if (p.kwrap != 0 && k0 == p.kwrap && k0 != k_first) {
+                // weight reuse along K ([hi | lo] activations against the same W): back to column 0 of the weight rows, once per block
+#pragma unroll
+                for (int i = 0; i < BPASS; ++i) bptr[i] -= ((bmask >> i) & 1u) ? p.kwrap : 0;
             }
         }
 #pragma unroll
@@ -586,7 +594,9 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(gl_gemm_args p) {
     int mr = m0 + (lane & 31);
     if (mr >= M) mr = M - 1;                                    // ragged last tile: clamp (rows discarded below)
     const half_t* ap = reinterpret_cast<const half_t*>(p.a) + (size_t)mr * p.lda + kw + 8 * (lane >> 5);
-    const half_t* wp = reinterpret_cast<const half_t*>(p.w) + (size_t)(n0 + (lane & 31)) * K + kw + 8 * (lane >> 5);
+    // weight reuse along K: K == 2 * kwrap, so the four K slices never straddle the wrap
+    const half_t* wp = reinterpret_cast<const half_t*>(p.w) + (size_t)(n0 + (lane & 31)) * p.ldw + (p.kwrap != 0 && kw >= p.kwrap ? kw - p.kwrap : kw) +
+                       8 * (lane >> 5);
     f32x16 acc;
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
@@ -630,6 +640,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(gl_gemm_args p) {
 // rows x (N / 32) tiles, every tile streams (32 + 32) x K operand halves: worth it while that stays cache-sized
 inline bool skinny_ok(const gl_gemm_args& g) {
     if (!g_opt_skinny || g.M > 1024 || (g.N % 32) != 0 || g.epi == GL_EPI_GEGLU || g.vt != nullptr || g.a2 != nullptr) return false;
+    if (g.kwrap != 0 && g.K != 2 * g.kwrap) return false;
     if (g.out_mode == GL_OUT_F32_NCHW || (g.lda % 8) != 0) return false;
     const long tiles = (long)gl_cdiv(g.M, 32) * (g.N / 32);
     return tiles * 64L * g.K * 2L <= (long)g_opt_skinny << 20;
@@ -743,7 +754,8 @@ int dispatch_shape(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
 template <bool CONV>
 int dispatch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K % 64) != 0) return GL_ERR_BAD_ARG;
-    if (g.out_mode < 0 || g.out_mode > GL_OUT_F32_ROWMAJOR) return GL_ERR_BAD_ARG;
+    if (g.out_mode < 0 || g.out_mode > GL_OUT_F16_HILO) return GL_ERR_BAD_ARG;
+    if (g.out_mode == GL_OUT_F16_HILO && (g.epi == GL_EPI_GEGLU || g.vt != nullptr || g.ldc < 2 * g.N)) return GL_ERR_BAD_ARG;
     if (g.out_mode != GL_OUT_F32_NCHW && ((g.N % 8) != 0 || (g.ldc % 8) != 0)) return GL_ERR_BAD_ARG;
     if (g.out_mode == GL_OUT_F32_ROWMAJOR && g.out2 != nullptr && (g.ldc2 % 8) != 0) return GL_ERR_BAD_ARG;
     if (g.out_mode == GL_OUT_F32_ROWMAJOR && g.epi == GL_EPI_GEGLU) return GL_ERR_UNSUPPORTED;
@@ -826,7 +838,11 @@ int dispatch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
 extern "C" int gl_gemm(const gl_gemm_args* a, void* stream) {
     if (!a || !a->a || !a->w || !a->out) return GL_ERR_BAD_ARG;
     ConvGeom cg{};
-    return dispatch<false>(*a, cg, (hipStream_t)stream);
+    gl_gemm_args g = *a;
+    if (g.kwrap != 0 && ((g.kwrap % 64) != 0 || g.kwrap >= g.K || g.K > 2 * g.kwrap)) return GL_ERR_BAD_ARG;
+    if (g.ldw == 0) g.ldw = g.kwrap != 0 ? g.kwrap : g.K;
+    if (g.ldw < (g.kwrap != 0 ? g.kwrap : g.K) || (g.ldw % 8) != 0) return GL_ERR_BAD_ARG;
+    return dispatch<false>(g, cg, (hipStream_t)stream);
 }
 
 extern "C" int gl_conv3x3(const gl_conv_args* a, void* stream) {
@@ -840,6 +856,8 @@ extern "C" int gl_conv3x3(const gl_conv_args* a, void* stream) {
     g.a2 = nullptr;
     g.M = a->B * a->Hout * a->Wout;
     g.K = 9 * a->Cin;
+    g.ldw = g.K;
+    g.kwrap = 0;
     ConvGeom cg{reinterpret_cast<const half_t*>(a->in), a->B, a->Hin, a->Win, a->Cin, a->Hout, a->Wout, a->stride,
                 a->upsample2x, nullptr};
     return dispatch<true>(g, cg, (hipStream_t)stream);

@@ -93,6 +93,13 @@ __device__ __forceinline__ void fin8_store(const gl_gemm_args& p, float gate, in
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = (half_t)v[j];
     st16(o16 + (size_t)m * ld16o + n, *reinterpret_cast<uint4*>(&o));
+    if (p.out_mode == GL_OUT_F16_HILO) {
+        // split-fp16 operand for the next 1x1 product: the fp16 residual goes N columns to the right
+        half8_t l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) l[j] = (half_t)(v[j] - (float)o[j]);
+        st16(o16 + (size_t)m * ld16o + p.N + n, *reinterpret_cast<uint4*>(&l));
+    }
 }
 
 __device__ __forceinline__ void finish8(const gl_gemm_args& p, float gate, int m, int n, float (&v)[8]) {

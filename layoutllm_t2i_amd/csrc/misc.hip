@@ -246,6 +246,8 @@ static gl_opts make_default_opts() {
     o.v[24] = 64;  o.v[25] = 1;   o.v[27] = 1;   o.v[29] = 1;   o.v[30] = 1;
     o.v[31] = 200; o.v[32] = 0;   o.v[33] = 0;   o.v[34] = 11;  o.v[35] = 5;
     o.v[37] = 1;
+    o.v[41] = 1;
+    o.v[42] = 1;
     return o;
 }
 gl_opts g_gl_opts = make_default_opts();
@@ -255,7 +257,7 @@ int g_gl_option_epoch = 0;
 bool gl_opts_store(gl_opts& t, int key, int value) {
     switch (key) {
         case 2: case 3: case 4: case 6: case 7: case 8: case 10: case 13: case 17: case 20: case 21: case 23: case 24: case 25:
-        case 27: case 29: case 30: case 31: case 32: case 33: case 35: case 37:
+        case 27: case 29: case 30: case 31: case 32: case 33: case 35: case 37: case 41: case 42:
             t.v[key] = value;
             return true;
         case 5:                                  // < 0: the built-in thresholds (plain GEMM 300 tiles, conv 450)
@@ -278,6 +280,7 @@ extern "C" int gl_abi_version(void) { return GL_ABI_VERSION; }
 extern "C" int gl_sizeof_gemm_args(void) { return (int)sizeof(gl_gemm_args); }
 extern "C" int gl_sizeof_conv_args(void) { return (int)sizeof(gl_conv_args); }
 extern "C" int gl_sizeof_attn_args(void) { return (int)sizeof(gl_attn_args); }
+extern "C" int gl_sizeof_gn_args(void) { return (int)sizeof(gl_gn_args); }
 extern "C" int gl_init(void) {
     const int e = gl_init_gemm();
     return e ? e : gl_init_ff();

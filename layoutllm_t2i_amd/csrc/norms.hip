@@ -14,13 +14,57 @@
 
 namespace {
 
-__device__ __forceinline__ const half_t* src_ptr(const half_t* x1, int C1, const half_t* x2, int C2, size_t pix,
-                                                 int c, int* cl) {
-    // channel c of the virtual concat [x1 | x2] at flat pixel index `pix`
-    if (c < C1) { *cl = c; return x1 + pix * C1; }
-    *cl = c - C1;
-    return x2 + pix * C2;
+// An 8-channel piece of an input row, fp16 (one 16-byte load) or fp32 (the residual stream: two 16-byte loads).  The
+// register-resident kernels keep the piece in its storage form (4 or 8 VGPRs).
+template <bool XF32> struct GnVec;
+template <> struct GnVec<false> {
+    uint4 r;
+    __device__ __forceinline__ void zero() { r = make_uint4(0u, 0u, 0u, 0u); }
+    __device__ __forceinline__ void load(const void* base, size_t elem) { r = ld16(reinterpret_cast<const half_t*>(base) + elem); }
+    __device__ __forceinline__ void get(float (&v)[8]) {
+        // opaque to the optimiser: the register-resident kernels call get() once per pass, and without this the converted
+        // floats of ALL vectors are kept live across the passes (8 instead of 4 VGPRs per vector: hundreds of spills at NV = 22)
+        asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w));
+        const half8_t hv = *reinterpret_cast<const half8_t*>(&r);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)hv[j];
+    }
+};
+template <> struct GnVec<true> {
+    float4 a, b;
+    __device__ __forceinline__ void zero() { a = make_float4(0.f, 0.f, 0.f, 0.f); b = a; }
+    __device__ __forceinline__ void load(const void* base, size_t elem) {
+        const float* p = reinterpret_cast<const float*>(base) + elem;
+        a = *reinterpret_cast<const float4*>(p);
+        b = *reinterpret_cast<const float4*>(p + 4);
+    }
+    __device__ __forceinline__ void get(float (&v)[8]) const {
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+};
+
+// fp16 store of 8 values; with `lo` also the fp16 residual v - float(fp16(v)) (split-fp16 operand, DESIGN.md 4: the
+// consumer multiplies [hi | lo] against [W | W], which restores ~22 mantissa bits of the activation operand)
+__device__ __forceinline__ void store_hl(half_t* hi, half_t* lo, const float (&v)[8]) {
+    half8_t h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[j] = (half_t)v[j];
+    st16(hi, *reinterpret_cast<uint4*>(&h));
+    if (lo != nullptr) {
+        half8_t l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) l[j] = (half_t)(v[j] - (float)h[j]);
+        st16(lo, *reinterpret_cast<uint4*>(&l));
+    }
 }
+
+// outputs of one GroupNorm launch (all row-major over the B * HW pixels):
+//   out [*, ldo] fp16 normalised rows; out_lo (optional, same stride) their fp16 residuals;
+//   raw (optional) [*, ldraw]: columns [0, C) = fp16(x), [C, 2C) = fp16(x - fp16(x)) of the INPUT concat
+struct GnOut {
+    half_t* out; half_t* out_lo; int ldo;
+    half_t* raw; int ldraw;
+};
 
 // grid (nchunk, B); block 256.  thread -> fixed 8-channel vector(s), strided over the chunk's pixels.
 //
@@ -32,8 +76,9 @@ __device__ __forceinline__ const half_t* src_ptr(const half_t* x1, int C1, const
 // in a fixed order (bitwise reproducible, no atomics).  partial[b][chunk][group] = (mean, M2); the element count of
 // a chunk follows from the geometry.
 constexpr int GN_MAX_C = 2560;
-__global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict__ x1, int C1,
-                                                       const half_t* __restrict__ x2, int C2, int HW, int nchunk,
+template <bool XF32>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const void* __restrict__ x1, int C1,
+                                                       const void* __restrict__ x2, int C2, int HW, int nchunk,
                                                        float* __restrict__ partial) {
     __shared__ float lmean[GN_MAX_C];
     __shared__ float lm2[GN_MAX_C];
@@ -61,38 +106,41 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict_
             for (int j = 0; j < 8; ++j) { s[j] = 0.0f; ss[j] = 0.0f; sh[j] = 0.0f; }
             const int c = vec * 8;
             if (npix > 0) {
-                int cl;
-                const half_t* base = src_ptr(x1, C1, x2, C2, (size_t)b * HW + first, c, &cl) + cl;
-                const size_t step = (size_t)nplanes * (c < C1 ? C1 : C2);
+                const void* src = c < C1 ? x1 : x2;
+                const int cs = c < C1 ? C1 : C2;
+                size_t e = ((size_t)b * HW + first) * cs + (c < C1 ? c : c - C1);
+                const size_t step = (size_t)nplanes * cs;
                 {
-                    uint4 raw = ld16(base);
-                    const half8_t hv = *reinterpret_cast<half8_t*>(&raw);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) sh[j] = (float)hv[j];
+                    GnVec<XF32> r0;
+                    r0.load(src, e);
+                    r0.get(sh);
                 }
                 int pix = first;
-                // 4 independent 16-byte loads in flight per thread
-                for (; pix + 3 * nplanes < p1; pix += 4 * nplanes, base += 4 * step) {
-                    uint4 raw[4];
+                // 4 independent loads in flight per thread
+                for (; pix + 3 * nplanes < p1; pix += 4 * nplanes, e += 4 * step) {
+                    GnVec<XF32> raw[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) raw[u] = ld16(base + u * step);
+                    for (int u = 0; u < 4; ++u) raw[u].load(src, e + u * step);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const half8_t hv = *reinterpret_cast<half8_t*>(&raw[u]);
+                        float xv[8];
+                        raw[u].get(xv);
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
-                            const float f = (float)hv[j] - sh[j];
+                            const float f = xv[j] - sh[j];
                             s[j] += f;
                             ss[j] = fmaf(f, f, ss[j]);
                         }
                     }
                 }
-                for (; pix < p1; pix += nplanes, base += step) {
-                    uint4 raw = ld16(base);
-                    const half8_t hv = *reinterpret_cast<half8_t*>(&raw);
+                for (; pix < p1; pix += nplanes, e += step) {
+                    GnVec<XF32> raw;
+                    raw.load(src, e);
+                    float xv[8];
+                    raw.get(xv);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float f = (float)hv[j] - sh[j];
+                        const float f = xv[j] - sh[j];
                         s[j] += f;
                         ss[j] = fmaf(f, f, ss[j]);
                     }
@@ -131,16 +179,17 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict_
     }
 }
 
-// grid (nblk, B); block 256: normalise (+SiLU) the virtual concat into out [B, HW, C].
+// grid (nblk, B); block 256: normalise (+SiLU) the virtual concat into out [B, HW, ldo].
 // A thread owns fixed 8-channel vectors (like gn_stats), so the per-channel affine
 //   y = x * (rstd*gamma) + (beta - mean*rstd*gamma)
 // is folded into 8 (scale, shift) register pairs once and the pixel loop is one 16-byte load, 8 FMAs
 // (+SiLU) and one 16-byte store with no integer division.
-__global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict__ x1, int C1,
-                                                       const half_t* __restrict__ x2, int C2, int HW, int nchunk,
+template <bool XF32>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const void* __restrict__ x1, int C1,
+                                                       const void* __restrict__ x2, int C2, int HW, int nchunk,
                                                        const float* __restrict__ partial,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       float eps, int silu, half_t* __restrict__ out, int ppb) {
+                                                       float eps, int silu, GnOut o, int ppb) {
     __shared__ float mean_s[32], rstd_s[32];
     __shared__ float red_s[8][32], red_q[8][32];
     const int C = C1 + C2;
@@ -202,41 +251,42 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
             sc[j] = a;
             sh[j] = beta[c + j] - mean_s[g] * a;
         }
-        const half_t* src;
-        int cs, cl;
-        if (c < C1) { src = x1; cs = C1; cl = c; } else { src = x2; cs = C2; cl = c - C1; }
-        const half_t* sp = src + ((size_t)b * HW + p0 + plane) * cs + cl;
-        half_t* dp = out + ((size_t)b * HW + p0 + plane) * C + c;
-        const size_t sstep = (size_t)nplanes * cs, dstep = (size_t)nplanes * C;
-        int pix = p0 + plane;
-        for (; pix + 3 * nplanes < p1; pix += 4 * nplanes, sp += 4 * sstep, dp += 4 * dstep) {
-            uint4 raw[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) raw[u] = ld16(sp + u * sstep);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const half8_t hv = *reinterpret_cast<half8_t*>(&raw[u]);
-                half8_t ov;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float v = fmaf((float)hv[j], sc[j], sh[j]);
-                    if (silu) v = silu_f(v);
-                    ov[j] = (half_t)v;
-                }
-                st16(dp + u * dstep, *reinterpret_cast<uint4*>(&ov));
-            }
-        }
-        for (; pix < p1; pix += nplanes, sp += sstep, dp += dstep) {
-            uint4 raw = ld16(sp);
-            const half8_t hv = *reinterpret_cast<half8_t*>(&raw);
-            half8_t ov;
+        const void* src = c < C1 ? x1 : x2;
+        const int cs = c < C1 ? C1 : C2;
+        size_t e = ((size_t)b * HW + p0 + plane) * cs + (c < C1 ? c : c - C1);
+        const size_t row0 = (size_t)b * HW + p0 + plane;
+        half_t* dp = o.out + row0 * o.ldo + c;
+        half_t* dl = o.out_lo ? o.out_lo + row0 * o.ldo + c : nullptr;
+        half_t* rp = o.raw ? o.raw + row0 * o.ldraw + c : nullptr;
+        const size_t sstep = (size_t)nplanes * cs, dstep = (size_t)nplanes * o.ldo, rstep = (size_t)nplanes * o.ldraw;
+        auto one = [&](GnVec<XF32>& raw, size_t u) {
+            float xv[8], yv[8];
+            raw.get(xv);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                float v = fmaf((float)hv[j], sc[j], sh[j]);
+                float v = fmaf(xv[j], sc[j], sh[j]);
                 if (silu) v = silu_f(v);
-                ov[j] = (half_t)v;
+                yv[j] = v;
             }
-            st16(dp, *reinterpret_cast<uint4*>(&ov));
+            store_hl(dp + u * dstep, dl ? dl + u * dstep : nullptr, yv);
+            if (rp) store_hl(rp + u * rstep, rp + u * rstep + C, xv);
+        };
+        int pix = p0 + plane;
+        for (; pix + 3 * nplanes < p1; pix += 4 * nplanes, e += 4 * sstep, dp += 4 * dstep) {
+            GnVec<XF32> raw[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) raw[u].load(src, e + u * sstep);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) one(raw[u], u);
+            if (dl) dl += 4 * dstep;
+            if (rp) rp += 4 * rstep;
+        }
+        for (; pix < p1; pix += nplanes, e += sstep, dp += dstep) {
+            GnVec<XF32> raw;
+            raw.load(src, e);
+            one(raw, 0);
+            if (dl) dl += dstep;
+            if (rp) rp += rstep;
         }
     }
 }
@@ -246,10 +296,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
 // squared deviations: exact, no E[x^2] - mean^2 cancellation) and normalised from the registers -- instead of
 // gn_stats + gn_apply, which at these sizes are two latency-bound launches that each re-read the tensor.
 // Needs whole 8-channel vectors per group (C % 256 == 0) and HW * C / 256 <= 256 * NV vectors.
-template <int NV>
-__global__ __launch_bounds__(256) void gn_fused_kernel(const half_t* __restrict__ x1, int C1, const half_t* __restrict__ x2, int C2,
+template <bool XF32, int NV>
+__global__ __launch_bounds__(256) void gn_fused_kernel(const void* __restrict__ x1, int C1, const void* __restrict__ x2, int C2,
                                                        int HW, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       float eps, int silu, half_t* __restrict__ out) {
+                                                       float eps, int silu, GnOut o) {
     __shared__ float red[4];
     const int C = C1 + C2;
     const int cpg = C / 32;
@@ -263,13 +313,13 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const half_t* __restrict_
         __syncthreads();
         return red[0] + red[1] + red[2] + red[3];
     };
-    uint4 raw[NV];
+    GnVec<XF32> raw[NV];
     int chan[NV], pix[NV];
     float s = 0.0f;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         const int idx = threadIdx.x + 256 * k;
-        raw[k] = make_uint4(0u, 0u, 0u, 0u);
+        raw[k].zero();
         chan[k] = -1;
         pix[k] = 0;
         if (idx < total) {
@@ -277,11 +327,11 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const half_t* __restrict_
             const int c = g * cpg + (idx - p * nv) * 8;
             chan[k] = c;
             pix[k] = p;
-            const half_t* src = (c < C1) ? x1 + ((size_t)b * HW + p) * C1 + c : x2 + ((size_t)b * HW + p) * C2 + (c - C1);
-            raw[k] = ld16(src);
-            const half8_t hv = *reinterpret_cast<half8_t*>(&raw[k]);
+            if (c < C1) raw[k].load(x1, ((size_t)b * HW + p) * C1 + c); else raw[k].load(x2, ((size_t)b * HW + p) * C2 + (c - C1));
+            float xv[8];
+            raw[k].get(xv);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s += (float)hv[j];
+            for (int j = 0; j < 8; ++j) s += xv[j];
         }
     }
     const float n = (float)cpg * (float)HW;
@@ -290,10 +340,11 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const half_t* __restrict_
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         if (chan[k] >= 0) {
-            const half8_t hv = *reinterpret_cast<half8_t*>(&raw[k]);
+            float xv[8];
+            raw[k].get(xv);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float d = (float)hv[j] - mean;
+                const float d = xv[j] - mean;
                 ss = fmaf(d, d, ss);
             }
         }
@@ -307,15 +358,17 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const half_t* __restrict_
             const float4 b0 = *reinterpret_cast<const float4*>(beta + c), b1 = *reinterpret_cast<const float4*>(beta + c + 4);
             const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
             const float bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-            const half8_t hv = *reinterpret_cast<half8_t*>(&raw[k]);
-            half8_t ov;
+            float xv[8], yv[8];
+            raw[k].get(xv);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                float v = ((float)hv[j] - mean) * rstd * gm[j] + bt[j];
+                float v = (xv[j] - mean) * rstd * gm[j] + bt[j];
                 if (silu) v = silu_f(v);
-                ov[j] = (half_t)v;
+                yv[j] = v;
             }
-            st16(out + ((size_t)b * HW + pix[k]) * C + c, *reinterpret_cast<uint4*>(&ov));
+            const size_t row = (size_t)b * HW + pix[k];
+            store_hl(o.out + row * o.ldo + c, o.out_lo ? o.out_lo + row * o.ldo + c : nullptr, yv);
+            if (o.raw) store_hl(o.raw + row * o.ldraw + c, o.raw + row * o.ldraw + C + c, xv);
         }
     }
 }
@@ -327,10 +380,10 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const half_t* __restrict_
 // vector spans at most two groups: it contributes a low and a high part), and the rows are normalised from the
 // registers -- one read + one write of the tensor instead of gn_stats (read) + gn_apply (read + write) in two
 // latency-bound launches.  80..240-byte pieces per pixel: ~80 % sector efficiency, still far cheaper than a second pass.
-template <int NV, int NT>
-__global__ __launch_bounds__(NT) void gn_bundle_kernel(const half_t* __restrict__ x1, int C1, const half_t* __restrict__ x2, int C2,
+template <bool XF32, int NV, int NT>
+__global__ __launch_bounds__(NT) void gn_bundle_kernel(const void* __restrict__ x1, int C1, const void* __restrict__ x2, int C2,
                                                        int HW, int cpg, int gb, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, float eps, int silu, half_t* __restrict__ out) {
+                                                       const float* __restrict__ beta, float eps, int silu, GnOut o) {
     constexpr int NWV = (NT + 63) / 64;
     __shared__ float red[NWV][4];
     __shared__ float stat[2][4];
@@ -345,8 +398,9 @@ __global__ __launch_bounds__(NT) void gn_bundle_kernel(const half_t* __restrict_
     const int wave = threadIdx.x >> 6;
     const int g0 = (v * 8) / cpg;            // group (within the bundle) of the vector's first channel
     const int js = (g0 + 1) * cpg - v * 8;   // elements [0, js) belong to g0, the rest to g0 + 1 (a vector spans <= 2 groups)
-    const half_t* src = (c < C1) ? x1 + (size_t)b * HW * C1 + c : x2 + (size_t)b * HW * C2 + (c - C1);
+    const void* src = (c < C1) ? x1 : x2;
     const int sstride = (c < C1) ? C1 : C2;
+    const size_t e0 = (size_t)b * HW * sstride + ((c < C1) ? c : c - C1);
     // block-wide sums of the (up to 4) per-group values
     auto bsum4 = [&](float lo, float hi, int slot) {
         float vq[4];
@@ -365,19 +419,19 @@ __global__ __launch_bounds__(NT) void gn_bundle_kernel(const half_t* __restrict_
         }
         __syncthreads();
     };
-    uint4 raw[NV];
+    GnVec<XF32> raw[NV];
     float lo = 0.0f, hi = 0.0f;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         const int p = pl + ps * k;
-        raw[k] = make_uint4(0u, 0u, 0u, 0u);
+        raw[k].zero();
         if (p < HW) {
-            raw[k] = ld16(src + (size_t)p * sstride);
-            const half8_t hv = *reinterpret_cast<half8_t*>(&raw[k]);
+            raw[k].load(src, e0 + (size_t)p * sstride);
+            float xv[8];
+            raw[k].get(xv);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float f = (float)hv[j];
-                if (j < js) lo += f; else hi += f;
+                if (j < js) lo += xv[j]; else hi += xv[j];
             }
         }
     }
@@ -389,10 +443,11 @@ __global__ __launch_bounds__(NT) void gn_bundle_kernel(const half_t* __restrict_
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         if (pl + ps * k < HW) {
-            const half8_t hv = *reinterpret_cast<half8_t*>(&raw[k]);
+            float xv[8];
+            raw[k].get(xv);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float d = (float)hv[j] - (j < js ? m0 : m1);
+                const float d = xv[j] - (j < js ? m0 : m1);
                 if (j < js) lo = fmaf(d, d, lo); else hi = fmaf(d, d, hi);
             }
         }
@@ -413,20 +468,21 @@ __global__ __launch_bounds__(NT) void gn_bundle_kernel(const half_t* __restrict_
             sh[j] = bt[j] - m * sc[j];
         }
     }
-    half_t* dst = out + (size_t)b * HW * C + c;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         const int p = pl + ps * k;
         if (p < HW) {
-            const half8_t hv = *reinterpret_cast<half8_t*>(&raw[k]);
-            half8_t ov;
+            float xv[8], yv[8];
+            raw[k].get(xv);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                float val = fmaf((float)hv[j], sc[j], sh[j]);
+                float val = fmaf(xv[j], sc[j], sh[j]);
                 if (silu) val = silu_f(val);
-                ov[j] = (half_t)val;
+                yv[j] = val;
             }
-            st16(dst + (size_t)p * C, *reinterpret_cast<uint4*>(&ov));
+            const size_t row = (size_t)b * HW + p;
+            store_hl(o.out + row * o.ldo + c, o.out_lo ? o.out_lo + row * o.ldo + c : nullptr, yv);
+            if (o.raw) store_hl(o.raw + row * o.ldraw + c, o.raw + row * o.ldraw + C + c, xv);
         }
     }
 }
@@ -523,38 +579,63 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
 
 }  // namespace
 
-extern "C" int gl_groupnorm_stats(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t B, int32_t HW,
-                                  float* partial, int32_t nchunk, void* stream) {
-    const int C = C1 + (x2 ? C2 : 0);
-    if (!x1 || !partial || C <= 0 || C > GN_MAX_C || (C % 32) || (C1 % 8) || (x2 && (C2 % 8)) || nchunk <= 0 || nchunk > HW)
+static int gn_stats_launch(const gl_gn_args& a, hipStream_t st) {
+    const int C2 = a.x2 ? a.C2 : 0;
+    const int C = a.C1 + C2;
+    if (!a.x1 || !a.partial || C <= 0 || C > GN_MAX_C || (C % 32) || (a.C1 % 8) || (C2 % 8) || a.nchunk <= 0 || a.nchunk > a.HW)
         return GL_ERR_BAD_ARG;
-    gn_stats_kernel<<<dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream>>>(
-        reinterpret_cast<const half_t*>(x1), C1, reinterpret_cast<const half_t*>(x2), x2 ? C2 : 0, HW, nchunk, partial);
+    if (a.x_f32) gn_stats_kernel<true><<<dim3(a.nchunk, a.B), dim3(256), 0, st>>>(a.x1, a.C1, a.x2, C2, a.HW, a.nchunk, a.partial);
+    else gn_stats_kernel<false><<<dim3(a.nchunk, a.B), dim3(256), 0, st>>>(a.x1, a.C1, a.x2, C2, a.HW, a.nchunk, a.partial);
     GL_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int gl_groupnorm_apply(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t B, int32_t HW,
-                                  const float* partial, int32_t nchunk, const float* gamma, const float* beta,
-                                  float eps, int32_t silu, void* out, void* stream) {
-    const int C = C1 + (x2 ? C2 : 0);
-    if (!x1 || !partial || !gamma || !beta || !out || C <= 0 || (C % 32) || (C1 % 8) || (x2 && (C2 % 8)))
-        return GL_ERR_BAD_ARG;
+static inline GnOut gn_out(const gl_gn_args& a, int C) {
+    GnOut o;
+    o.out = reinterpret_cast<half_t*>(a.out);
+    o.out_lo = reinterpret_cast<half_t*>(a.out_lo);
+    o.ldo = a.ldo > 0 ? a.ldo : C;
+    o.raw = reinterpret_cast<half_t*>(a.raw);
+    o.ldraw = a.ldraw;
+    return o;
+}
+
+static int gn_apply_launch(const gl_gn_args& a, hipStream_t st) {
+    const int C2 = a.x2 ? a.C2 : 0;
+    const int C = a.C1 + C2;
+    if (!a.x1 || !a.partial || !a.gamma || !a.beta || !a.out || C <= 0 || (C % 32) || (a.C1 % 8) || (C2 % 8)) return GL_ERR_BAD_ARG;
     // pixels per block: >= 2 pixels per pixel-lane, ~1-2k blocks at the 64x64 level
     const int nvec = C / 8;
     const int nplanes = 256 / (nvec < 256 ? nvec : 256);
     int ppb = g_gn_ppb * nplanes;
     if (ppb < 16) ppb = 16;
-    if (ppb > HW) ppb = HW;
-    const int nblk = gl_cdiv(HW, ppb);
-    gn_apply_kernel<<<dim3(nblk, B), dim3(256), 0, (hipStream_t)stream>>>(
-        reinterpret_cast<const half_t*>(x1), C1, reinterpret_cast<const half_t*>(x2), x2 ? C2 : 0, HW, nchunk, partial,
-        gamma, beta, eps, silu, reinterpret_cast<half_t*>(out), ppb);
+    if (ppb > a.HW) ppb = a.HW;
+    const int nblk = gl_cdiv(a.HW, ppb);
+    const GnOut o = gn_out(a, C);
+    if (a.x_f32)
+        gn_apply_kernel<true><<<dim3(nblk, a.B), dim3(256), 0, st>>>(a.x1, a.C1, a.x2, C2, a.HW, a.nchunk, a.partial, a.gamma, a.beta, a.eps, a.silu, o, ppb);
+    else
+        gn_apply_kernel<false><<<dim3(nblk, a.B), dim3(256), 0, st>>>(a.x1, a.C1, a.x2, C2, a.HW, a.nchunk, a.partial, a.gamma, a.beta, a.eps, a.silu, o, ppb);
     GL_CHECK_LAUNCH();
     return 0;
 }
 
-// how many launches gl_groupnorm issues for this shape: 1 (fused small-map kernel) or 2 (statistics + apply)
+extern "C" int gl_groupnorm_stats(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t B, int32_t HW,
+                                  float* partial, int32_t nchunk, void* stream) {
+    gl_gn_args a{};
+    a.x1 = x1; a.C1 = C1; a.x2 = x2; a.C2 = C2; a.B = B; a.HW = HW; a.partial = partial; a.nchunk = nchunk;
+    return gn_stats_launch(a, (hipStream_t)stream);
+}
+
+extern "C" int gl_groupnorm_apply(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t B, int32_t HW,
+                                  const float* partial, int32_t nchunk, const float* gamma, const float* beta,
+                                  float eps, int32_t silu, void* out, void* stream) {
+    gl_gn_args a{};
+    a.x1 = x1; a.C1 = C1; a.x2 = x2; a.C2 = C2; a.B = B; a.HW = HW; a.partial = const_cast<float*>(partial); a.nchunk = nchunk;
+    a.gamma = gamma; a.beta = beta; a.eps = eps; a.silu = silu; a.out = out;
+    return gn_apply_launch(a, (hipStream_t)stream);
+}
+
 // bundle geometry of gn_bundle_kernel: groups per bundle (1, 2 or 4) such that the bundle is whole 8-channel vectors
 static inline int gn_bundle_groups(int C) {
     const int cpg = C / 32;
@@ -564,7 +645,9 @@ static inline int gn_bundle_groups(int C) {
     return 0;
 }
 
-extern "C" int gl_groupnorm_launches(int32_t C, int32_t HW) {
+// how many launches gl_groupnorm issues for this shape: 1 (a register-resident single-launch kernel) or 2 (statistics +
+// apply).  fp32 inputs hold twice the registers per vector, so the bundle form covers half the slab.
+extern "C" int gl_groupnorm_launches_ex(int32_t C, int32_t HW, int32_t x_f32) {
     if (!g_gn_fused) return 2;
     if ((C % 256) == 0) {
         const int64_t vecs = (int64_t)HW * (C / 256);
@@ -578,55 +661,71 @@ extern "C" int gl_groupnorm_launches(int32_t C, int32_t HW) {
     // one block moves the whole HW x bundle slab: measured faster than the two launches up to 80 KB per block (640 ch @ 32x32:
     // 17.4 -> 15.0 us, 640 ch @ 16x16: 15.5 -> 8.1 us), slower beyond (320 ch @ 64x64 = 320 KB per block on 64 blocks: 22.8 -> 43 us)
     if ((int64_t)HW * nvp * 16 > 80 * 1024) return 2;
-    return gl_cdiv(HW, 960 / nvp) <= 22 ? 1 : 2;        // and the slab fits the registers of one 960-thread block
+    return gl_cdiv(HW, 960 / nvp) <= (x_f32 ? 8 : 22) ? 1 : 2;        // and the slab fits the registers of one 960-thread block
+}
+extern "C" int gl_groupnorm_launches(int32_t C, int32_t HW) { return gl_groupnorm_launches_ex(C, HW, 0); }
+
+template <bool XF32>
+static int gn_single_launch(const gl_gn_args& a, int C, bool small_map, hipStream_t st) {
+    const int C2 = a.x2 ? a.C2 : 0;
+    const GnOut o = gn_out(a, C);
+    if (small_map) {
+        const int64_t vecs = (int64_t)a.HW * (C / 256);
+        const dim3 grid(32, a.B), blk(256);
+        if (vecs <= 256 * 3) gn_fused_kernel<XF32, 3><<<grid, blk, 0, st>>>(a.x1, a.C1, a.x2, C2, a.HW, a.gamma, a.beta, a.eps, a.silu, o);
+        else if (vecs <= 256 * 5) gn_fused_kernel<XF32, 5><<<grid, blk, 0, st>>>(a.x1, a.C1, a.x2, C2, a.HW, a.gamma, a.beta, a.eps, a.silu, o);
+        else gn_fused_kernel<XF32, 10><<<grid, blk, 0, st>>>(a.x1, a.C1, a.x2, C2, a.HW, a.gamma, a.beta, a.eps, a.silu, o);
+        GL_CHECK_LAUNCH();
+        return 0;
+    }
+    const int cpg = C / 32, gb = gn_bundle_groups(C);
+    const dim3 grid(32 / gb, a.B);
+#define GL_GNB(V, T) gn_bundle_kernel<XF32, V, T><<<grid, dim3(T), 0, st>>>(a.x1, a.C1, a.x2, C2, a.HW, cpg, gb, a.gamma, a.beta, a.eps, a.silu, o)
+    // block sizes that are whole multiples of the vectors per pixel (5, 10 or 15): 320 = 5 waves, 960 = 15 waves
+    const int nvp = cpg * gb / 8;
+    if (nvp == 15) {
+        const int passes = gl_cdiv(a.HW, 960 / 15);
+        if (passes <= 4) GL_GNB(4, 960); else if (passes <= 8) GL_GNB(8, 960);
+        else if constexpr (XF32) return GL_ERR_UNSUPPORTED;
+        else if (passes <= 16) GL_GNB(16, 960); else GL_GNB(22, 960);
+    } else {
+        const int p320 = gl_cdiv(a.HW, 320 / nvp);
+        const int p960 = gl_cdiv(a.HW, 960 / nvp);
+        if (p320 <= 4) GL_GNB(4, 320); else if (p320 <= 8) GL_GNB(8, 320);
+        else if (p960 <= 8) GL_GNB(8, 960);
+        else if constexpr (XF32) return GL_ERR_UNSUPPORTED;
+        else if (p960 <= 16) GL_GNB(16, 960); else GL_GNB(22, 960);
+    }
+#undef GL_GNB
+    GL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gl_groupnorm_ex(const gl_gn_args* ap, void* stream) {
+    if (!ap) return GL_ERR_BAD_ARG;
+    const gl_gn_args& a = *ap;
+    const int C2 = a.x2 ? a.C2 : 0;
+    const int C = a.C1 + C2;
+    if (!a.x1 || !a.gamma || !a.beta || !a.out || C <= 0 || (C % 32) || (a.C1 % 8) || (C2 % 8) || a.B <= 0 || a.HW <= 0) return GL_ERR_BAD_ARG;
+    const int ldo = a.ldo > 0 ? a.ldo : C;
+    if (ldo < C || (ldo % 8) != 0) return GL_ERR_BAD_ARG;
+    if (a.raw != nullptr && (a.ldraw < 2 * C || (a.ldraw % 8) != 0)) return GL_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const bool small_map = g_gn_fused && (C % 256) == 0 && (int64_t)a.HW * (C / 256) <= 256 * 10;
+    if (small_map || gl_groupnorm_launches_ex(C, a.HW, a.x_f32) == 1)
+        return a.x_f32 ? gn_single_launch<true>(a, C, small_map, st) : gn_single_launch<false>(a, C, small_map, st);
+    if (!a.partial || a.nchunk <= 0) return GL_ERR_BAD_ARG;
+    const int rc = gn_stats_launch(a, st);
+    if (rc != 0) return rc;
+    return gn_apply_launch(a, st);
 }
 
 extern "C" int gl_groupnorm(const void* x1, int32_t C1, const void* x2, int32_t C2, int32_t B, int32_t HW, const float* gamma,
                             const float* beta, float eps, int32_t silu, void* out, float* partial, int32_t nchunk, void* stream) {
-    const int C = C1 + (x2 ? C2 : 0);
-    if (!x1 || !gamma || !beta || !out || C <= 0 || (C % 32) || (C1 % 8) || (x2 && (C2 % 8))) return GL_ERR_BAD_ARG;
-    const bool small_map = g_gn_fused && (C % 256) == 0 && (int64_t)HW * (C / 256) <= 256 * 10;
-    if (!small_map && gl_groupnorm_launches(C, HW) == 1) {
-        const int cpg = C / 32, gb = gn_bundle_groups(C);
-        const dim3 grid(32 / gb, B);
-        const half_t* a = reinterpret_cast<const half_t*>(x1);
-        const half_t* b2 = reinterpret_cast<const half_t*>(x2);
-        half_t* o = reinterpret_cast<half_t*>(out);
-        hipStream_t st = (hipStream_t)stream;
-        const int c2 = x2 ? C2 : 0;
-#define GL_GNB(V, T) gn_bundle_kernel<V, T><<<grid, dim3(T), 0, st>>>(a, C1, b2, c2, HW, cpg, gb, gamma, beta, eps, silu, o)
-        // block sizes that are whole multiples of the vectors per pixel (5, 10 or 15): 320 = 5 waves, 960 = 15 waves
-        const int nvp = cpg * gb / 8;
-        if (nvp == 15) {
-            const int passes = gl_cdiv(HW, 960 / 15);
-            if (passes <= 4) GL_GNB(4, 960); else if (passes <= 8) GL_GNB(8, 960); else if (passes <= 16) GL_GNB(16, 960); else GL_GNB(22, 960);
-        } else {
-            const int p320 = gl_cdiv(HW, 320 / nvp);
-            const int p960 = gl_cdiv(HW, 960 / nvp);
-            if (p320 <= 4) GL_GNB(4, 320); else if (p320 <= 8) GL_GNB(8, 320);
-            else if (p960 <= 8) GL_GNB(8, 960); else if (p960 <= 16) GL_GNB(16, 960); else GL_GNB(22, 960);
-        }
-#undef GL_GNB
-        GL_CHECK_LAUNCH();
-        return 0;
-    }
-    if (small_map) {
-        const int64_t vecs = (int64_t)HW * (C / 256);
-        const dim3 grid(32, B), blk(256);
-        const half_t* a = reinterpret_cast<const half_t*>(x1);
-        const half_t* b2 = reinterpret_cast<const half_t*>(x2);
-        half_t* o = reinterpret_cast<half_t*>(out);
-        hipStream_t st = (hipStream_t)stream;
-        if (vecs <= 256 * 3) gn_fused_kernel<3><<<grid, blk, 0, st>>>(a, C1, b2, x2 ? C2 : 0, HW, gamma, beta, eps, silu, o);
-        else if (vecs <= 256 * 5) gn_fused_kernel<5><<<grid, blk, 0, st>>>(a, C1, b2, x2 ? C2 : 0, HW, gamma, beta, eps, silu, o);
-        else gn_fused_kernel<10><<<grid, blk, 0, st>>>(a, C1, b2, x2 ? C2 : 0, HW, gamma, beta, eps, silu, o);
-        GL_CHECK_LAUNCH();
-        return 0;
-    }
-    if (!partial || nchunk <= 0) return GL_ERR_BAD_ARG;
-    const int rc = gl_groupnorm_stats(x1, C1, x2, C2, B, HW, partial, nchunk, stream);
-    if (rc != 0) return rc;
-    return gl_groupnorm_apply(x1, C1, x2, C2, B, HW, partial, nchunk, gamma, beta, eps, silu, out, stream);
+    gl_gn_args a{};
+    a.x1 = x1; a.C1 = C1; a.x2 = x2; a.C2 = C2; a.B = B; a.HW = HW; a.gamma = gamma; a.beta = beta; a.eps = eps; a.silu = silu;
+    a.out = out; a.partial = partial; a.nchunk = nchunk;
+    return gl_groupnorm_ex(&a, stream);
 }
 
 extern "C" int gl_layernorm(const void* x, int32_t ldx, int32_t x_f32, void* y, int32_t ldy, const float* gamma,

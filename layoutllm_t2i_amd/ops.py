@@ -11,8 +11,8 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import (EPI_BIAS, EPI_GATE_RES, EPI_GEGLU, EPI_RES, EPI_ROWBIAS, EPI_SILU, OUT_F16_ROWMAJOR, OUT_F32_NCHW,
-                   OUT_F32_ROWMAJOR, AttnArgs, ConvArgs, GemmArgs, check)
+from ._lib import (EPI_BIAS, EPI_GATE_RES, EPI_GEGLU, EPI_RES, EPI_ROWBIAS, EPI_SILU, OUT_F16_HILO, OUT_F16_ROWMAJOR, OUT_F32_NCHW,
+                   OUT_F32_ROWMAJOR, AttnArgs, ConvArgs, GemmArgs, GnArgs, check)
 
 F16 = torch.float16
 F32 = torch.float32
@@ -68,9 +68,9 @@ def _workspace(device) -> torch.Tensor:
     return t
 
 
-def _fill_epilogue(g: GemmArgs, epi, out, N_out, bias, res, gate, rowbias, rows_per_sample, nchw_hw, out16=None):
+def _fill_epilogue(g: GemmArgs, epi, out, N_out, bias, res, gate, rowbias, rows_per_sample, nchw_hw, out16=None, hilo_out=False):
     """``out`` fp16 [M, N] (plain), fp32 [M, N] (residual stream; ``out16`` = optional fp16 copy) or, with ``nchw_hw``,
-    fp32 NCHW.  ``res`` may be fp16 or fp32 (residual stream)."""
+    fp32 NCHW; ``hilo_out``: fp16 [M, 2N] = [hi | lo] (GL_OUT_F16_HILO).  ``res`` may be fp16 or fp32 (residual stream)."""
     ws = _workspace(out.device)
     g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     g.bias = _ptr(bias)
@@ -85,9 +85,11 @@ def _fill_epilogue(g: GemmArgs, epi, out, N_out, bias, res, gate, rowbias, rows_
         f32out = out.dtype == F32
         _req(out, F32 if f32out else F16, "out", 16 if f32out else 8)
         r, c, ld = _rows(out, "out")
-        if c != N_out:
-            raise ValueError(f"out has {c} columns, expected {N_out}")
-        g.out_mode, g.hw = (OUT_F32_ROWMAJOR if f32out else OUT_F16_ROWMAJOR), 0
+        if c != (2 * N_out if hilo_out else N_out):
+            raise ValueError(f"out has {c} columns, expected {2 * N_out if hilo_out else N_out}")
+        if hilo_out and f32out:
+            raise ValueError("hilo_out writes fp16")
+        g.out_mode, g.hw = (OUT_F16_HILO if hilo_out else OUT_F32_ROWMAJOR if f32out else OUT_F16_ROWMAJOR), 0
         g.out, g.ldc = out.data_ptr(), ld
         if out16 is not None:
             if not f32out:
@@ -111,8 +113,10 @@ def _fill_epilogue(g: GemmArgs, epi, out, N_out, bias, res, gate, rowbias, rows_
 
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias=None, epi: int = EPI_BIAS, res=None, gate=None,
          rowbias=None, rows_per_sample: int = 0, a2: Optional[torch.Tensor] = None, nchw_hw: int = 0, out16=None,
-         vt: Optional[torch.Tensor] = None, vt_col0: int = 0, vt_rows: int = 0) -> torch.Tensor:
+         vt: Optional[torch.Tensor] = None, vt_col0: int = 0, vt_rows: int = 0, hilo_a: bool = False, hilo_out: bool = False) -> torch.Tensor:
     """out = [a | a2] @ w.T (+ epilogue).  a [M, K1], a2 [M, K2] (optional), w [N, K1+K2] fp16.
+    ``hilo_a``: a is [M, 2K] = [hi | lo] of a split-fp16 activation and w [N, K] is used for both halves (gl_gemm_args.kwrap);
+    ``hilo_out``: out is fp16 [M, 2N] = [hi | lo] of the result (GL_OUT_F16_HILO).
     ``vt`` [B, H, d, ldvt] fp16: columns [vt_col0, N) are written there as gl_attention's V^T operand (row m = sample
     m // vt_rows, key m % vt_rows) instead of to ``out`` (fused QKV projection)."""
     _req(a, F16, "a")
@@ -129,11 +133,16 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias=None, epi: in
         if M2 != M or K1 + K2 != K:
             raise ValueError("a2 shape mismatch")
         g.a2, g.lda2, g.ksplit = a2.data_ptr(), lda2, K1
+    elif hilo_a:
+        if K1 != 2 * K:
+            raise ValueError(f"hilo_a: a has {K1} columns, expected 2 x K = {2 * K}")
+        g.kwrap, g.ldw = K, K
+        K = 2 * K
     elif K1 != K:
         raise ValueError(f"a has K={K1}, w has K={K}")
     g.w = w.data_ptr()
     g.M, g.N, g.K = M, N, K
-    _fill_epilogue(g, epi, out, N // 2 if epi == EPI_GEGLU else N, bias, res, gate, rowbias, rows_per_sample, nchw_hw, out16)
+    _fill_epilogue(g, epi, out, N // 2 if epi == EPI_GEGLU else N, bias, res, gate, rowbias, rows_per_sample, nchw_hw, out16, hilo_out)
     if vt is not None:
         _req(vt, F16, "vt")
         if vt.dim() != 4 or not vt.is_contiguous():
@@ -219,23 +228,39 @@ def gn_nchunk(HW: int) -> int:
 
 
 def groupnorm(x1: torch.Tensor, x2: Optional[torch.Tensor], B: int, HW: int, gamma: torch.Tensor, beta: torch.Tensor,
-              eps: float, silu: bool, out: torch.Tensor, partial: torch.Tensor) -> torch.Tensor:
-    """GroupNorm(32) of the channel concat [x1 | x2] (x2 may be None); x* are [B*HW, C*] fp16."""
-    _req(x1, F16, "x1")
+              eps: float, silu: bool, out: torch.Tensor, partial: torch.Tensor, out_lo: Optional[torch.Tensor] = None,
+              raw: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """GroupNorm(32) of the channel concat [x1 | x2] (x2 may be None); x* are [B*HW, C*], both fp16 or both fp32 (the residual
+    stream).  ``out`` fp16 [B*HW, C] (may be a column view of a wider buffer); ``out_lo`` (optional, same row stride): the
+    fp16 residual of the normalised rows; ``raw`` (optional) fp16 [B*HW, >= 2C]: the INPUT as [hi | lo] (gl_groupnorm_ex)."""
+    xf32 = x1.dtype == F32
+    _req(x1, F32 if xf32 else F16, "x1")
     C1 = x1.shape[-1]
     C2 = 0
     if x2 is not None:
-        _req(x2, F16, "x2")
+        _req(x2, F32 if xf32 else F16, "x2")
         C2 = x2.shape[-1]
     _req(gamma, F32, "gamma")
     _req(beta, F32, "beta")
-    _req(out, F16, "out")
+    for t_, n_ in ((out, "out"), (out_lo, "out_lo"), (raw, "raw")):
+        if t_ is not None and (t_.dtype != F16 or not t_.is_cuda or t_.stride(-1) != 1 or t_.data_ptr() % 16):
+            raise _lib.HipLibraryError(f"{n_}: fp16 GPU rows, 16-byte aligned")
     _req(partial, F32, "partial")
     nchunk = gn_nchunk(HW)
     if partial.numel() < B * nchunk * 64:
         raise ValueError("partial buffer too small")
-    check(_lib.lib().gl_groupnorm(x1.data_ptr(), C1, _ptr(x2), C2, B, HW, gamma.data_ptr(), beta.data_ptr(), eps, int(silu),
-                                  out.data_ptr(), partial.data_ptr(), nchunk, _stream()), "gl_groupnorm")
+    a = GnArgs()
+    a.x1, a.C1, a.x2, a.C2, a.x_f32, a.B, a.HW = x1.data_ptr(), C1, _ptr(x2), C2, int(xf32), B, HW
+    a.gamma, a.beta, a.eps, a.silu = gamma.data_ptr(), beta.data_ptr(), eps, int(silu)
+    a.out, a.ldo = out.data_ptr(), out.stride(0)
+    if out_lo is not None:
+        if out_lo.stride(0) != out.stride(0):
+            raise ValueError("out_lo must have out's row stride")
+        a.out_lo = out_lo.data_ptr()
+    if raw is not None:
+        a.raw, a.ldraw = raw.data_ptr(), raw.stride(0)
+    a.partial, a.nchunk = partial.data_ptr(), nchunk
+    check(_lib.lib().gl_groupnorm_ex(C.byref(a), _stream()), "gl_groupnorm_ex")
     return out
 
 
@@ -315,7 +340,7 @@ def ff_fused_applicable(Cc: int, M: int) -> bool:
     return bool(_lib.lib().gl_ff_fused_applicable(int(Cc), int(M)))
 
 
-def ff_fused(x, w1, b1, w2, b2, res, out, gate=None):
+def ff_fused(x, w1, b1, w2, b2, res, out, gate=None, hilo_out: bool = False):
     """out = res (+ | gate *) (GEGLU(x . w1^T + b1) . w2^T + b2) in one launch (gl_ff_fused; attention.py:38-62).
     x fp16 [M, C]; w1 / b1 the packed GEGLU operands [8C, C] / [8C]; w2 [C, 4C]; res fp32 or fp16 [M, C]; out fp16 or fp32."""
     _req(x, F16, "x")
@@ -333,7 +358,7 @@ def ff_fused(x, w1, b1, w2, b2, res, out, gate=None):
     a.w1, a.b1, a.w2, a.b2 = w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr()
     a.res, a.ldres, a.res_f32 = res.data_ptr(), res.stride(0), int(res.dtype == F32)
     a.gate = _ptr(gate)
-    a.out, a.ldc, a.out_mode = out.data_ptr(), out.stride(0), (OUT_F32_ROWMAJOR if out.dtype == F32 else OUT_F16_ROWMAJOR)
+    a.out, a.ldc, a.out_mode = out.data_ptr(), out.stride(0), (OUT_F16_HILO if hilo_out else OUT_F32_ROWMAJOR if out.dtype == F32 else OUT_F16_ROWMAJOR)
     a.M, a.C = M, Cc
     check(_lib.lib().gl_ff_fused(C.byref(a), _stream()), "gl_ff_fused")
     return out

@@ -57,6 +57,9 @@ class PyRefEngine:
         self._pool: Dict[Tuple, torch.Tensor] = {}
         self._gates: Dict[str, torch.Tensor] = {}
         self.st_layers: List[Layer] = self.plan.st_layers()
+        # the engine's precision mode (gl_set_option keys 41 / 42, both on by default): split-fp16 1x1 convs + GroupNorm on the fp32
+        # stream, and the ResBlock's first conv writing fp32
+        self.precise, self.h1_f32 = True, True
         # constant gates of rela_fuse, per-step gates of the fuser (scale * tanh(alpha))
         for l in self.st_layers:
             t = l.prefix + ".transformer_blocks.0"
@@ -161,33 +164,50 @@ class PyRefEngine:
         self._fuser_scale = scale
 
     # ------------------------------------------------------------------ layers
-    def _groupnorm(self, x1, x2, Bn, HW, p, eps, silu, tag):
+    def _groupnorm(self, x1, x2, Bn, HW, p, eps, silu, tag, hilo=False, raw_tag=None):
+        """x1 / x2 fp16 or fp32 (stream).  hilo: rows come out as [hi | lo] (2C wide); raw_tag: also the INPUT concat as [hi | lo]."""
         C = x1.shape[-1] + (x2.shape[-1] if x2 is not None else 0)
-        out = self.buf(tag, (Bn * HW, C))
+        out = self.buf(tag, (Bn * HW, 2 * C if hilo else C))
         partial = self.buf("gn.partial", (Bn * 64 * 64,), F32)
-        return ops.groupnorm(x1, x2, Bn, HW, self.W[p + ".g"], self.W[p + ".b"], eps, silu, out, partial)
+        raw = self.buf(raw_tag, (Bn * HW, 2 * C)) if raw_tag else None
+        ops.groupnorm(x1, x2, Bn, HW, self.W[p + ".g"], self.W[p + ".b"], eps, silu, out[:, :C], partial,
+                      out_lo=out[:, C:] if hilo else None, raw=raw)
+        return (out, raw) if raw_tag else out
 
-    def _stream(self, tag, M, C):
-        """fp32 residual-stream tensor + its fp16 copy for matrix-core consumers"""
-        return self.buf(tag + ".f32", (M, C), F32), self.buf(tag, (M, C))
+    def _stream(self, tag, M, C, need_h=True):
+        """fp32 residual-stream tensor + (where a down / up conv consumes it, or in the fp16-copy mode) its fp16 copy"""
+        return self.buf(tag + ".f32", (M, C), F32), (self.buf(tag, (M, C)) if need_h else None)
 
-    def _res_block(self, l: Layer, h, skip, Bn, side, emb_out, out_tag):
+    def _res_block(self, l: Layer, h, skip, Bn, side, emb_out, out_tag, need_h=True):
         """h = (fp32, fp16) stream pair; skip = (fp32, fp16) pair popped from the skip stack or None."""
         W, p = self.W, l.prefix
         HW = side * side
         h32, h16 = h
-        s16 = skip[1] if skip is not None else None
-        t = self._groupnorm(h16, s16, Bn, HW, p + ".in_layers.0", 1e-5, True, "rb.gn1")
+        split = None
+        if self.precise:
+            s32 = skip[0] if skip is not None else None
+            if l.cin != l.cout:
+                t, split = self._groupnorm(h32, s32, Bn, HW, p + ".in_layers.0", 1e-5, True, "rb.gn1", raw_tag="rb.split")
+            else:
+                t = self._groupnorm(h32, s32, Bn, HW, p + ".in_layers.0", 1e-5, True, "rb.gn1")
+        else:
+            s16 = skip[1] if skip is not None else None
+            t = self._groupnorm(h16, s16, Bn, HW, p + ".in_layers.0", 1e-5, True, "rb.gn1")
         off = self.P.emb_offsets[p]
-        h1 = ops.conv3x3(t, W[p + ".in_layers.2.w"], self.buf("rb.h1", (Bn * HW, l.cout)), Bn, side, side,
+        h1f = self.precise and self.h1_f32
+        h1 = ops.conv3x3(t, W[p + ".in_layers.2.w"], self.buf("rb.h1f" if h1f else "rb.h1", (Bn * HW, l.cout), F32 if h1f else F16), Bn, side, side,
                          W[p + ".in_layers.2.b"], epi=EPI_ROWBIAS, rowbias=emb_out[:, off:off + l.cout], rows_per_sample=HW)
         t2 = self._groupnorm(h1, None, Bn, HW, p + ".out_layers.0", 1e-5, True, "rb.gn2")
         if l.cin != l.cout:
-            sk = ops.gemm(h16, W[p + ".skip_connection.w"], self.buf("rb.skip.f32", (Bn * HW, l.cout), F32), W[p + ".skip_connection.b"], a2=s16)
+            skb = self.buf("rb.skip.f32", (Bn * HW, l.cout), F32)
+            if self.precise:
+                sk = ops.gemm(split, W[p + ".skip_connection.w"], skb, W[p + ".skip_connection.b"], hilo_a=True)
+            else:
+                sk = ops.gemm(h16, W[p + ".skip_connection.w"], skb, W[p + ".skip_connection.b"], a2=s16)
         else:
             assert skip is None
             sk = h32
-        o32, o16 = self._stream(out_tag, Bn * HW, l.cout)
+        o32, o16 = self._stream(out_tag, Bn * HW, l.cout, need_h)
         ops.conv3x3(t2, W[p + ".out_layers.3.w"], o32, Bn, side, side, W[p + ".out_layers.3.b"], epi=EPI_RES, res=sk, out16=o16)
         return o32, o16
 
@@ -205,16 +225,16 @@ class PyRefEngine:
                       Bn, H, d, Nq, Nk, d ** -0.5, q_prescaled=True)
         return att
 
-    def _feed_forward(self, xn, res, p, M, C, out, gate=None):
+    def _feed_forward(self, xn, res, p, M, C, out, gate=None, hilo_out=False):
         W = self.W
         if ops.ff_fused_applicable(C, M):
-            return ops.ff_fused(xn, W[p + ".ff1.w"], W[p + ".ff1.b"], W[p + ".ff2.w"], W[p + ".ff2.b"], res, out, gate=gate)
+            return ops.ff_fused(xn, W[p + ".ff1.w"], W[p + ".ff1.b"], W[p + ".ff2.w"], W[p + ".ff2.b"], res, out, gate=gate, hilo_out=hilo_out)
         hg = ops.gemm(xn, W[p + ".ff1.w"], self.buf("ff.h", (M, 4 * C)), W[p + ".ff1.b"], EPI_GEGLU)
         if gate is None:
-            return ops.gemm(hg, W[p + ".ff2.w"], out, W[p + ".ff2.b"], EPI_RES, res=res)
+            return ops.gemm(hg, W[p + ".ff2.w"], out, W[p + ".ff2.b"], EPI_RES, res=res, hilo_out=hilo_out)
         return ops.gemm(hg, W[p + ".ff2.w"], out, W[p + ".ff2.b"], EPI_GATE_RES, res=res, gate=gate)
 
-    def _spatial_transformer(self, l: Layer, li: int, x_in, Bn, side, fuser_on, out_tag):
+    def _spatial_transformer(self, l: Layer, li: int, x_in, Bn, side, fuser_on, out_tag, need_h=True):
         """x_in = (fp32, fp16) stream pair.  Inside the block x lives in fp32 only (two ping-pong buffers)."""
         W, c, cfg = self.W, self.cond, self.cfg
         p = l.prefix
@@ -225,8 +245,12 @@ class PyRefEngine:
         mo, R, Lc = c["mo"], c["R"], c["Lc"]
         xin32, xin16 = x_in
         xa, xb = self.buf("st.xa", (M, C), F32), self.buf("st.xb", (M, C), F32)
-        g0 = self._groupnorm(xin16, None, Bn, N, p + ".norm", 1e-6, False, "st.gn")
-        x = ops.gemm(g0, W[p + ".proj_in.w"], xa, W[p + ".proj_in.b"])
+        if self.precise:     # Normalize on the fp32 stream, [hi | lo] rows, both halves against proj_in's weight
+            g0 = self._groupnorm(xin32, None, Bn, N, p + ".norm", 1e-6, False, "st.gn", hilo=True)
+            x = ops.gemm(g0, W[p + ".proj_in.w"], xa, W[p + ".proj_in.b"], hilo_a=True)
+        else:
+            g0 = self._groupnorm(xin16, None, Bn, N, p + ".norm", 1e-6, False, "st.gn")
+            x = ops.gemm(g0, W[p + ".proj_in.w"], xa, W[p + ".proj_in.b"])
         nxt = lambda cur: xb if cur is xa else xa
         # --- attn1 (attention.py:395)
         n1 = ops.layernorm(x, self.buf("st.ln", (M, C)), W[t + ".norm1.g"], W[t + ".norm1.b"], Bn, N)
@@ -273,10 +297,10 @@ class PyRefEngine:
         x = ops.gemm(a2, W[t + ".attn2.o.w"], nxt(x), W[t + ".attn2.o.b"], EPI_RES, res=x)
         # --- GEGLU feed-forward (attention.py:401): the sum is only consumed by proj_out's matrix product -> fp16
         n3 = ops.layernorm(x, self.buf("st.ln", (M, C)), W[t + ".norm3.g"], W[t + ".norm3.b"], Bn, N)
-        x16 = self._feed_forward(n3, x, t + ".ff", M, C, self.buf("st.x6", (M, C)))
+        x16 = self._feed_forward(n3, x, t + ".ff", M, C, self.buf("st.x6", (M, 2 * C if self.precise else C)), hilo_out=self.precise)
         # --- proj_out + residual (attention.py:444-446)
-        o32, o16 = self._stream(out_tag, M, C)
-        ops.gemm(x16, W[p + ".proj_out.w"], o32, W[p + ".proj_out.b"], EPI_RES, res=xin32, out16=o16)
+        o32, o16 = self._stream(out_tag, M, C, need_h)
+        ops.gemm(x16, W[p + ".proj_out.w"], o32, W[p + ".proj_out.b"], EPI_RES, res=xin32, out16=o16, hilo_a=self.precise)
         return o32, o16
 
     # ------------------------------------------------------------------ one forward (eager launch sequence)
@@ -295,39 +319,45 @@ class PyRefEngine:
         xin = ops.pack_latent(x_lat, CIN_PAD, reps, self.buf("in.x", (Bn * side * side, CIN_PAD)))
         fc = "sd_first_conv" if sd_conv else "input_blocks.0.0"
         M0 = Bn * side * side
-        h = self._stream("skip.0", M0, mc)
+        # fp16 copies of stream tensors only where a down / up conv reads them (same rule as engine.hip)
+        first_kind = lambda blk: blk.layers[0].kind if blk is not None and blk.layers else None
+        wants_h = lambda kind: (not self.precise) or kind in ("down", "up")
+        ib = self.plan.input_blocks
+        h = self._stream("skip.0", M0, mc, wants_h(first_kind(ib[1] if len(ib) > 1 else None)))
         ops.conv3x3(xin, W[fc + ".w"], h[0], Bn, side, side, W[fc + ".b"], out16=h[1])
         skips: List[Tuple[Tuple[torch.Tensor, torch.Tensor], int]] = [(h, side)]
 
-        def run_block(b: Block, h, side, bi: str, skip=None):
+        def run_block(b: Block, h, side, bi: str, skip=None, nxt_block=None):
             for j, l in enumerate(b.layers):
                 tag = f"{bi}.{j}"
+                need_h = wants_h(b.layers[j + 1].kind if j + 1 < len(b.layers) else first_kind(nxt_block))
                 if l.kind == "res":
-                    h = self._res_block(l, h, skip, Bn, side, emb_out, tag)
+                    h = self._res_block(l, h, skip, Bn, side, emb_out, tag, need_h)
                     skip = None
                 elif l.kind == "st":
-                    h = self._spatial_transformer(l, st_index[l.prefix], h, Bn, side, fuser_on, tag)
+                    h = self._spatial_transformer(l, st_index[l.prefix], h, Bn, side, fuser_on, tag, need_h)
                 elif l.kind == "down":
-                    o = self._stream(tag, Bn * (side // 2) ** 2, l.cout)
+                    o = self._stream(tag, Bn * (side // 2) ** 2, l.cout, need_h)
                     ops.conv3x3(h[1], W[l.prefix + ".w"], o[0], Bn, side, side, W[l.prefix + ".b"], stride=2, out16=o[1])
                     h = o
                     side //= 2
                 elif l.kind == "up":
-                    o = self._stream(tag, Bn * (side * 2) ** 2, l.cout)
+                    o = self._stream(tag, Bn * (side * 2) ** 2, l.cout, need_h)
                     ops.conv3x3(h[1], W[l.prefix + ".w"], o[0], Bn, side, side, W[l.prefix + ".b"], upsample2x=True, out16=o[1])
                     h = o
                     side *= 2
             return h, side
 
-        for i, b in enumerate(self.plan.input_blocks[1:], start=1):
-            h, side = run_block(b, h, side, f"skip.{i}")
+        ob = self.plan.output_blocks
+        for i, b in enumerate(ib[1:], start=1):
+            h, side = run_block(b, h, side, f"skip.{i}", nxt_block=ib[i + 1] if i + 1 < len(ib) else self.plan.middle)
             skips.append((h, side))
-        h, side = run_block(self.plan.middle, h, side, "mid")
-        for i, b in enumerate(self.plan.output_blocks):
+        h, side = run_block(self.plan.middle, h, side, "mid", nxt_block=ob[0] if ob else None)
+        for i, b in enumerate(ob):
             sk, sside = skips.pop()
             assert sside == side
-            h, side = run_block(b, h, side, f"out.{i}", skip=sk)
-        g = self._groupnorm(h[1], None, Bn, side * side, "out.0", 1e-5, True, "fin.gn")
+            h, side = run_block(b, h, side, f"out.{i}", skip=sk, nxt_block=ob[i + 1] if i + 1 < len(ob) else None)
+        g = self._groupnorm(h[0] if self.precise else h[1], None, Bn, side * side, "out.0", 1e-5, True, "fin.gn")
         ops.conv3x3(g, W["out.2.w"], eps_out, Bn, side, side, W["out.2.b"], nchw_hw=side * side)
 
     # ------------------------------------------------------------------ public forward
@@ -359,7 +389,7 @@ class PyRefEngine:
         if not self.use_graphs:
             self._launch_forward(x_static, t_buf, reps, fuser_on, sd_conv, eps_out)
             return eps_out
-        key = (Bn, side, c["R"], c["Lc"], c["mo"], fuser_on, sd_conv, reps, eps_out.data_ptr(), tuple(x_lat.shape))
+        key = (Bn, side, c["R"], c["Lc"], c["mo"], fuser_on, sd_conv, reps, eps_out.data_ptr(), tuple(x_lat.shape), self.precise, self.h1_f32)
         g = self._graphs.get(key)
         if g is None:
             # warm-up run allocates every pooled buffer, then capture the same launch sequence

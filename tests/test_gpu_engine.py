@@ -260,3 +260,42 @@ def test_handle_option_overrides_are_per_engine():
         e2.set_option(99, 1)
     with pytest.raises(Exception):
         e2.set_option(1, 1)                     # not a knob
+
+
+def test_precision_modes_match_python_sequence_and_precise_is_closer_to_the_oracle():
+    """gl_set_option 41 / 42: the default mode (split-fp16 activations for the three kinds of 1x1 conv, GroupNorm on
+    the fp32 stream, fp32 first-conv output inside a ResBlock), the mode with fp16 h1, and round 3's fp16-copy mode are each
+    BITWISE equal to the Python launch sequence in the same mode; against the fp32 oracle the default mode is the closest."""
+    from oracle import unet_ref
+    cfg = UNetConfig(image_size=16, model_channels=128, num_heads=8, channel_mult=(1, 2), attention_resolutions=(1, 2), num_res_blocks=1,
+                     context_dim=128, pos_in_dim=64, pos_out_dim=128)
+    dev = torch.device(DEV)
+    sd = recipe.state_dict(cfg, 3)
+    P = pack_state_dict(sd, cfg, dev, recipe.sd_first_conv(cfg, 3))
+    eng, ref = UNetEngine(P), PyRefEngine(P)
+    B, hw = 2, 16
+    inp = {k: T(v) for k, v in recipe.synth_inputs(cfg, B, hw, n_boxes=5, n_rel=3, seed=8).items()}
+    x = inp["x"].to(DEV)
+    for e in (eng, ref):
+        e.set_conditioning(inp["context"], inp["relations"], inp["boxes"], inp["masks"], inp["positive_embeddings"], hw)
+    osd = {k: (T(np.asarray(v)).float().half().float() if np.asarray(v).ndim >= 2 else T(np.asarray(v)).float()) for k, v in sd.items()}
+    with torch.no_grad():
+        want = unet_ref.unet_forward(osd, cfg, inp["x"].half().float(), torch.full((B,), 481), inp["context"].half().float(),
+                                     inp["relations"].half().float(), inp["boxes"], inp["masks"], inp["positive_embeddings"])
+    errs = {}
+    try:
+        for name, k41, k42 in (("precise", 1, 1), ("precise_h1_fp16", 1, 0), ("fp16_copies", 0, 0)):
+            ops.set_option(41, k41)
+            ops.set_option(42, k42)
+            ref.precise, ref.h1_f32 = bool(k41), bool(k42)
+            a = eng.forward(x, 481.0, 1.0, False, 1).clone()
+            b = ref.forward(x, 481.0, 1.0, False, 1).clone()
+            assert same(a, b), (name, float((a - b).abs().max()))
+            assert same(eng.forward(x, 481.0, 0.0, True, 1).clone(), ref.forward(x, 481.0, 0.0, True, 1).clone()), name
+            errs[name] = float((a.cpu() - want).norm() / want.norm())
+    finally:
+        ops.set_option(41, 1)
+        ops.set_option(42, 1)
+    print("[precision modes] rel-L2 vs fp32 oracle (fp16-rounded weights):", {k: f"{v:.3e}" for k, v in errs.items()})
+    assert errs["precise"] < errs["precise_h1_fp16"] < errs["fp16_copies"], errs
+    assert errs["precise"] < 0.75 * errs["fp16_copies"], errs

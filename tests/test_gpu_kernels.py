@@ -137,6 +137,15 @@ def test_ff_fused(M, C, mode):
     d = float((out[:M].float() - out2.float()).norm() / out2.float().norm())
     print(f"[ff_fused {M}x{C} {mode}] rel-L2 vs two-launch form = {d:.2e}")
     assert d < (4e-4 if odt == torch.float16 else 2e-5), d
+    if mode == "res32_f16":
+        # GL_OUT_F16_HILO: [hi | lo] rows for a split-fp16 consumer (proj_out); hi = the fp16 output above, hi + lo = the fp32 output
+        hl = torch.full((M + 1, 2 * C), 7.0, dtype=torch.float16, device=DEV)
+        ops.ff_fused(xd, w1d, b1d, w2d, b2.to(DEV), rd, hl[:M], gate=gate, hilo_out=True)
+        f32o = torch.empty(M, C, dtype=torch.float32, device=DEV)
+        ops.ff_fused(xd, w1d, b1d, w2d, b2.to(DEV), rd, f32o, gate=gate)
+        v = f32o.cpu()
+        assert torch.equal(hl[:M, :C], out[:M]) and torch.equal(hl[:M, C:].cpu().float(), (v - v.half().float()).half().float())
+        assert float((hl[M:].float() - 7.0).abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(240, 320, 320, "bias"), (240, 320, 320, "gate"), (240, 1280, 1280, "gate"), (240, 640, 2560, "gate"),
@@ -644,6 +653,90 @@ def test_groupnorm_single_launch_form_matches_two_launch_form(C1, C2, HW):
     d = (a.float() - b.float()).abs()
     assert float(d.max()) <= 4e-3 and float((d > 0).float().mean()) < 0.03, (float(d.max()), float((d > 0).float().mean()))
     assert float((a[B * HW:].float() - 7.0).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("C1,C2,HW,silu", [(320, 0, 4096, True), (640, 320, 1024, True), (320, 0, 1024, False), (640, 0, 256, True), (1280, 640, 256, True),
+                                          (1280, 1280, 64, True), (1280, 0, 256, False), (960, 0, 1024, True), (640, 0, 1024, False), (64, 0, 100, True)])
+def test_groupnorm_fp32_stream_hilo_and_raw_split(C1, C2, HW, silu):
+    """gl_groupnorm_ex on fp32 inputs (the residual stream), every launch form (statistics + apply, small-map, group bundles):
+    hi = the fp16 normalised rows, hi + lo = the same rows to ~2^-22 (the split-fp16 operand of proj_in), and raw = the INPUT
+    concat as [hi | lo] (the operand of a ResBlock's 1x1 skip_connection), written into column views of wider buffers."""
+    B = 2
+    C = C1 + C2
+    x1 = rnd(f"gx1{C1}{HW}", (B * HW, C1)) * 1.5 + 0.3
+    x2 = rnd(f"gx2{C2}{HW}", (B * HW, C2)) * 0.7 - 0.2 if C2 else None
+    gam = 1 + 0.1 * rnd(f"gxg{C}", (C,))
+    bet = 0.1 * rnd(f"gxb{C}", (C,))
+    out = torch.full((B * HW + 1, 2 * C), 7.0, dtype=torch.float16, device=DEV)
+    raw = torch.full((B * HW + 1, 2 * C + 8), 7.0, dtype=torch.float16, device=DEV)
+    partial = torch.empty(B * 64 * 64, dtype=torch.float32, device=DEV)
+    ops.groupnorm(x1.to(DEV), x2.to(DEV) if C2 else None, B, HW, gam.to(DEV), bet.to(DEV), 1e-5, silu, out[:B * HW, :C], partial,
+                  out_lo=out[:B * HW, C:], raw=raw[:B * HW])
+    x = x1 if x2 is None else torch.cat([x1, x2], 1)
+    ref = F.group_norm(x.double().view(B, HW, C).permute(0, 2, 1), 32, gam.double(), bet.double(), 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 1).reshape(B * HW, C).float()
+    o = out.cpu().float()
+    check(o[:B * HW, :C], ref, f"groupnorm_f32_hi_{C1}+{C2}_{HW}")
+    # hi + lo: only the fp32 arithmetic of the kernel is left (rstd, exp of the SiLU): 1e-5 relative
+    check(o[:B * HW, :C] + o[:B * HW, C:], ref, f"groupnorm_f32_hilo_{C1}+{C2}_{HW}", rtol=2e-5, atol=2e-6)
+    r = raw.cpu().float()
+    assert torch.equal(r[:B * HW, :C], x.half().float())                                       # raw hi = fp16(x), bitwise
+    assert torch.equal(r[:B * HW, C:2 * C], (x - x.half().float()).half().float())             # raw lo = fp16(x - hi), bitwise
+    assert float((o[B * HW:] - 7.0).abs().max()) == 0.0 and float((r[B * HW:] - 7.0).abs().max()) == 0.0 and float((r[:, 2 * C:] - 7.0).abs().max()) == 0.0
+
+
+def test_groupnorm_fp32_launch_forms():
+    """fp32 inputs take the same launch form as fp16 ones on every UNet shape (the 80 KB-per-block cap of the bundle form binds
+    before the register budget of its fp32 instantiations, <= 8 vectors per thread, does); the query tells the engine"""
+    from layoutllm_t2i_amd import _lib
+    l = _lib.lib()
+    for C, HW in ((1280, 256), (2560, 64), (320, 1024), (640, 256), (640, 1024), (1920, 256), (320, 4096), (960, 1024), (1280, 4096)):
+        assert l.gl_groupnorm_launches_ex(C, HW, 1) == l.gl_groupnorm_launches_ex(C, HW, 0) == l.gl_groupnorm_launches(C, HW), (C, HW)
+    assert l.gl_groupnorm_launches_ex(640, 1024, 1) == 1 and l.gl_groupnorm_launches_ex(320, 4096, 1) == 2
+
+
+@pytest.mark.parametrize("M,N,K,res", [(4096, 320, 320, False), (700, 640, 1280, True), (512, 1280, 1280, True), (8192, 640, 640, True),
+                                       (32768, 320, 320, True), (2048, 1280, 2560, False), (240, 320, 640, False)])
+def test_gemm_split_fp16_activation(M, N, K, res):
+    """hilo_a: A = [hi | lo] of an fp32 activation against ONE copy of W (gl_gemm_args.kwrap) -- 4-wave, 8-wave, split-K and
+    skinny dispatch.  Against the fp32 product of the UNROUNDED activation the error drops from the fp16-operand level
+    (~3e-4 relative) to fp32-accumulation level; the plain fp16 product of the same rows is measured beside it."""
+    x = rnd(f"sa{M}{K}", (M, K)) * 1.7 + 0.4
+    w, wd = h16(rnd(f"sw{N}{K}", (N, K), 1 / math.sqrt(K)))
+    b = rnd(f"sb{N}", (N,), 0.1)
+    hi = x.half()
+    lo = (x - hi.float()).half()
+    a = torch.cat([hi, lo], 1).to(DEV)
+    r = rnd(f"sr{M}{N}", (M, N)) if res else None
+    out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm(a, wd, out, b.to(DEV), EPI_RES if res else EPI_BIAS, res=r.to(DEV) if res else None, hilo_a=True)
+    ref = F.linear(x.double(), w.double(), b.double()).float() + (r if res else 0)
+    e_split = float((out.cpu() - ref).norm() / ref.norm())
+    plain = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm(hi.to(DEV), wd, plain, b.to(DEV), EPI_RES if res else EPI_BIAS, res=r.to(DEV) if res else None)
+    e_plain = float((plain.cpu() - ref).norm() / ref.norm())
+    print(f"[gemm_hilo_{M}x{N}x{K}] rel_l2 split={e_split:.2e} plain fp16={e_plain:.2e}")
+    assert e_split < 2e-6 and e_plain > 20 * e_split, (e_split, e_plain)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 320, 1280), (4096, 640, 2560), (512, 1280, 5120)])
+def test_gemm_hilo_output(M, N, K):
+    """GL_OUT_F16_HILO: the epilogue writes hi = fp16(v) and lo = fp16(v - hi) N columns apart (bias + fp32 residual epilogue)."""
+    a, ad = h16(rnd(f"ha{M}", (M, K)))
+    w, wd = h16(rnd(f"hw{N}", (N, K), 1 / math.sqrt(K)))
+    b = rnd(f"hb{N}", (N,), 0.1)
+    r = rnd(f"hr{M}{N}", (M, N))
+    out = torch.full((M + 1, 2 * N), 7.0, dtype=torch.float16, device=DEV)
+    ops.gemm(ad, wd, out[:M], b.to(DEV), EPI_RES, res=r.to(DEV), hilo_out=True)
+    f32 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm(ad, wd, f32, b.to(DEV), EPI_RES, res=r.to(DEV))
+    v = f32.cpu()
+    o = out.cpu().float()
+    assert torch.equal(o[:M, :N], v.half().float()) and torch.equal(o[:M, N:], (v - v.half().float()).half().float())
+    assert float((o[M:] - 7.0).abs().max()) == 0.0
+    check(o[:M, :N] + o[:M, N:], F.linear(a, w, b) + r, f"gemm_hilo_out_{M}x{N}x{K}", rtol=2e-5, atol=2e-6)
 
 
 @pytest.mark.parametrize("C1,C2,HW", [(320, 0, 4096), (640, 320, 1024), (1280, 0, 144), (1280, 0, 256), (2560, 0, 64)])
