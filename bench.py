@@ -422,11 +422,27 @@ def main():
         eng.set_conditioning(cat(inp["context"], inp["uc"]), cat(inp["relations"], inp["relations"]), cat(inp["boxes"], zz(inp["boxes"])),
                              cat(inp["masks"], zz(inp["masks"])), cat(inp["positive_embeddings"], zz(inp["positive_embeddings"])), side)
         rl2 = lambda a, b: float((a.float().cpu() - b).norm() / b.norm())
+        # fraction of elements outside north_star's elementwise tolerance rtol 1e-3 / atol 1e-4
+        outside = lambda a, b: float(((a.float().cpu() - b).abs() > 1e-4 + 1e-3 * b.abs()).float().mean())
         e_on = eng.forward(inp["x"], 481.0, 1.0, False, 2).clone()
         e_off = eng.forward(inp["x"], 481.0, 0.0, False, 2).clone()
+        # one more oracle forward on fp16-ROUNDED weight matrices (what the engine stores): isolates the arithmetic error from the
+        # weight quantisation, the quantity tests/test_gpu_configs.py bounds
+        sd_r = {k: (v.half().float() if v.dim() >= 2 else v) for k, v in sd_cpu_sample.items()}
+        with torch.no_grad():
+            ref_r = unet_ref.unet_forward(sd_r, cfg, ci["x"], torch.tensor([481]), ci["context"], ci["relations"], ci["boxes"], ci["masks"],
+                                          ci["positive_embeddings"], fuser_scale=1.0)
+        del sd_r
         result["parity_at_bench_batch"] = {"rel_l2_cond_on": rl2(e_on[0:1], refs["cond_on"]), "rel_l2_uncond_on": rl2(e_on[B:B + 1], refs["uncond_on"]),
                                            "rel_l2_cond_off": rl2(e_off[0:1], refs["cond_off"]), "rel_l2_uncond_off": rl2(e_off[B:B + 1], refs["uncond_off"]),
-                                           "note": "HIP engine sample 0 / B of the 2B batch vs the fp32 oracle (fp32 weights), t=481"}
+                                           "outside_rtol1e-3_atol1e-4": {"cond_on": round(outside(e_on[0:1], refs["cond_on"]), 4),
+                                                                         "uncond_on": round(outside(e_on[B:B + 1], refs["uncond_on"]), 4),
+                                                                         "cond_off": round(outside(e_off[0:1], refs["cond_off"]), 4),
+                                                                         "uncond_off": round(outside(e_off[B:B + 1], refs["uncond_off"]), 4)},
+                                           "vs_fp16_rounded_weights_cond_on": {"rel_l2": rl2(e_on[0:1], ref_r),
+                                                                               "outside_rtol1e-3_atol1e-4": round(outside(e_on[0:1], ref_r), 4)},
+                                           "note": "HIP engine sample 0 / B of the 2B batch vs the fp32 oracle, t=481: on UNROUNDED fp32 weights (includes the "
+                                                   "fp16 rounding of the stored weights) and, for cond_on, on fp16-rounded weight matrices (arithmetic only)"}
         with torch.no_grad():
             pass
         S = args.plms_steps

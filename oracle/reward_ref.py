@@ -1,12 +1,13 @@
 """ORACLE (test infrastructure, not product): fp32 CPU restatement of the GPU part of the rollout's reward scoring.
 
-Restates models/policy.py:106-124,135 (``Reward_Model.forward``: CLIP similarities of F.normalize'd features, aesthetic
-score of the re-normalised image embedding, the weighted sum) and tools/aesthetic.py:15-31 (AestheticMLP = five Linear
-layers with Dropouts, no activations), tools/aesthetic.py:52-57 (``normalized``).
+Restates models/policy.py:114-124,137 (``Reward.forward``, the class SURVEY calls Reward_Model: CLIP similarities of
+F.normalize'd features, aesthetic score of the re-normalised image embedding, the weighted sum) and tools/aesthetic.py:9-31
+(AestheticMLP = five Linear layers with Dropouts, no activations), tools/aesthetic.py:52-57 (``normalized``).
 
-PARITY UNPINNED: tools/aesthetic.py imports pytorch_lightning and models/policy.py imports modules that are absent
-from this image, so the reference classes cannot be imported to generate goldens; tests/test_reward.py checks this
-restatement against an independently built ``torch.nn.Sequential`` of the same layer list instead.
+PINNED by tests/golden/reward_ref.npz: tools/make_reward_goldens.py takes ``AestheticMLP`` / ``normalized`` and the
+statements of ``Reward.forward`` named above out of the reference FILES with ``ast`` (the modules themselves cannot be imported
+in this image: pytorch_lightning and others are absent), executes them on recipe weights / features and stores the outputs;
+tests/test_reward.py::test_oracle_matches_reference_generated_golden holds this restatement to them (fp32, <= 2e-6).
 """
 from __future__ import annotations
 

@@ -3,8 +3,9 @@ batch): the 2B = 8 batch of configs[1], the 2B = 32 batch of configs[4], configs
 16 boxes.  Samples of a batch are independent (GroupNorm is per sample, LayerNorm per token), so the oracle is
 evaluated for ONE sample of each batch on the host CPU and compared with the engine's row for that sample.
 
-Bounds are <= 1.5x the values measured on MI355X (printed by ``report``); the arithmetic floor of ANY implementation
-that feeds fp16 operands to the matrix cores is rel-L2 ~1.1e-3 on this network (tools/precision_sim.py).
+Bounds are <= 1.1x the values measured on MI355X (printed by ``report``).  north_star's elementwise rtol 1e-3 / atol 1e-4 is NOT
+met by every element: 27-30 % lie outside it (rel-L2 6.7e-4 .. 7.5e-4).  With fp16 operands for the 3x3 convs and the FF / attention
+projections the floor is rel-L2 6.5e-4 / 26 % outside (tools/precision_sim.py); the engine sits at it.
 """
 import os
 import sys
@@ -33,9 +34,8 @@ def rel_l2(a, b):
 
 
 def report(name, out, ref, frac_bound=None):
-    """rel-L2, and the fraction of elements outside north_star's elementwise rtol 1e-3 / atol 1e-4 -- which is NOT met with
-    fp16 matrix operands (floor: 43 % outside at rel-L2 1.1e-3, tools/precision_sim.py); ``frac_bound`` asserts that the
-    engine stays at that floor (<= 1.1x the measured fraction) instead of only printing it."""
+    """rel-L2, and the fraction of elements outside north_star's elementwise rtol 1e-3 / atol 1e-4; ``frac_bound`` asserts that
+    fraction (<= 1.1x the measured one) instead of only printing it."""
     out, ref = out.float().cpu(), ref.float().cpu()
     r = rel_l2(out, ref)
     d = (out - ref).abs()
@@ -100,8 +100,10 @@ def oracle_one(sd, cfg, inp, k, cond, tval, fuser_scale=1.0, first_conv=None):
 
 
 # measured on MI355X (round 2): see DESIGN.md section 4; asserts are <= 1.5x these
-BOUND_FULL = 1.8e-3          # measured 1.11e-3 .. 1.21e-3 over all (batch, mode) cases and both 768px rows
-FRAC_FULL = 0.52             # elements outside rtol 1e-3 / atol 1e-4: measured 42 .. 47 % (fp16-operand floor 43 %); bound = 1.1x
+# measured on MI355X (round 4: split-fp16 1x1 convs + GroupNorm on the fp32 stream): rel-L2 6.66e-4 .. 7.49e-4, 26.8 .. 30.0 % outside over
+# all (batch, mode) cases and both 768px rows; round 3 (fp16 copies): 1.11e-3 .. 1.23e-3, 44 .. 48 %.  Bounds = 1.1x the worst case.
+BOUND_FULL = 8.3e-4
+FRAC_FULL = 0.33             # elements outside north_star's rtol 1e-3 / atol 1e-4
 
 
 @pytest.mark.parametrize("B", [4, 8, 16], ids=["configs1_2B8", "configs3_2B16", "configs4_2B32"])

@@ -1,9 +1,11 @@
 """Per-kernel parity on a real MI355X, through the C ABI (layoutllm_t2i_amd.ops -> libgligen_hip.so).
 
 Reference = the same op in torch fp32 on the CPU, evaluated on the SAME fp16-rounded inputs/weights
-(isolates kernel error from quantisation of the inputs).  Tolerance is north_star's
-rtol=1e-3 / atol=1e-4 scaled by the output magnitude (fp16 output rounding is 4.9e-4 relative),
-except where a comment says otherwise.  Sampler arithmetic is checked bit-exactly.
+(isolates kernel error from quantisation of the inputs).  Tolerance: rtol 1e-3 and an atol that is
+MAGNITUDE-SCALED, 1e-4 x max(1, max|ref|) -- this is looser than north_star's rtol 1e-3 / atol 1e-4 wherever
+the outputs exceed 1 (an fp16 output alone rounds by 4.9e-4 relative); attention uses 2e-3 / 2e-4 (P is rounded
+to fp16 before P.V).  north_star's unscaled tolerance is applied to the WHOLE UNet in tests/test_gpu_configs.py
+(fraction of elements outside it asserted).  Sampler arithmetic is checked bit-exactly.
 """
 import math
 import os

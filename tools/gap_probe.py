@@ -13,6 +13,10 @@ from layoutllm_t2i_amd.engine import UNetEngine
 from layoutllm_t2i_amd.weights import pack_state_dict, random_state_dict
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+from layoutllm_t2i_amd import ops
+for kv in sys.argv[2:]:                      # gl_set_option overrides for an A/B timeline: key=value ...
+    k, v = kv.split("=")
+    ops.set_option(int(k), int(v))
 dev = torch.device("cuda:0")
 cfg = UNetConfig()
 P = pack_state_dict(random_state_dict(cfg, dev, seed=0), cfg, dev, recipe.sd_first_conv(cfg, 0))
