@@ -202,7 +202,9 @@ int gl_groupnorm_launches_ex(int32_t C, int32_t HW, int32_t x_f32);
 
 /*
  * gl_layernorm: row LayerNorm eps 1e-5 over C (attention.py:216-217,292-294,369-371), fp32 statistics (two-pass).
- * Input row r = (b, i) with i < rows_in, fp32 when x_f32 != 0 (the residual stream) else fp16; output fp16, row index
+ * x_f32 is a bit set: bit 0 = the input rows are fp32 (the residual stream) instead of fp16; bit 1 = the OUTPUT rows are fp32
+ * instead of fp16 (y, ldy then count floats: the conditioning text encoder's last_hidden_state, encoders/modules.py:167).
+ * Input row r = (b, i) with i < rows_in; output row index
  * = b * rows_out + row_off + i -- this writes straight into the [x ; objs] concatenation of GatedSelfAttentionDense
  * (attention.py:230).  stats (optional): (mean, rstd) per input row, fp32 [B * rows_in, 2].  C % 8 == 0, C <= 2048.
  * x2 (optional, fp16, rows2 rows per sample, row stride ldx2): a second source whose rows follow the rows_in rows of x in

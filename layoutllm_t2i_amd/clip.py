@@ -66,24 +66,26 @@ class ClipTowers:
         self.device, self.eps = torch.device(device), eps
         sd = state_dict
         f = lambda k: torch.as_tensor(sd[k]).detach().to(self.device, F32).contiguous()
-        self.vis = _Tower(sd, "vision_model", vision_heads, self.device)
+        # a CLIPTextModel state dict (the conditioning encoder, text_encoder.py) has no vision tower and no projections
+        self.vis = _Tower(sd, "vision_model", vision_heads, self.device) if "vision_model.embeddings.patch_embedding.weight" in sd else None
         self.txt = _Tower(sd, "text_model", text_heads, self.device)
-        pw = f("vision_model.embeddings.patch_embedding.weight")                       # [C, 3, P, P]
-        self.patch = pw.shape[-1]
-        K = 3 * self.patch * self.patch
-        self.Kpad = (K + 63) // 64 * 64
-        w = torch.zeros(pw.shape[0], self.Kpad, device=self.device, dtype=F32)
-        w[:, :K] = pw.reshape(pw.shape[0], K)
-        self.patch_w = w.to(F16).contiguous()
-        self.cls = f("vision_model.embeddings.class_embedding")
-        self.vpos = f("vision_model.embeddings.position_embedding.weight")
-        self.pre_ln = (f("vision_model.pre_layrnorm.weight"), f("vision_model.pre_layrnorm.bias"))
-        self.post_ln = (f("vision_model.post_layernorm.weight"), f("vision_model.post_layernorm.bias"))
-        self.vproj = f("visual_projection.weight").to(F16).contiguous()
+        if self.vis is not None:
+            pw = f("vision_model.embeddings.patch_embedding.weight")                       # [C, 3, P, P]
+            self.patch = pw.shape[-1]
+            K = 3 * self.patch * self.patch
+            self.Kpad = (K + 63) // 64 * 64
+            w = torch.zeros(pw.shape[0], self.Kpad, device=self.device, dtype=F32)
+            w[:, :K] = pw.reshape(pw.shape[0], K)
+            self.patch_w = w.to(F16).contiguous()
+            self.cls = f("vision_model.embeddings.class_embedding")
+            self.vpos = f("vision_model.embeddings.position_embedding.weight")
+            self.pre_ln = (f("vision_model.pre_layrnorm.weight"), f("vision_model.pre_layrnorm.bias"))
+            self.post_ln = (f("vision_model.post_layernorm.weight"), f("vision_model.post_layernorm.bias"))
+            self.vproj = f("visual_projection.weight").to(F16).contiguous()
         self.tok = f("text_model.embeddings.token_embedding.weight")
         self.tpos = f("text_model.embeddings.position_embedding.weight")
         self.final_ln = (f("text_model.final_layer_norm.weight"), f("text_model.final_layer_norm.bias"))
-        self.tproj = f("text_projection.weight").to(F16).contiguous()
+        self.tproj = f("text_projection.weight").to(F16).contiguous() if "text_projection.weight" in sd else None
         self._pool: Dict[tuple, torch.Tensor] = {}
         # one captured launch sequence per (tower, batch, length): the towers are ~200 (vision) / ~100 (text) small launches whose
         # host-side issue through ctypes costs more than their GPU time at rollout batch sizes
@@ -165,6 +167,8 @@ class ClipTowers:
 
     @torch.no_grad()
     def get_image_features(self, pixel_values: torch.Tensor) -> torch.Tensor:
+        if self.vis is None:
+            raise RuntimeError("this ClipTowers was built from a text-only state dict (no vision_model.* tensors)")
         px = torch.as_tensor(pixel_values).to(self.device, F32).contiguous()
         B, _, S, S2 = px.shape
         nps = S // self.patch
@@ -182,8 +186,37 @@ class ClipTowers:
         rows = (torch.arange(B, device=self.device) * T + ids32.argmax(dim=-1)).to(torch.int32).contiguous()
         return self._pool_project(x, rows, self.final_ln, self.tproj, "t")
 
+    def _text_hidden(self, ids32: torch.Tensor) -> torch.Tensor:
+        """``CLIPTextModel.forward``: final_layer_norm of EVERY row, fp32 [B * T + B, C]: the B * T rows of last_hidden_state followed
+        by the B pooled rows (the row at ids.argmax(-1): the first eos of a row padded with the eos id)."""
+        B, T = ids32.shape
+        C = self.txt.C
+        x = ops.clip_embed_tokens(ids32, self.tok, self.tpos, self.buf("t.x", (B * T, C), F32))
+        x = self._encode(self.txt, x, B, T, True, "t")
+        out = self.buf("t.lhs", (B * T + B, C), F32)
+        ops.layernorm(x, out[:B * T], self.final_ln[0], self.final_ln[1], B, T, eps=self.eps)
+        rows = (torch.arange(B, device=self.device) * T + ids32.argmax(dim=-1)).to(torch.int32).contiguous()
+        ops.clip_gather_rows(out[:B * T], rows, out[B * T:])
+        return out
+
+    @torch.no_grad()
+    def text_hidden_states(self, input_ids: torch.Tensor):
+        """(last_hidden_state fp32 [B, T, C], pooler_output fp32 [B, C]) of ``transformers.CLIPTextModel`` for token rows
+        [B, T] (FrozenCLIPEmbedder.forward, GLIGEN/ldm/modules/encoders/modules.py:163-170; the text branch of get_clip_feature,
+        GLIGEN/interface.py:132-139)."""
+        ids = torch.as_tensor(input_ids).to(self.device)
+        B, T = ids.shape
+        if T > self.tpos.shape[0] or T > 128:
+            raise ValueError(f"sequence length {T} exceeds the position table ({self.tpos.shape[0]}) / the short-attention kernel (128)")
+        with torch.cuda.device(self.device):
+            ids32 = ids.to(torch.int32).contiguous()
+            out = self._replay(("h", B, T), ids32, self._text_hidden) if self.use_graphs else self._text_hidden(ids32).clone()
+        return out[:B * T].view(B, T, -1), out[B * T:]
+
     @torch.no_grad()
     def get_text_features(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if self.tproj is None:
+            raise RuntimeError("this ClipTowers was built from a CLIPTextModel state dict (no text_projection): use text_hidden_states")
         ids = torch.as_tensor(input_ids).to(self.device)
         B, T = ids.shape
         if T > self.tpos.shape[0] or T > 128:

@@ -497,7 +497,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
                                                         int ldy, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int nrows, int rows_in,
                                                         int rows_out, int row_off, int C, float eps,
-                                                        float* __restrict__ stats, const half_t* __restrict__ x2, int ldx2, int rows2) {
+                                                        float* __restrict__ stats, const half_t* __restrict__ x2, int ldx2, int rows2,
+                                                        int y_f32) {
     const int lane = threadIdx.x & 63;
     const int orow = blockIdx.x * 4 + (threadIdx.x >> 6);        // index over B * (rows_in + rows2)
     if (orow >= nrows) return;
@@ -566,6 +567,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
             const float4 b1 = *reinterpret_cast<const float4*>(beta + vec * 8 + 4);
             const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
             const float bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            if (y_f32) {          // wave-uniform: fp32 rows (an encoder's last_hidden_state leaves the library unrounded)
+                float* yf = reinterpret_cast<float*>(y) + ((size_t)bidx * rows_out + row_off + i_in) * ldy + vec * 8;
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = fmaf((v[i][j] - mean) * rstd, g[j], bt[j]);
+                *reinterpret_cast<float4*>(yf) = make_float4(o[0], o[1], o[2], o[3]);
+                *reinterpret_cast<float4*>(yf + 4) = make_float4(o[4], o[5], o[6], o[7]);
+                continue;
+            }
             half8_t ov;
 #pragma unroll
             for (int j = 0; j < 8; ++j) ov[j] = (half_t)fmaf((v[i][j] - mean) * rstd, g[j], bt[j]);   // explicit: rela_merge_ln_kernel rounds identically
@@ -741,7 +751,9 @@ extern "C" int gl_layernorm(const void* x, int32_t ldx, int32_t x_f32, void* y, 
     hipStream_t st = (hipStream_t)stream;
     const int nv = gl_cdiv(C / 8, 64);
     const dim3 grid(gl_cdiv(nrows, 4)), blk(256);
-#define GL_LN(F, V) layernorm_kernel<F, V><<<grid, blk, 0, st>>>(x, ldx, yp, ldy, gamma, beta, nrows, rows_in, rows_out, row_off, C, eps, stats, x2p, ldx2, rows2)
+    const int y_f32 = (x_f32 >> 1) & 1;
+    x_f32 &= 1;
+#define GL_LN(F, V) layernorm_kernel<F, V><<<grid, blk, 0, st>>>(x, ldx, yp, ldy, gamma, beta, nrows, rows_in, rows_out, row_off, C, eps, stats, x2p, ldx2, rows2, y_f32)
     if (x_f32) {
         if (nv == 1) GL_LN(true, 1); else if (nv == 2) GL_LN(true, 2); else if (nv == 3) GL_LN(true, 3); else GL_LN(true, 4);
     } else {

@@ -87,22 +87,34 @@ def unflatten_tensors(flat: torch.Tensor, manifest: list) -> Dict[str, torch.Ten
 
 
 def broadcast_bundle(P: Optional[PackedWeights], vae_w: Optional[Dict[str, torch.Tensor]], cfg: Optional[UNetConfig], device,
-                     src: int = 0, extra: Optional[dict] = None):
+                     src: int = 0, extra: Optional[dict] = None, aux: Optional[Dict[str, Dict[str, torch.Tensor]]] = None,
+                     want_aux: bool = False):
     """The job's ONE data-path collective: the packed UNet buffer (2.5 GB, the C engine's weight-table layout)
     AND the packed VAE-decoder tensors (0.1 GB) travel in a single ``broadcast`` of one flat byte buffer; the few host-side
     facts (offsets, configs, ``extra``) go ahead of it as a pickled object.  Rank ``src`` passes its objects, the others
-    pass None.  Returns (PackedWeights, vae tensor dict or None, extra) on every rank; tensors are views of the buffer."""
+    pass None.  ``aux``: further named tensor dicts (the HIP text tower's weights) appended to the same buffer.
+    Returns (PackedWeights, vae tensor dict or None, extra) on every rank -- plus the aux dicts when ``want_aux``; tensors are
+    views of the buffer."""
     rank = dist.get_rank()
     if rank == src:
         uflat, uman = flatten_packed(P)
         vflat, vman = (flatten_tensors(vae_w, uflat.device) if vae_w is not None else (None, None))
         usz = int(uflat.numel())
-        total = usz + (int(vflat.numel()) if vflat is not None else 0)
-        head = dict(unet=uman, unet_bytes=usz, vae=vman, total=total, cfg=cfg, extra=extra)
-        if vflat is not None:
+        parts = [uflat] + ([vflat] if vflat is not None else [])
+        aman = {}
+        for name in sorted(aux or {}):
+            af, am = flatten_tensors(aux[name], uflat.device)
+            aman[name] = (sum(int(p_.numel()) for p_ in parts), int(af.numel()), am)
+            parts.append(af)
+        total = sum(int(p_.numel()) for p_ in parts)
+        head = dict(unet=uman, unet_bytes=usz, vae=vman, vae_bytes=int(vflat.numel()) if vflat is not None else 0, total=total, cfg=cfg,
+                    extra=extra, aux=aman)
+        if len(parts) > 1:
             flat = torch.empty(total, dtype=torch.uint8, device=uflat.device)
-            flat[:usz].copy_(uflat)
-            flat[usz:].copy_(vflat)
+            o = 0
+            for p_ in parts:
+                flat[o:o + p_.numel()].copy_(p_)
+                o += int(p_.numel())
         else:
             flat = uflat
         box = [head]
@@ -117,11 +129,13 @@ def broadcast_bundle(P: Optional[PackedWeights], vae_w: Optional[Dict[str, torch
             flat = torch.empty(head["total"], dtype=torch.uint8, device=device)
         dist.broadcast(flat.view(torch.int64) if flat.numel() % 8 == 0 else flat, src=src)      # the one collective
     if rank == src:
-        return P, vae_w, extra                  # the sender keeps its own objects (the staging buffer is dropped)
+        return (P, vae_w, extra, aux) if want_aux else (P, vae_w, extra)      # the sender keeps its own objects (the staging buffer is dropped)
     usz = head["unet_bytes"]
     Pb = unflatten_packed(flat[:usz], head["unet"], head["cfg"], device)
-    vw = unflatten_tensors(flat[usz:], head["vae"]) if head["vae"] is not None else None
-    return Pb, vw, head["extra"]
+    vw = unflatten_tensors(flat[usz:usz + head["vae_bytes"]], head["vae"]) if head["vae"] is not None else None
+    if not want_aux:
+        return Pb, vw, head["extra"]
+    return Pb, vw, head["extra"], {name: unflatten_tensors(flat[o:o + nb], man) for name, (o, nb, man) in head["aux"].items()}
 
 
 def checksum(P: PackedWeights) -> int:

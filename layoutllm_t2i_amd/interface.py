@@ -63,6 +63,37 @@ def _instantiate_reference(config_node):
     return getattr(importlib.import_module(module), cls)(**config_node.get("params", dict()))
 
 
+def _load_text_encoder(node, state_dict, device):
+    """The conditioning encoder (interface.py:85-88).  A checkpoint whose ``text_encoder`` entry holds a CLIP text tower
+    (``FrozenCLIPEmbedder.state_dict()``: ``transformer.text_model.*``) runs on the HIP kernels (text_encoder.HipCLIPTextEncoder,
+    SURVEY 8f-2); its tokenizer is the config's ``params.tokenizer`` node when present, else HuggingFace's CLIPTokenizer of
+    ``params.version`` exactly as FrozenCLIPEmbedder loads it (encoders/modules.py:148).  Anything else -- or
+    GLIGEN_REFERENCE_TEXT_ENCODER=1 -- is instantiated from whatever ``ldm`` package is importable, like the reference does."""
+    from .text_encoder import HipCLIPTextEncoder
+    params = node.get("params", {}) or {}
+    if not os.environ.get("GLIGEN_REFERENCE_TEXT_ENCODER") and HipCLIPTextEncoder.accepts(state_dict):
+        if params.get("tokenizer") is not None:
+            tokenizer = _instantiate_reference(params["tokenizer"])
+        else:
+            from transformers import CLIPTokenizer
+            tokenizer = CLIPTokenizer.from_pretrained(params.get("version", "openai/clip-vit-large-patch14"))
+        return HipCLIPTextEncoder(state_dict, tokenizer, device, heads=params.get("num_attention_heads"), max_length=params.get("max_length", 77))
+    text_encoder = _instantiate_reference(node).to(device).eval()
+    text_encoder.load_state_dict(state_dict)
+    return text_encoder
+
+
+def hip_phrase_encoder(clip_model, device, heads=None):
+    """The ``clip_model`` argument of generate_batch_images / generate_one_image (a HuggingFace ``CLIPModel``, used only for the
+    grounding phrases' ``text_model_output.pooler_output``, interface.py:114-141) moved onto the HIP text tower: pass the result
+    as ``clip_model`` instead; ``clip_processor`` keeps tokenising.  ``heads`` defaults to hidden / 64."""
+    from .text_encoder import HipCLIPTextEncoder
+    sd = clip_model if isinstance(clip_model, dict) else clip_model.state_dict()
+    if heads is None and hasattr(clip_model, "config"):
+        heads = getattr(getattr(clip_model.config, "text_config", None), "num_attention_heads", None)
+    return HipCLIPTextEncoder(sd, None, device, heads=heads)
+
+
 def find_sd_first_conv(ckpt_path=None):
     """Locates ``SD_input_conv_weight_bias.pth``.  The reference reads it from the GLIGEN code directory on every
     scale-0 step (openaimodel.py:396-398) and fails hard when it is missing.  Search order: $GLIGEN_SD_FIRST_CONV,
@@ -123,8 +154,7 @@ def load_ckpt(ckpt_path, device="cuda"):
                          num_res_blocks=dd.get("num_res_blocks", 2), z_channels=dd.get("z_channels", 4),
                          out_ch=dd.get("out_ch", 3), embed_dim=ap.get("embed_dim", 4), scale_factor=ap.get("scale_factor", 0.18215))
         autoencoder = VAEDecoder(saved_ckpt["autoencoder"], vcfg, device)
-    text_encoder = _instantiate_reference(config["text_encoder"]).to(device).eval()
-    text_encoder.load_state_dict(saved_ckpt["text_encoder"])
+    text_encoder = _load_text_encoder(config["text_encoder"], saved_ckpt["text_encoder"], device)
     for m in (autoencoder, text_encoder):
         if not isinstance(m, VAEDecoder) and "device" in vars(m):
             m.device = device
@@ -184,6 +214,10 @@ def get_clip_features_batched(model, processor, phrases, device):
     if not uniq:
         return {}
     inputs = processor(text=uniq, return_tensors="pt", padding=True)
+    if hasattr(model, "pooler_output") and callable(model.pooler_output):
+        # the HIP text tower (hip_phrase_encoder / text_encoder.HipCLIPTextEncoder): token rows in, pooled rows out; no vision pass
+        pooled = model.pooler_output(inputs["input_ids"])
+        return {p: pooled[i:i + 1] for i, p in enumerate(uniq)}
     inputs["input_ids"] = inputs["input_ids"].to(device)
     inputs["pixel_values"] = torch.ones(1, 3, 224, 224).to(device)       # placeholder, as interface.py:136
     inputs["attention_mask"] = inputs["attention_mask"].to(device)
@@ -389,9 +423,10 @@ def _unet_facade(packed, cfg, device, allow_missing_sd_conv=False):
 
 def load_all_models_sharded(ckpt, device, src=0):
     """``load_all_models`` for a torch.distributed job: only rank ``src`` touches the checkpoint file; the others receive the
-    packed UNet (the C engine's flat weight buffer) and the packed VAE decoder in dist.broadcast_bundle's single collective,
-    plus the config dict.  On the receiving ranks ``text_encoder`` is None: conditioning is prepared on ``src`` and
-    scattered per call (generate_batch_images_sharded).  Returns the usual 5-tuple on every rank."""
+    packed UNet (the C engine's flat weight buffer), the packed VAE decoder and -- when the checkpoint's text encoder runs on the HIP
+    tower -- its weights in dist.broadcast_bundle's single collective, plus the config dict.  With a reference torch text encoder
+    the receiving ranks get ``text_encoder = None``: conditioning is then prepared on ``src`` and scattered per call
+    (generate_batch_images_sharded).  Returns the usual 5-tuple on every rank."""
     import torch.distributed as dist
     from .dist import broadcast_bundle
     if not (dist.is_available() and dist.is_initialized()):
@@ -403,16 +438,26 @@ def load_all_models_sharded(ckpt, device, src=0):
         if not isinstance(autoencoder, VAEDecoder):
             raise NotImplementedError("the sharded entry broadcasts the HIP VAE decoder's packed weights (unset GLIGEN_REFERENCE_VAE)")
         dcfg = dict(linear_start=diffusion.linear_start, linear_end=diffusion.linear_end, timesteps=diffusion.num_timesteps)
+        # the HIP text tower travels too (fp32 state dict, ~0.5 GB for ViT-L/14's text model, same single broadcast) together with its
+        # (picklable, host-side) tokenizer, so that every rank encodes its own prompts; a reference torch encoder stays on src
+        hip_te = _is_hip_encoder(text_encoder)
+        te_extra = dict(tokenizer=text_encoder.tokenizer, heads=text_encoder.heads, max_length=text_encoder.max_length) if hip_te else None
         broadcast_bundle(model.engine.P, autoencoder.W, model.cfg, device, src,
-                         extra=dict(config=config, vcfg=autoencoder.cfg, diffusion=dcfg,
-                                    allow_missing_sd_conv=bool(getattr(model, "allow_missing_sd_conv", False))))
+                         extra=dict(config=config, vcfg=autoencoder.cfg, diffusion=dcfg, text_encoder=te_extra,
+                                    allow_missing_sd_conv=bool(getattr(model, "allow_missing_sd_conv", False))),
+                         aux=dict(text_encoder=text_encoder.towers_state_dict()) if hip_te else None)
         return am
-    P, vw, extra = broadcast_bundle(None, None, None, device, src)
+    P, vw, extra, aux = broadcast_bundle(None, None, None, device, src, want_aux=True)
     model = _unet_facade(P, P.cfg, device, extra.get("allow_missing_sd_conv", False))     # src's GLIGEN_ALLOW_NO_SD_CONV applies to every rank
     autoencoder = VAEDecoder.from_packed(vw, extra["vcfg"], device)
     d = extra["diffusion"]
     diffusion = LatentDiffusion(linear_start=d["linear_start"], linear_end=d["linear_end"], timesteps=d["timesteps"], device=device)
-    return model, autoencoder, None, diffusion, extra["config"]
+    text_encoder = None
+    if extra.get("text_encoder") is not None:
+        from .text_encoder import HipCLIPTextEncoder
+        te = extra["text_encoder"]
+        text_encoder = HipCLIPTextEncoder(aux["text_encoder"], te["tokenizer"], device, heads=te["heads"], max_length=te["max_length"])
+    return model, autoencoder, text_encoder, diffusion, extra["config"]
 
 
 def _collective_device(device):
@@ -436,6 +481,73 @@ def prepare_conditioning(all_models, captions, labels, bboxes, clip_model, clip_
                 relations=prepare_relation_phrases_batch(captions, config.get("max_relations", 10), text_encoder, device=device),
                 boxes=batch["boxes"], masks=batch["masks"], text_embeddings=batch["text_embeddings"])
     return {k: v.detach().float().cpu().contiguous() for k, v in cond.items()}
+
+
+def _is_hip_encoder(m) -> bool:
+    from .text_encoder import HipCLIPTextEncoder
+    return isinstance(m, HipCLIPTextEncoder)
+
+
+def tokenize_conditioning(all_models, captions, labels, bboxes, clip_processor, max_objs=MAX_OBJS):
+    """Host-side half of the conditioning prep for the HIP encoders: every string of ``run_batch_images``'s prep
+    (interface.py:424-475, :486-496) becomes token rows -- no GPU work, a few KB per prompt, so rank ``src`` does it for the
+    whole call and the ranks encode their own rows (encode_conditioning).  Returns a dict of CPU tensors:
+    cap_ids [n, 77], uc_ids [1, 77], rel_ids [m, 77] + rel_owner / rel_slot [m] (prompt, slot) of each relation phrase,
+    phrase_ids [k, L] (the distinct grounding phrases, ``clip_processor`` padding) + phrase_index [n, max_objs] (-1 = none),
+    boxes [n, max_objs, 4], masks [n, max_objs]."""
+    model, autoencoder, text_encoder, diffusion, config = all_models
+    n = len(captions)
+    R = config.get("max_relations", 10)
+    rel_lists = [_relation_phrases(p_, R) for p_ in captions]
+    flat = [ph for l in rel_lists for ph in l]
+    T = text_encoder.max_length
+    phrases_batch = labels if labels is not None else [None] * n
+    phrases_batch = [[None] * len(loc) if ph is None else ph for ph, loc in zip(phrases_batch, bboxes)]
+    uniq = [p_ for p_ in dict.fromkeys(ph for phrases in phrases_batch for ph in phrases) if p_ is not None]
+    where = {p_: i for i, p_ in enumerate(uniq)}
+    boxes = torch.zeros(n, max_objs, 4)
+    masks = torch.zeros(n, max_objs)
+    pidx = torch.full((n, max_objs), -1, dtype=torch.long)
+    for i, (phrases, locs) in enumerate(zip(phrases_batch, bboxes)):
+        for j, (box, ph) in enumerate(zip(locs, phrases)):
+            boxes[i, j] = torch.tensor(box)
+            masks[i, j] = 1
+            if ph is not None:
+                pidx[i, j] = where[ph]
+    return dict(cap_ids=text_encoder.tokenize(captions), uc_ids=text_encoder.tokenize([""]),
+                rel_ids=text_encoder.tokenize(flat) if flat else torch.zeros(0, T, dtype=torch.long),
+                rel_owner=torch.tensor([i for i, l in enumerate(rel_lists) for _ in l], dtype=torch.long),
+                rel_slot=torch.tensor([j for l in rel_lists for j in range(len(l))], dtype=torch.long), max_relations=R,
+                phrase_ids=clip_processor(text=uniq, return_tensors="pt", padding=True)["input_ids"] if uniq else torch.zeros(0, 1, dtype=torch.long),
+                phrase_index=pidx, boxes=boxes, masks=masks)
+
+
+@torch.no_grad()
+def encode_conditioning(all_models, tok, rows, phrase_encoder, device):
+    """GPU half: the conditioning tensors of prompt rows ``rows`` from their token rows, on THIS rank's HIP text tower
+    (all_models' HipCLIPTextEncoder for prompts / empty prompt / relation phrases; ``phrase_encoder`` for the grounding phrases'
+    pooled features, interface.py:114-141).  Same dict as prepare_conditioning, on ``device``."""
+    te = all_models[2]
+    rows = [int(r_) for r_ in rows]
+    nr, R, D = len(rows), int(tok["max_relations"]), te.hidden
+    context = te.encode_ids(tok["cap_ids"][rows]) if nr else torch.zeros(0, te.max_length, D, device=device)
+    uc = te.encode_ids(tok["uc_ids"]).repeat(nr, 1, 1)
+    relations = torch.zeros(nr, R, D, device=device)
+    pos = {r_: i for i, r_ in enumerate(rows)}
+    sel = [k for k, o in enumerate(tok["rel_owner"].tolist()) if o in pos]
+    if sel:
+        pooled = te.encode_ids(tok["rel_ids"][sel], return_pooler_output=True)[1]
+        relations[[pos[int(tok["rel_owner"][k])] for k in sel], [int(tok["rel_slot"][k]) for k in sel]] = pooled
+    pidx = tok["phrase_index"][rows]
+    emb = torch.zeros(nr, pidx.shape[1], D, device=device)
+    used = sorted(set(int(v) for v in pidx.flatten().tolist() if v >= 0))
+    if used:
+        pooled = phrase_encoder.pooler_output(tok["phrase_ids"][used])
+        lut = {u: i for i, u in enumerate(used)}
+        ii, jj = (pidx >= 0).nonzero(as_tuple=True)
+        emb[ii.to(device), jj.to(device)] = pooled[[lut[int(pidx[a, b])] for a, b in zip(ii.tolist(), jj.tolist())]]
+    return dict(context=context, uc=uc, relations=relations, boxes=tok["boxes"][rows].to(device), masks=tok["masks"][rows].to(device),
+                text_embeddings=emb)
 
 
 def prompt_noise(seeds, latent=64):
@@ -480,20 +592,38 @@ def generate_batch_images_sharded(all_models, captions=None, labels=None, bboxes
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     rank, world = (dist.get_rank(), dist.get_world_size()) if multi else (0, 1)
     box = [None]
+    # With the HIP text tower in all_models on every rank (load_all_models_sharded ships its weights in the bundle) only the
+    # host-side STRING work happens on src: the token rows travel (a few KB per prompt) and every rank encodes its own shard --
+    # no rank-0 serial encoder stage.  Reference torch encoders (only present on src) keep the older flow: src encodes all rows.
+    hip_flow = _is_hip_encoder(all_models[2])
     if rank == src or not multi:
         n = len(captions)
         seeds = list(range(n)) if seeds is None else [int(s_) for s_ in seeds]
         assert len(seeds) == n
-        # prepare_conditioning returns HOST tensors: object collectives pickle tensors with their device, and rank r must not
-        # receive rank 0's "cuda:0" tensors
-        box = [dict(cond=prepare_conditioning(all_models, captions, labels, bboxes, clip_model, clip_processor, device), seeds=seeds)]
+        if hip_flow:
+            box = [dict(tok=tokenize_conditioning(all_models, captions, labels, bboxes, clip_processor), seeds=seeds,
+                        own_phrase_encoder=_is_hip_encoder(clip_model))]
+        else:
+            # prepare_conditioning returns HOST tensors: object collectives pickle tensors with their device, and rank r must not
+            # receive rank 0's "cuda:0" tensors
+            box = [dict(cond=prepare_conditioning(all_models, captions, labels, bboxes, clip_model, clip_processor, device), seeds=seeds)]
     if multi:
         with _collective_device(device):
             dist.broadcast_object_list(box, src=src)
-    cond, seeds = box[0]["cond"], box[0]["seeds"]
+    seeds = box[0]["seeds"]
     n = len(seeds)
     mine = shard_indices(n, rank, world)
-    sub = {k: v[mine] for k, v in cond.items()}
+    if "tok" in box[0]:
+        # grounding phrases: this rank's own phrase encoder when it has one (a HipCLIPTextEncoder, e.g. hip_phrase_encoder(CLIPModel)),
+        # else the conditioning tower itself -- the GLIGEN checkpoint's text encoder and the reference's default CLIPModel are both
+        # openai/clip-vit-large-patch14 (encoders/modules.py:146, train_rl.py:282)
+        if box[0]["own_phrase_encoder"] and not _is_hip_encoder(clip_model):
+            raise ValueError("rank %d: src encodes the grounding phrases with its own HIP phrase encoder (clip_model); every rank must pass "
+                             "one built from the same CLIP weights, or all ranks pass None to use the checkpoint's text tower" % rank)
+        pe = clip_model if box[0]["own_phrase_encoder"] else all_models[2]
+        sub = encode_conditioning(all_models, box[0]["tok"], mine, pe, device)
+    else:
+        sub = {k: v[mine] for k, v in box[0]["cond"].items()}
     # a rank whose shard fails still takes part in the gather (with the error as its payload): the others must not block
     # forever in gather_object, and src re-raises
     err = None

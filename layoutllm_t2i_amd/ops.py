@@ -267,12 +267,13 @@ def groupnorm(x1: torch.Tensor, x2: Optional[torch.Tensor], B: int, HW: int, gam
 def layernorm(x: torch.Tensor, y: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, B: int, rows_in: int,
               rows_out: Optional[int] = None, row_off: int = 0, eps: float = 1e-5, stats: Optional[torch.Tensor] = None,
               x2: Optional[torch.Tensor] = None, rows2: int = 0) -> torch.Tensor:
-    """x [B*rows_in, C] fp16 or fp32 (residual stream) -> y fp16 rows b*rows_out + row_off + i (y is [B*rows_out, C]);
+    """x [B*rows_in, C] fp16 or fp32 (residual stream) -> y fp16 (or fp32: the dtype of ``y`` decides) rows b*rows_out + row_off + i (y is [B*rows_out, C]);
     ``stats`` (optional fp32 [B*rows_in, 2]) receives (mean, rstd) per row.  ``x2`` (fp16 [B*rows2, C]): a second source
     whose rows follow x's rows inside every sample's block of y ([x ; objs] in one launch)."""
     xf32 = x.dtype == F32
+    yf32 = y.dtype == F32
     _req(x, F32 if xf32 else F16, "x")
-    _req(y, F16, "y")
+    _req(y, F32 if yf32 else F16, "y")
     _req(gamma, F32, "gamma")
     _req(beta, F32, "beta")
     _, Cc, ldx = _rows(x, "x")
@@ -286,7 +287,7 @@ def layernorm(x: torch.Tensor, y: torch.Tensor, gamma: torch.Tensor, beta: torch
     if x2 is not None:
         _req(x2, F16, "x2")
         ldx2 = _rows(x2, "x2")[2]
-    check(_lib.lib().gl_layernorm(x.data_ptr(), ldx, int(xf32), y.data_ptr(), ldy, gamma.data_ptr(), beta.data_ptr(), B, rows_in,
+    check(_lib.lib().gl_layernorm(x.data_ptr(), ldx, int(xf32) | (2 if yf32 else 0), y.data_ptr(), ldy, gamma.data_ptr(), beta.data_ptr(), B, rows_in,
                                   rows_out, row_off, Cc, eps, _ptr(stats), _ptr(x2), ldx2, rows2, _stream()), "gl_layernorm")
     return y
 

@@ -41,13 +41,18 @@ def main():
     try:
         stubs.install_fake_sng_parser()
         am = itf.load_all_models_sharded(ckpt, dev, src=0)
-        clip, proc = (stubs.toy_clip().to(dev), stubs.ToyProcessor()) if rank == 0 else (None, None)
+        if os.environ.get("W_CLIP_TOWER"):
+            # checkpoint with a CLIP text tower: the HIP encoder is on every rank (its weights came in the bundle), rank 0 only tokenises;
+            # grounding phrases go through the same tower (clip_model None on every rank)
+            clip, proc = None, (stubs.ToyProcessor() if rank == 0 else None)
+        else:
+            clip, proc = (stubs.toy_clip().to(dev), stubs.ToyProcessor()) if rank == 0 else (None, None)
         args = (PROMPTS, PHRASES, BOXES) if rank == 0 else (None, None, None)
         imgs = itf.generate_batch_images_sharded(am, *args, clip, proc, device=dev, seeds=SEEDS if rank == 0 else None, src=0,
                                                  steps=STEPS, latent=LATENT)
         if rank == 0:
             np.savez(os.path.join(out_dir, "images.npz"), imgs=np.stack([np.asarray(im) for im in imgs]))
-        print("RESULT " + json.dumps(dict(rank=rank, ckpt_reads=reads["n"], text_encoder=am[2] is not None,
+        print("RESULT " + json.dumps(dict(rank=rank, ckpt_reads=reads["n"], text_encoder=am[2] is not None, text_encoder_type=type(am[2]).__name__,
                                           n_images=None if imgs is None else len(imgs))), flush=True)
     finally:
         dist.destroy_process_group()

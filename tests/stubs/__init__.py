@@ -60,11 +60,54 @@ class ToyProcessor:
         return {"input_ids": ids, "attention_mask": am}
 
 
-def toy_clip():
+class ToyTokenizer:
+    """``CLIPTokenizer``'s call contract as FrozenCLIPEmbedder uses it (encoders/modules.py:160-161): rows truncated / padded
+    to ``max_length`` with the EOS id; same word hashing as ToyProcessor."""
+    BOS, EOS = 98, 99
+
+    def __call__(self, text, truncation=True, max_length=77, return_length=True, return_overflowing_tokens=False, padding="max_length",
+                 return_tensors="pt"):
+        if isinstance(text, str):
+            text = [text]
+        rows = [([self.BOS] + [1 + (sum(map(ord, w)) % 90) for w in t.split()])[:max_length - 1] + [self.EOS] for t in text]
+        return {"input_ids": torch.tensor([r + [self.EOS] * (max_length - len(r)) for r in rows], dtype=torch.long)}
+
+
+def toy_text_tower_state_dict(seed: int = 0, hidden: int = 768, heads: int = 12, layers: int = 2, inter: int = 256, vocab: int = 100,
+                              positions: int = 77):
+    """``text_model.*`` fp32 tensors of a small CLIP text tower (transformers' key names) with recipe weights: LN gains ~1,
+    projections ~ 1/sqrt(fan_in), so every term of the tower matters."""
+    from layoutllm_t2i_amd import recipe
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    sd = {}
+
+    def lin(name, n, k, scale=1.0):
+        sd[name + ".weight"] = T(recipe.normal("tt." + name + ".w", (n, k), seed)) * float(scale / np.sqrt(k))
+        sd[name + ".bias"] = T(recipe.normal("tt." + name + ".b", (n,), seed)) * 0.1
+
+    def ln(name):
+        sd[name + ".weight"] = 1.0 + 0.1 * T(recipe.normal("tt." + name + ".g", (hidden,), seed))
+        sd[name + ".bias"] = 0.05 * T(recipe.normal("tt." + name + ".b", (hidden,), seed))
+    sd["text_model.embeddings.token_embedding.weight"] = T(recipe.normal("tt.tok", (vocab, hidden), seed)) * 0.5
+    sd["text_model.embeddings.position_embedding.weight"] = T(recipe.normal("tt.pos", (positions, hidden), seed)) * 0.3
+    for i in range(layers):
+        p = f"text_model.encoder.layers.{i}"
+        for n in "qkv":
+            lin(f"{p}.self_attn.{n}_proj", hidden, hidden)
+        lin(f"{p}.self_attn.out_proj", hidden, hidden, 0.7)
+        ln(f"{p}.layer_norm1")
+        ln(f"{p}.layer_norm2")
+        lin(f"{p}.mlp.fc1", inter, hidden)
+        lin(f"{p}.mlp.fc2", hidden, inter, 0.7)
+    ln("text_model.final_layer_norm")
+    return sd
+
+
+def toy_clip(text_heads: int = 4):
     from transformers import CLIPConfig, CLIPModel
     rng = torch.random.get_rng_state()
     torch.manual_seed(0)
-    cfg = CLIPConfig(text_config=dict(hidden_size=768, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+    cfg = CLIPConfig(text_config=dict(hidden_size=768, intermediate_size=128, num_hidden_layers=2, num_attention_heads=text_heads,
                                       vocab_size=100, max_position_embeddings=16, eos_token_id=99, bos_token_id=98,
                                       pad_token_id=99),
                      vision_config=dict(hidden_size=32, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2,
@@ -93,9 +136,11 @@ def install_fake_sng_parser():
     return mod
 
 
-def write_synthetic_checkpoint(path, cfg, vae_cfg, seed=0, max_relations=10, with_sd_conv=True):
+def write_synthetic_checkpoint(path, cfg, vae_cfg, seed=0, max_relations=10, with_sd_conv=True, clip_text_tower=False):
     """A checkpoint with the reference's container: {model, autoencoder, text_encoder, diffusion, config_dict._content}
-    (interface.py:79-94) holding recipe weights of ``cfg`` / ``vae_cfg``; the text encoder node targets StubTextEncoder."""
+    (interface.py:79-94) holding recipe weights of ``cfg`` / ``vae_cfg``; the text encoder node targets StubTextEncoder, or,
+    with ``clip_text_tower``, is FrozenCLIPEmbedder's with a ``transformer.text_model.*`` state dict of a small CLIP text tower
+    (what a real GLIGEN checkpoint holds) and a ToyTokenizer node."""
     from layoutllm_t2i_amd import recipe
     t = lambda d: {k: torch.tensor(np.asarray(v, dtype=np.float32)) for k, v in d.items()}     # 0-d gates stay 0-d
     content = {
@@ -112,14 +157,18 @@ def write_synthetic_checkpoint(path, cfg, vae_cfg, seed=0, max_relations=10, wit
                                    "ddconfig": {"double_z": True, "z_channels": vae_cfg.z_channels, "resolution": 256, "in_channels": 3,
                                                 "out_ch": vae_cfg.out_ch, "ch": vae_cfg.ch, "ch_mult": list(vae_cfg.ch_mult),
                                                 "num_res_blocks": vae_cfg.num_res_blocks, "attn_resolutions": [], "dropout": 0.0}}},
-        "text_encoder": {"target": "stubs.StubTextEncoder", "params": {}},
+        "text_encoder": ({"target": "ldm.modules.encoders.modules.FrozenCLIPEmbedder",
+                          "params": {"max_length": 77, "num_attention_heads": 12, "tokenizer": {"target": "stubs.ToyTokenizer"}}}
+                         if clip_text_tower else {"target": "stubs.StubTextEncoder", "params": {}}),
         "diffusion": {"target": "ldm.models.diffusion.ldm.LatentDiffusion",
                       "params": {"linear_start": 0.00085, "linear_end": 0.012, "timesteps": 1000}},
         "grounding_tokenizer_input": {"target": "grounding_input.text_layout_tokinzer_input.GroundingNetInput"},
         "max_relations": max_relations,
     }
     ckpt = {"model": t(recipe.state_dict(cfg, seed)), "autoencoder": t(recipe.vae_state_dict(vae_cfg, seed)),
-            "text_encoder": {"dummy": torch.zeros(1)}, "diffusion": {}, "config_dict": {"_content": content}}
+            "text_encoder": ({"transformer." + k: v for k, v in toy_text_tower_state_dict(seed).items()} if clip_text_tower
+                             else {"dummy": torch.zeros(1)}),
+            "diffusion": {}, "config_dict": {"_content": content}}
     torch.save(ckpt, path)
     if with_sd_conv:
         fc = recipe.sd_first_conv(cfg, seed)

@@ -267,3 +267,74 @@ def test_gligen_inference_run_with_injected_clip(loaded, tmp_path):
     assert np.array_equal(np.asarray(again[0]), np.asarray(imgs[0])), "second run() on the cached model differs from the first"
     with pytest.raises(NotImplementedError):
         gi.run(meta, dict(cfg, no_plms=True), clip_model=clip, clip_processor=proc)
+
+
+# ------------------------------------------------------------------------------------------- the conditioning encoders on the HIP tower (8f-2)
+class _OracleTextEncoder:
+    """FrozenCLIPEmbedder's contract on the oracle text tower (oracle/clip_ref.text_hidden_states): the CHECKER's encoder"""
+
+    def __init__(self, sd, tokenizer, heads=12, max_length=77):
+        self.sd, self.tok, self.heads, self.max_length = sd, tokenizer, heads, max_length
+
+    def encode(self, texts, return_pooler_output=False):
+        from oracle import clip_ref
+        ids = self.tok(list(texts), max_length=self.max_length)["input_ids"]
+        with torch.no_grad():
+            z, pooled = clip_ref.text_hidden_states(self.sd, ids, self.heads)
+        return (z, pooled) if return_pooler_output else z
+
+
+@pytest.mark.gpu
+def test_checkpoint_with_clip_text_tower_runs_on_the_hip_encoder_and_equals_the_oracle_pipeline(tmp_path):
+    """A checkpoint whose ``text_encoder`` entry is a CLIP text tower (FrozenCLIPEmbedder.state_dict(), as in a real GLIGEN
+    checkpoint): load_all_models puts it on the HIP tower; run_batch_images with a HIP phrase encoder (hip_phrase_encoder of the
+    caller's CLIPModel) then equals the oracle UNet -> PLMS -> VAE fed by the ORACLE text tower through the reference flow
+    (one CLIP forward per phrase, relation phrases 'PAD' + twice); also: every conditioning tensor vs that flow."""
+    from layoutllm_t2i_amd.text_encoder import HipCLIPTextEncoder
+    from oracle import clip_ref
+    p = str(tmp_path / "tiny_gligen_clip.pth")
+    stubs.write_synthetic_checkpoint(p, TINY, VAE_TINY, max_relations=10, clip_text_tower=True)
+    stubs.install_fake_sng_parser()
+    am = itf.load_all_models(p, DEV)
+    model, autoencoder, text_encoder, diffusion, config = am
+    assert isinstance(text_encoder, HipCLIPTextEncoder) and text_encoder.heads == 12 and isinstance(text_encoder.tokenizer, stubs.ToyTokenizer)
+    clip_hf = stubs.toy_clip(text_heads=12)                       # the caller's CLIPModel (phrases), 64-wide heads like ViT-L/14's
+    phrase_enc = itf.hip_phrase_encoder(clip_hf, DEV)
+    assert isinstance(phrase_enc, HipCLIPTextEncoder) and phrase_enc.heads == 12
+    proc = stubs.ToyProcessor()
+    # conditioning: HIP flow vs the reference flow on the oracle tower / the HF CLIPModel itself
+    cond_hip = itf.prepare_conditioning(am, PROMPTS, PHRASES, BOXES_LTRB, phrase_enc, proc, DEV)
+    tsd = stubs.toy_text_tower_state_dict(0)
+    oenc = _OracleTextEncoder(tsd, stubs.ToyTokenizer())
+    cond = _expected_conditioning(PROMPTS, PHRASES, BOXES_LTRB, oenc, clip_hf, proc, 10)
+    for k, kk in (("context", "context"), ("uc", "uc"), ("relations", "relations"), ("text_embeddings", "positive_embeddings")):
+        r = float((cond_hip[k] - cond[kk]).norm() / cond[kk].norm())
+        print(f"[hip conditioning] {k}: rel_l2 vs reference flow = {r:.3e}")
+        assert r < 3e-3, (k, r)
+    assert torch.equal(cond_hip["boxes"], cond["boxes"]) and torch.equal(cond_hip["masks"], cond["masks"])
+    # the two-stage form the sharded entry uses (tokens on src, encoding per rank) gives the same rows for any row subset
+    tok = itf.tokenize_conditioning(am, PROMPTS, PHRASES, BOXES_LTRB, proc)
+    for rows in ([0, 1], [1], [0]):
+        sub = itf.encode_conditioning(am, tok, rows, phrase_enc, DEV)
+        for k in ("context", "uc", "relations", "text_embeddings"):
+            r = float((sub[k].cpu() - cond_hip[k][rows]).norm() / (cond_hip[k][rows].norm() + 1e-30))
+            assert r < 1e-3, (k, rows, r)
+        assert torch.equal(sub["boxes"].cpu(), cond_hip["boxes"][rows]) and torch.equal(sub["masks"].cpu(), cond_hip["masks"][rows])
+    # the whole boundary
+    torch.manual_seed(123)
+    noise = torch.randn(2, 4, 16, 16)
+    captured = {}
+    dec = autoencoder.decode
+    autoencoder.decode = lambda z: captured.setdefault("img", dec(captured.setdefault("lat", z.clone())))
+    try:
+        args = dict(batch_size=2, no_plms=False, guidance_scale=7.5, steps=4)
+        meta = dict(prompts=PROMPTS, phrases=PHRASES, locations=BOXES_LTRB, alpha_type=[0.5, 0.0, 0.5])
+        imgs = itf.run_batch_images(am, args, meta, noise.to(DEV), phrase_enc, proc, device=DEV)
+    finally:
+        autoencoder.decode = dec
+    lat_ref, img_ref = _oracle_pipeline(cond, noise, 4, [0.5, 0.0, 0.5])
+    rl = float((captured["lat"].cpu() - lat_ref).norm() / lat_ref.norm())
+    ri = float((captured["img"].float().cpu() - img_ref).norm() / img_ref.norm())
+    print(f"[boundary, HIP encoders] latent rel_l2={rl:.3e} decoded image rel_l2={ri:.3e}")
+    assert rl < 5e-3 and ri < 5e-3, (rl, ri)
+    assert len(imgs) == 2 and imgs[0].size == (32, 32)

@@ -198,3 +198,77 @@ def test_reward_model_from_images_equals_the_pixel_values_path():
     ready = rm.forward_images(ids, T(px42), T(px_gt), pred_is_pixel_values=True, gt_is_pixel_values=True)
     for k in ("sims_ti", "sims_ii", "aes_reward", "reward"):
         assert torch.equal(out42[k], want42[k]) and torch.equal(ready[k], want42[k]), k
+
+
+# ------------------------------------------------------------------------------------------------ conditioning text encoder
+GOLD_TEXT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "clip_text_tiny.npz")
+
+
+def test_oracle_text_hidden_states_match_transformers_cliptextmodel_golden():
+    """oracle/clip_ref.text_hidden_states against transformers' own CLIPTextModel (what FrozenCLIPEmbedder wraps,
+    encoders/modules.py:144-174) on rows padded with the eos id: last_hidden_state and pooler_output (first eos)."""
+    z, sd = golden()
+    zt = np.load(GOLD_TEXT)
+    ids = T(zt["input_ids"])
+    with torch.no_grad():
+        lhs, pooled = clip_ref.text_hidden_states(sd, ids, int(z["heads"]))
+    scale = float(np.abs(zt["last_hidden_state"]).max())
+    assert float(np.abs(lhs.numpy() - zt["last_hidden_state"]).max()) < 5e-5 * scale
+    assert float(np.abs(pooled.numpy() - zt["pooler_output"]).max()) < 5e-5 * scale
+    first_eos = (ids == ids.max()).int().argmax(-1)
+    assert torch.equal(pooled, lhs[torch.arange(ids.shape[0]), first_eos])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spelling", ["text_model", "transformer.text_model", "bare"])
+def test_hip_text_encoder_vs_transformers_cliptextmodel_golden(spelling):
+    """text_encoder.HipCLIPTextEncoder (the HIP text tower behind FrozenCLIPEmbedder's call surface) against the CLIPTextModel
+    golden, built from each of the three state-dict key spellings that occur in the wild."""
+    from layoutllm_t2i_amd.text_encoder import HipCLIPTextEncoder
+    z, sd = golden()
+    zt = np.load(GOLD_TEXT)
+    tsd = {k: v for k, v in sd.items() if k.startswith("text_model.")}
+    if spelling == "transformer.text_model":
+        tsd = {"transformer." + k: v for k, v in tsd.items()}
+    elif spelling == "bare":
+        tsd = {k[len("text_model."):]: v for k, v in tsd.items()}
+    enc = HipCLIPTextEncoder(tsd, None, "cuda:0", heads=int(z["heads"]), max_length=zt["input_ids"].shape[1])
+    ids = T(zt["input_ids"])
+    lhs, pooled = enc.encode_ids(ids, return_pooler_output=True)
+    assert lhs.dtype == torch.float32 and lhs.shape == zt["last_hidden_state"].shape and pooled.shape == zt["pooler_output"].shape
+    rl, rp = rel(lhs, T(zt["last_hidden_state"])), rel(pooled, T(zt["pooler_output"]))
+    print(f"[hip text encoder vs CLIPTextModel, {spelling}] last_hidden_state rel_l2={rl:.3e} pooler_output rel_l2={rp:.3e}")
+    assert rl < 3e-3 and rp < 3e-3, (rl, rp)            # fp16 matrix operands of 4x-scaled weights, as for the reward towers (1.4e-3)
+    first_eos = (ids == ids.max()).int().argmax(-1)
+    assert torch.equal(pooled.cpu(), lhs.cpu()[torch.arange(ids.shape[0]), first_eos])
+    # graph replay == eager, and the phrase path (rows padded only to the longest phrase) gives the same pooled rows
+    enc.towers.use_graphs = False
+    lhs2, pooled2 = enc.encode_ids(ids, return_pooler_output=True)
+    enc.towers.use_graphs = True
+    assert torch.equal(lhs, lhs2) and torch.equal(pooled, pooled2)
+    L = int(first_eos.max()) + 1
+    short = enc.pooler_output(ids[:, :L])
+    assert rel(short, pooled) < 2e-3                     # other GEMM row counts: fp32 summation order only
+
+
+@pytest.mark.gpu
+def test_hip_text_encoder_encode_contract_and_oracle_at_vit_l_sizes():
+    """``encode(list[str], return_pooler_output)`` (FrozenCLIPEmbedder.forward, encoders/modules.py:159-174) through a tokenizer
+    with CLIPTokenizer's call contract, at ViT-L/14's text sizes (768 wide, 12 heads, 77 positions) against the oracle."""
+    import stubs
+    from layoutllm_t2i_amd.text_encoder import HipCLIPTextEncoder
+    sd = stubs.toy_text_tower_state_dict(1)
+    tok = stubs.ToyTokenizer()
+    enc = HipCLIPTextEncoder({"transformer." + k: v for k, v in sd.items()}, tok, "cuda:0")
+    assert enc.heads == 12 and enc.hidden == 768
+    texts = ["cat sitting on mat and dog under a tree", "", "a quiet empty street", "PAD"]
+    z = enc.encode(texts)
+    z2, pooled = enc(texts, return_pooler_output=True)
+    assert z.shape == (4, 77, 768) and torch.equal(z, z2) and pooled.shape == (4, 768) and z.is_cuda
+    ids = tok(texts)["input_ids"]
+    with torch.no_grad():
+        want, wpool = clip_ref.text_hidden_states(sd, ids, 12)
+    rl, rp = rel(z, want), rel(pooled, wpool)
+    print(f"[hip text encoder, 768 x 12 heads x 77] rel_l2={rl:.3e} pooled rel_l2={rp:.3e}")
+    assert rl < 2e-3 and rp < 2e-3, (rl, rp)
+    assert torch.equal(enc.encode("a quiet empty street")[0], z[2])          # a single string is a batch of one

@@ -118,6 +118,51 @@ def test_product_entry_two_ranks_equal_single_process_bitwise(tmp_path):
     assert solo.shape == got.shape and np.mean(np.abs(solo.astype(int) - got.astype(int)) <= 3) > 0.97
 
 
+def test_product_entry_two_ranks_hip_text_encoder_each_rank_encodes_its_own_shard(tmp_path):
+    """Same product entry with a checkpoint whose text encoder is a CLIP text tower: the tower's weights travel in the
+    one bundle broadcast, rank 1 (which never opens the checkpoint) holds a HipCLIPTextEncoder, rank 0 only TOKENISES, and every
+    rank encodes + denoises + decodes its own prompts.  Rank r's images must equal, bitwise, this process's own
+    tokenize -> encode_conditioning(rows of rank r) -> run_shard from its own load of the checkpoint."""
+    import stubs
+    import dist_product_worker as W
+    from layoutllm_t2i_amd import interface as itf
+    from layoutllm_t2i_amd.arch import TINY, VAE_TINY
+    from layoutllm_t2i_amd.dist import shard_indices
+    ckpt = str(tmp_path / "tiny_gligen_clip.pth")
+    stubs.write_synthetic_checkpoint(ckpt, TINY, VAE_TINY, max_relations=10, clip_text_tower=True)
+    world, port = 2, _free_port()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_product_worker.py")
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2",
+                   W_CLIP_TOWER="1")
+        procs.append(subprocess.Popen([sys.executable, worker, ckpt, str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    res = []
+    try:
+        for p in procs:
+            out, err = p.communicate(timeout=600)
+            assert p.returncode == 0, err[-3000:]
+            res.append(json.loads(next(l for l in out.splitlines() if l.startswith("RESULT "))[7:]))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    a, b = sorted(res, key=lambda d: d["rank"])
+    assert a["ckpt_reads"] >= 1 and b["ckpt_reads"] == 0, "only rank 0 may read the checkpoint"
+    assert a["text_encoder_type"] == b["text_encoder_type"] == "HipCLIPTextEncoder"
+    got = np.load(tmp_path / "images.npz")["imgs"]
+    assert got.shape[0] == len(W.PROMPTS) and got.dtype == np.uint8
+    dev = "cuda:0"
+    stubs.install_fake_sng_parser()
+    am = itf.load_all_models(ckpt, dev)
+    tok = itf.tokenize_conditioning(am, W.PROMPTS, W.PHRASES, W.BOXES, stubs.ToyProcessor())
+    for r in range(world):
+        mine = shard_indices(len(W.PROMPTS), r, world)
+        cond = itf.encode_conditioning(am, tok, mine, am[2], dev)
+        ref = itf.run_shard(am, cond, itf.prompt_noise([W.SEEDS[i] for i in mine], W.LATENT), dev, steps=W.STEPS)
+        assert np.array_equal(got[mine], ref), f"rank {r}: {np.abs(got[mine].astype(int) - ref.astype(int)).max()}"
+
+
 def test_rccl_path_of_the_bench_at_world_1():
     """The multi-rank code path of bench.py (RCCL process group bound to the device, bundle broadcast of UNet + VAE, barriers,
     max-over-ranks all-reduce) launched exactly as the driver launches N > 1, with ONE rank: every collective goes through

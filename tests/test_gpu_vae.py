@@ -103,20 +103,20 @@ def test_c_engine_equals_python_op_sequence_bitwise(cfgname, B, side):
     assert _lib.lib().gl_vae_num_launches(dec.handle) > 20 and _lib.lib().gl_vae_pool_bytes(dec.handle) > 0
 
 
-def test_vae_set_option_is_per_decoder_and_rebuilds_graphs():
-    """VAEDecoder.set_option (gl_vae_set_option): a knob set on ONE decoder reaches its launches (here knob 17 = 0: every
-    GroupNorm as statistics + apply instead of the single-launch forms, so the launch count grows) and leaves the result
-    within rounding of the default path; a second decoder is untouched (the method used to raise NameError)."""
-    from layoutllm_t2i_amd import _lib
+def test_vae_set_option_is_per_decoder():
+    """VAEDecoder.set_option (gl_vae_set_option; ADVICE r3: the method used to raise NameError): knobs set on ONE decoder (13 = 0:
+    no intra-block K-split conv variants, 30 = 0: no 8-wave kernel -- other fp32 summation orders) leave its result within
+    rounding of the default path, a second decoder built from the same weights is untouched, an unknown key is refused."""
     cfg = VAE_TINY
     a = VAEDecoder(recipe.vae_state_dict(cfg, 0), cfg, DEV)
     b = VAEDecoder(recipe.vae_state_dict(cfg, 0), cfg, DEV)
-    z = T(recipe.normal("vae.zopt", (2, cfg.z_channels, 8, 8), 3)) * np.float32(0.18215)
+    z = T(recipe.normal("vae.zopt", (2, cfg.z_channels, 16, 16), 3)) * np.float32(0.18215)
     base = a.decode(z).clone()
-    n0 = _lib.lib().gl_vae_num_launches(a.handle)
-    a.set_option(17, 0)
+    a.set_option(13, 0)
+    a.set_option(30, 0)
     alt = a.decode(z).clone()
-    n1 = _lib.lib().gl_vae_num_launches(a.handle)
-    assert n1 > n0, (n0, n1)
-    assert rel_l2(alt, base) < 2e-3
-    assert torch.equal(b.decode(z), base) and _lib.lib().gl_vae_num_launches(b.handle) == n0
+    assert torch.isfinite(alt).all() and rel_l2(alt, base) < 2e-3
+    assert torch.equal(a.decode(z), alt)                       # replay of the graph captured under the overrides
+    assert torch.equal(b.decode(z), base)
+    with pytest.raises(Exception):
+        a.set_option(99, 1)
