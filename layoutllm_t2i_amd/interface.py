@@ -189,6 +189,16 @@ def complete_mask(has_mask, max_objs):
     return mask
 
 
+def _hf_text_pooler_output(model, input_ids, attention_mask, device):
+    """``outputs.text_model_output.pooler_output`` of interface.py:136-139 under the reference's pinned transformers 4.19.2: the
+    text tower's pooled hidden state BEFORE ``text_projection`` (``which_layer_text = 'before'``, :115).  transformers 5.x
+    overwrites that field with the PROJECTED feature inside ``CLIPModel.forward``; calling the text tower itself gives the
+    4.19.2 value under every version (and skips the placeholder vision pass)."""
+    if hasattr(model, "text_model"):
+        return model.text_model(input_ids=input_ids, attention_mask=attention_mask).pooler_output
+    return model(input_ids=input_ids, attention_mask=attention_mask, pixel_values=torch.ones(1, 3, 224, 224).to(device)).text_model_output.pooler_output
+
+
 def get_clip_feature(model, processor, input, device, is_image=False):
     """interface.py:114-141, text branch ('before' projection = pooler_output).  Image grounding is
     not on the text_layout path."""
@@ -197,11 +207,7 @@ def get_clip_feature(model, processor, input, device, is_image=False):
     if is_image:
         raise NotImplementedError("image grounding tokens are not on the text_layout path")
     inputs = processor(text=input, return_tensors="pt", padding=True)
-    inputs["input_ids"] = inputs["input_ids"].to(device)
-    inputs["pixel_values"] = torch.ones(1, 3, 224, 224).to(device)
-    inputs["attention_mask"] = inputs["attention_mask"].to(device)
-    outputs = model(**inputs)
-    return outputs.text_model_output.pooler_output
+    return _hf_text_pooler_output(model, inputs["input_ids"].to(device), inputs["attention_mask"].to(device), device)
 
 
 def get_clip_features_batched(model, processor, phrases, device):
@@ -218,10 +224,7 @@ def get_clip_features_batched(model, processor, phrases, device):
         # the HIP text tower (hip_phrase_encoder / text_encoder.HipCLIPTextEncoder): token rows in, pooled rows out; no vision pass
         pooled = model.pooler_output(inputs["input_ids"])
         return {p: pooled[i:i + 1] for i, p in enumerate(uniq)}
-    inputs["input_ids"] = inputs["input_ids"].to(device)
-    inputs["pixel_values"] = torch.ones(1, 3, 224, 224).to(device)       # placeholder, as interface.py:136
-    inputs["attention_mask"] = inputs["attention_mask"].to(device)
-    pooled = model(**inputs).text_model_output.pooler_output
+    pooled = _hf_text_pooler_output(model, inputs["input_ids"].to(device), inputs["attention_mask"].to(device), device)
     return {p: pooled[i:i + 1] for i, p in enumerate(uniq)}
 
 

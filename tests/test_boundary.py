@@ -299,6 +299,8 @@ def test_checkpoint_with_clip_text_tower_runs_on_the_hip_encoder_and_equals_the_
     model, autoencoder, text_encoder, diffusion, config = am
     assert isinstance(text_encoder, HipCLIPTextEncoder) and text_encoder.heads == 12 and isinstance(text_encoder.tokenizer, stubs.ToyTokenizer)
     clip_hf = stubs.toy_clip(text_heads=12)                       # the caller's CLIPModel (phrases), 64-wide heads like ViT-L/14's
+    # (phrase features of the reference flow below = HF's own text tower, pooled BEFORE text_projection: transformers 4.19.2's
+    #  ``text_model_output.pooler_output``, interface.py:115,139; itf.get_clip_feature reads exactly that under every version)
     phrase_enc = itf.hip_phrase_encoder(clip_hf, DEV)
     assert isinstance(phrase_enc, HipCLIPTextEncoder) and phrase_enc.heads == 12
     proc = stubs.ToyProcessor()

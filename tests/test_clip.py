@@ -271,4 +271,5 @@ def test_hip_text_encoder_encode_contract_and_oracle_at_vit_l_sizes():
     rl, rp = rel(z, want), rel(pooled, wpool)
     print(f"[hip text encoder, 768 x 12 heads x 77] rel_l2={rl:.3e} pooled rel_l2={rp:.3e}")
     assert rl < 2e-3 and rp < 2e-3, (rl, rp)
-    assert torch.equal(enc.encode("a quiet empty street")[0], z[2])          # a single string is a batch of one
+    one = enc.encode("a quiet empty street")                                  # a single string is a batch of one
+    assert one.shape == (1, 77, 768) and rel(one[0], z[2]) < 1e-3             # (other GEMM row counts: fp32 summation order only)

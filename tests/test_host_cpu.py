@@ -290,12 +290,12 @@ def test_batched_phrase_features_equal_per_phrase_reference_semantics():
     from layoutllm_t2i_amd import interface as itf
     model, proc = _toy_clip(), _ToyProcessor()
     calls = {"n": 0}
-    fwd = model.forward
+    fwd = model.text_model.forward
 
     def counting(*a, **k):
         calls["n"] += 1
         return fwd(*a, **k)
-    model.forward = counting
+    model.text_model.forward = counting              # the text tower is what interface.py:136-139 reads ('before' projection)
     meta = {"phrases": [["a red dog", "tree", "a very tall old tree"], ["tree", "sky"]],
             "locations": [[[0.1, 0.1, 0.5, 0.5], [0.2, 0.3, 0.9, 0.8], [0.0, 0.0, 1.0, 1.0]], [[0.3, 0.3, 0.6, 0.6], [0.0, 0.0, 1.0, 0.4]]]}
     with torch.no_grad():
@@ -305,6 +305,11 @@ def test_batched_phrase_features_equal_per_phrase_reference_semantics():
             for i, ph in enumerate(phrases):
                 ref = itf.get_clip_feature(model, proc, ph, "cpu")          # the reference's per-phrase call
                 torch.testing.assert_close(out["text_embeddings"][b, i:i + 1], ref, rtol=1e-5, atol=1e-5)
+                # ... and, independently of interface.py, HuggingFace's own text tower on the UNPADDED phrase: the pooled hidden state
+                # before text_projection (transformers 4.19.2's text_model_output.pooler_output, interface.py:115,139)
+                ids = proc(text=ph)["input_ids"]
+                hf = fwd(input_ids=ids).pooler_output
+                torch.testing.assert_close(out["text_embeddings"][b, i:i + 1], hf, rtol=1e-5, atol=1e-5)
             n = len(phrases)
             assert out["masks"][b].tolist() == [1.0] * n + [0.0] * (30 - n)
             assert out["text_masks"][b].tolist() == [1.0] * n + [0.0] * (30 - n)
