@@ -90,7 +90,7 @@ def test_tiny_unet_matches_reference_golden(name):
     out = model(d)
     ref = T(np.load(os.path.join(GOLD, name + ".npz"))["out"])
     r = report(name, out, ref)
-    assert r < 2.6e-3, r            # measured 1.67e-3 .. 1.77e-3 (fp32 reference weights: includes fp16 weight rounding)
+    assert r < 2.1e-3, r            # round 4: 1.34e-3 .. 1.43e-3 (round 3: 1.67e-3 .. 1.77e-3); fp32 reference weights: includes fp16 weight rounding
 
 
 def test_cfg_batched_2b_equals_two_calls():
@@ -126,7 +126,7 @@ def test_plms_tiny_matches_reference_golden():
     ref = T(np.load(os.path.join(GOLD, "plms_tiny.npz"))["out"])
     # 22 chained fp16 UNet evaluations with CFG 7.5 on a random-weight (non-contractive) denoiser
     r = report("plms_tiny", out, ref)
-    assert r < 4.3e-3, r            # measured 2.89e-3
+    assert r < 3.1e-3, r            # round 4: 2.04e-3 (round 3: 2.89e-3)
 
 
 def test_sampler_loop_equals_oracle_loop_given_engine_eps():
@@ -180,7 +180,7 @@ def test_full_width_level_vs_oracle(name, cfg, hw, B):
         ref = unet_ref.unet_forward(oracle_sd(sd), cfg, inp["x"].half().float(), t, inp["context"].half().float(),
                                     inp["relations"].half().float(), inp["boxes"], inp["masks"], inp["positive_embeddings"])
     r = report(name, out, ref)
-    assert r < 1.3e-3, r            # measured 7.9e-4 .. 8.5e-4
+    assert r < 7.5e-4, r            # round 4: 4.6e-4 .. 5.0e-4 (round 3: 7.9e-4 .. 8.5e-4)
     del model
     torch.cuda.empty_cache()
 
@@ -212,8 +212,8 @@ def test_full_unet_config2_vs_oracle():
                                       inp["positive_embeddings"])
     r_h = report("full_unet_fp16_rounded_weights", out, ref_h)
     r_f = report("full_unet_fp32_weights", out, ref_f)
-    assert r_h < 1.7e-3, r_h        # measured 1.13e-3 (round 1, fp16 residual stream: 1.68e-3)
-    assert r_f < 2.3e-3, r_f        # measured 1.56e-3 (round 1: 1.98e-3)
+    assert r_h < 8.5e-4, r_h        # round 4: 6.75e-4 (round 3: 1.13e-3; round 1, fp16 residual stream: 1.68e-3)
+    assert r_f < 1.9e-3, r_f        # round 4: 1.26e-3 (round 3: 1.56e-3; round 1: 1.98e-3): dominated by the fp16 rounding of the stored weights
     # size-independent properties at the full size:
     # (1) graph replay is deterministic (fixed reduction orders everywhere)
     out2 = eng.forward(inp["x"].to(DEV), 481.0, 1.0, False, 1).clone()
@@ -274,7 +274,7 @@ def test_full_size_plms_5step_cfg_vs_oracle():
         return e_u + guidance * (e_c - e_u)
     ref = plms_ref.plms_sample(eps_fn, inp["x"], S, alpha_type)
     r = report("full_size_plms_5step", out, ref)
-    assert r < 2.6e-3, r            # measured 1.73e-3 (round 1: 2.6e-3)
+    assert r < 1.5e-3, r            # round 4: 1.0e-3 (round 3: 1.73e-3; round 1: 2.6e-3)
     del model
     torch.cuda.empty_cache()
 
@@ -296,7 +296,7 @@ def test_config3_768px_level_vs_oracle():
         ref = unet_ref.unet_forward(oracle_sd(sd), cfg, inp["x"].half().float(), t, inp["context"].half().float(),
                                     inp["relations"].half().float(), inp["boxes"], inp["masks"], inp["positive_embeddings"])
     r = report("L0_c320_d40_96x96", out, ref)
-    assert r < 1.3e-3, r            # measured 8.4e-4
+    assert r < 7.5e-4, r            # round 4: 4.9e-4 (round 3: 8.4e-4)
     del model
     torch.cuda.empty_cache()
 
@@ -317,7 +317,7 @@ def test_tiny_unet_max_boxes_max_relations_vs_oracle():
                                     inp["relations"].half().float(), inp["boxes"], inp["masks"], inp["positive_embeddings"])
     r = report("tiny_30boxes_10relations", out, ref)
     assert float(inp["masks"].sum()) == 90.0
-    assert r < 2.0e-3, r            # measured 1.33e-3
+    assert r < 1.2e-3, r            # round 4: 8.0e-4 (round 3: 1.33e-3)
 
 
 def test_bench_two_ranks_on_one_gpu_gloo():
