@@ -475,7 +475,11 @@ int gl_sizeof_gn_args(void);
  * Keys that DO change results (precision): key 41 = the engine's 1x1 convs (ResBlock skip_connection, proj_in, proj_out)
  * take split-fp16 activations ([hi | lo] against the same weight) and every GroupNorm that reads a residual-stream tensor reads it
  * in fp32 (1 default; 0 = round-3 behaviour: fp16 copies); key 42 = the ResBlock's first conv writes its output in fp32 for the
- * following GroupNorm (1 default, 0 = fp16). */
+ * following GroupNorm (1 default, 0 = fp16).
+ * key 44 = a [cond ; uncond] forward (reps == 2, one timestep for the batch) computes everything that precedes the first
+ * conditioning-dependent op -- conv_in, the first ResBlock, proj_in .. attn1 of the first transformer block -- ONCE on the shared
+ * latents and duplicates it for the uncond half (1 default; 0 = both halves computed; results equal up to the tile / split-K choice
+ * of the half-sized launches). */
 int gl_set_option(int key, int value);
 /* gl_set_option writes the PROCESS defaults (op-level calls and every handle without an override see them).  A handle can
  * override individual keys for itself: while one of ITS entry points (gl_set_conditioning / gl_unet_forward / gl_plms_step,

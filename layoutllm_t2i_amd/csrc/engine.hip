@@ -33,6 +33,9 @@ constexpr int64_t WS_BYTES = 96ll << 20; // split-K fp32 partial tiles
 #define g_force_fuser gl_opt(20)  // default 0;                   // test knob (gl_set_option 20): execute the fuser even at scale 0 (zero gates)
 #define g_precise gl_opt(41)      // default 1;                   // split-fp16 activations for the 1x1 convs + GroupNorm on the fp32 stream
 #define g_h1_f32 gl_opt(42)       // default 1;                   // with key 41: the ResBlock's first conv writes fp32 for out_layers' GroupNorm
+#define g_share gl_opt(44)        // default 1;                   // 2B = [cond ; uncond] forwards: everything before the first conditioning-dependent op
+                                                                  // (conv_in, the first ResBlock, proj_in .. attn1 of the first transformer) runs ONCE on
+                                                                  // the B shared latents and is duplicated
 
 enum Kind { CONV_IN = 0, RES = 1, ST = 2, DOWN = 3, UP = 4 };
 struct LayerD {
@@ -445,10 +448,22 @@ struct Run {
         ++launches;
         return gl_attention(&a, st);
     }
+    // rows [0, n) of a row-major tensor copied to rows [n, 2n): the uncond half of a tensor computed once for both halves
+    int dup_rows(void* base, size_t bytes_half) {
+        ++launches;
+        return hipMemcpyAsync(reinterpret_cast<char*>(base) + bytes_half, base, bytes_half, hipMemcpyDeviceToDevice, st) == hipSuccess ? 0 : GL_ERR_BAD_ARG;
+    }
     int transpose_v(const half_t* v, int64_t vb, int ldv, half_t* vt, int ldvt, int B, int H, int d, int Nk) {
         ++launches;
         return gl_transpose_v(v, vb, ldv, vt, ldvt, B, H, d, Nk, st);
     }
+};
+
+struct BnScope {            // the engine's batch for the duration of a half-batch (shared cond / uncond) section
+    gl_engine* e;
+    int saved;
+    BnScope(gl_engine* e_, int bn) : e(e_), saved(e_->Bn) { e->Bn = bn; }
+    ~BnScope() { e->Bn = saved; }
 };
 
 struct Stream2 {            // a residual-stream tensor: fp32 master + fp16 copy for matrix-core consumers
@@ -592,7 +607,10 @@ int res_block(Run& r, const LayerD& l, Stream2 h, const Stream2* skip, int skip_
 }
 
 // SpatialTransformer.forward + BasicTransformerBlock._forward (attention.py:436-446, :394-402)
-int spatial_transformer(Run& r, const LayerD& l, int li, Stream2 xin, int side, bool fuser_on, const std::string& tag, bool need_h, Stream2* out) {
+// share_half: xin holds only the first Bn / 2 samples (the shared cond / uncond prefix): GroupNorm .. attn1 run on those rows, then xin and x
+// are duplicated into the second half and the block continues on all Bn samples (from the first conditioning-dependent op on).
+int spatial_transformer(Run& r, const LayerD& l, int li, Stream2 xin, int side, bool fuser_on, const std::string& tag, bool need_h, Stream2* out,
+                        bool share_half = false) {
     gl_engine* e = r.e;
     const gl_unet_config& cfg = e->cfg;
     const std::string& p = l.prefix;
@@ -609,25 +627,34 @@ int spatial_transformer(Run& r, const LayerD& l, int li, Stream2 xin, int side, 
     const float* gates = e->f32("gates", e->st_layers.size() * 4) + (size_t)li * 4;
     float* x = xa;
     auto nxt = [&](float* cur) { return cur == xa ? xb : xa; };
-    if (precise) {
-        // Normalize on the fp32 stream, rows written as [hi | lo]; proj_in takes both halves against the same weight
-        CK(r.gn(xin.f, C, nullptr, 0, 1, Bn, N, p + ".norm", 1e-6f, 0, g0, 2 * C, g0 + C));
-        CK(r.gemm(g0, 2 * C, p + ".proj_in.w", M, x, C, GL_OUT_F32_ROWMAJOR, p + ".proj_in.b", GL_EPI_BIAS, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, 0, 0,
-                  true));
-    } else {
-        CKP(xin.h);
-        CK(r.gn(xin.h, C, nullptr, 0, 0, Bn, N, p + ".norm", 1e-6f, 0, g0));
-        CK(r.gemm(g0, C, p + ".proj_in.w", M, x, C, GL_OUT_F32_ROWMAJOR, p + ".proj_in.b"));
-    }
-    // --- attn1 (attention.py:395)
-    half_t* att = nullptr;
-    CK(r.ln(x, C, 1, lnb, C, t + ".norm1", Bn, N, N, 0, C));
-    CK(self_attention(r, lnb, N, N, N, C, d, t + ".attn1", "st.sa", &att));
     {
+        const int B1 = share_half ? Bn / 2 : Bn, M1 = B1 * N;
+        BnScope half(e, B1);              // self_attention reads e->Bn
+        if (precise) {
+            // Normalize on the fp32 stream, rows written as [hi | lo]; proj_in takes both halves against the same weight
+            CK(r.gn(xin.f, C, nullptr, 0, 1, B1, N, p + ".norm", 1e-6f, 0, g0, 2 * C, g0 + C));
+            CK(r.gemm(g0, 2 * C, p + ".proj_in.w", M1, x, C, GL_OUT_F32_ROWMAJOR, p + ".proj_in.b", GL_EPI_BIAS, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, 0,
+                      0, true));
+        } else {
+            CKP(xin.h);
+            CK(r.gn(xin.h, C, nullptr, 0, 0, B1, N, p + ".norm", 1e-6f, 0, g0));
+            CK(r.gemm(g0, C, p + ".proj_in.w", M1, x, C, GL_OUT_F32_ROWMAJOR, p + ".proj_in.b"));
+        }
+        // --- attn1 (attention.py:395)
+        half_t* att1 = nullptr;
+        CK(r.ln(x, C, 1, lnb, C, t + ".norm1", B1, N, N, 0, C));
+        CK(self_attention(r, lnb, N, N, N, C, d, t + ".attn1", "st.sa", &att1));
         float* y = nxt(x);
-        CK(r.gemm(att, C, t + ".attn1.o.w", M, y, C, GL_OUT_F32_ROWMAJOR, t + ".attn1.o.b", GL_EPI_RES, x, C, 1));
+        CK(r.gemm(att1, C, t + ".attn1.o.w", M1, y, C, GL_OUT_F32_ROWMAJOR, t + ".attn1.o.b", GL_EPI_RES, x, C, 1));
         x = y;
+        if (share_half) {
+            // the uncond half: identical up to here (same latent, t, weights; attention.py:395 is the last op before the conditioning enters)
+            CK(r.dup_rows(x, (size_t)M1 * C * 4));
+            CK(r.dup_rows(xin.f, (size_t)M1 * C * 4));
+            if (xin.h) CK(r.dup_rows(xin.h, (size_t)M1 * C * 2));
+        }
     }
+    half_t* att = nullptr;
     // --- gated self-attention fuser over [x ; objs] (attention.py:226-234); exact identity at scale 0
     if (fuser_on) {
         const std::string f = t + ".fuser";
@@ -718,9 +745,14 @@ int spatial_transformer(Run& r, const LayerD& l, int li, Stream2 xin, int side, 
                   C, nullptr, 0, 0, precise);
 }
 
-int launch_forward(gl_engine* e, int reps, bool fuser_on, bool sd_conv, hipStream_t st, int* n_launches) {
+int launch_forward(gl_engine* e, int reps, bool fuser_on, bool sd_conv, bool uniform_t, hipStream_t st, int* n_launches) {
     const gl_unet_config& cfg = e->cfg;
     const int Bn = e->Bn, mc = cfg.model_channels;
+    // [cond ; uncond] batch over ONE set of latents and one timestep: the two halves are identical until the first op that reads the
+    // conditioning (fuser / rela_fuse / attn2 of the first transformer block) -- run that prefix once on Bn / 2 samples
+    const bool share = g_share != 0 && reps == 2 && uniform_t && (Bn % 2) == 0 && e->input_blocks.size() > 1 &&
+                       !e->input_blocks[1].layers.empty() && e->input_blocks[1].layers[0].kind == RES;
+    const int B0 = share ? Bn / 2 : Bn;
     int side = e->hw;
     Run r{e, st, e->buf("splitk.ws", WS_BYTES)};
     CKP(r.ws);
@@ -743,7 +775,7 @@ int launch_forward(gl_engine* e, int reps, bool fuser_on, bool sd_conv, hipStrea
     half_t* xin = e->h16("in.x", (size_t)Bn * side * side * CIN_PAD);
     CKP(xin);
     ++r.launches;
-    CK(gl_pack_latent(x_lat, Bn / reps, cfg.in_channels, side * side, CIN_PAD, reps, xin, st));
+    CK(gl_pack_latent(x_lat, Bn / reps, cfg.in_channels, side * side, CIN_PAD, share ? 1 : reps, xin, st));
     const std::string fc = sd_conv ? "sd_first_conv" : "input_blocks.0.0";
     // fp16 copies of stream tensors: only where a down / up conv consumes the tensor (precise mode: every GroupNorm and 1x1 conv
     // reads the fp32 stream), or everywhere in the round-3 fp16-copy mode
@@ -754,25 +786,40 @@ int launch_forward(gl_engine* e, int reps, bool fuser_on, bool sd_conv, hipStrea
     h.f = e->f32("skip.0.f32", (size_t)Bn * side * side * mc);
     h.h = wants_h(first_kind(e->input_blocks.size() > 1 ? &e->input_blocks[1] : nullptr)) ? e->h16("skip.0", (size_t)Bn * side * side * mc) : nullptr;
     CKP(h.f);
-    CK(r.conv(xin, fc + ".w", fc + ".b", Bn, side, side, CIN_PAD, 1, 0, h.f, GL_OUT_F32_ROWMAJOR, GL_EPI_BIAS, nullptr, 0, 0, nullptr, 0, 0, h.h));
+    CK(r.conv(xin, fc + ".w", fc + ".b", B0, side, side, CIN_PAD, 1, 0, h.f, GL_OUT_F32_ROWMAJOR, GL_EPI_BIAS, nullptr, 0, 0, nullptr, 0, 0, h.h));
+    if (share) {            // skip-stack entry 0 is consumed at full batch by the last output block
+        CK(r.dup_rows(h.f, (size_t)B0 * side * side * mc * 4));
+        if (h.h) CK(r.dup_rows(h.h, (size_t)B0 * side * side * mc * 2));
+    }
     struct Skip { Stream2 s; int side, c; };
     std::vector<Skip> skips{{h, side, mc}};
     int st_idx = 0;
     int h_c = mc;
 
-    auto run_block = [&](const BlockD& b, const std::string& bi, const Skip* skip, const BlockD* next) -> int {
+    auto run_block = [&](const BlockD& b, const std::string& bi, const Skip* skip, const BlockD* next, bool half_first = false) -> int {
         const Stream2* sk = skip ? &skip->s : nullptr;
         int sk_c = skip ? skip->c : 0;
+        bool half_pending = false;          // h holds only the first Bn / 2 samples (shared prefix)
         for (size_t j = 0; j < b.layers.size(); ++j) {
             const LayerD& l = b.layers[j];
             const std::string tag = bi + "." + std::to_string(j);
             const bool need_h = wants_h(j + 1 < b.layers.size() ? b.layers[j + 1].kind : first_kind(next));
             Stream2 o;
             if (l.kind == RES) {
-                CK(res_block(r, l, h, sk, sk_c, side, emb_out, tag, need_h, &o));
+                if (half_first && j == 0) {
+                    // the block's output tensors at FULL size first (the pool hands back the same buffers to the half-batch call below)
+                    CKP(e->f32(tag + ".f32", (size_t)Bn * side * side * l.cout));
+                    if (need_h) CKP(e->h16(tag, (size_t)Bn * side * side * l.cout));
+                    BnScope half(e, B0);
+                    CK(res_block(r, l, h, sk, sk_c, side, emb_out, tag, need_h, &o));
+                    half_pending = true;
+                } else {
+                    CK(res_block(r, l, h, sk, sk_c, side, emb_out, tag, need_h, &o));
+                }
                 sk = nullptr; sk_c = 0;
             } else if (l.kind == ST) {
-                CK(spatial_transformer(r, l, st_idx++, h, side, fuser_on, tag, need_h, &o));
+                CK(spatial_transformer(r, l, st_idx++, h, side, fuser_on, tag, need_h, &o, half_pending));
+                half_pending = false;       // the transformer duplicated its input and its own stream after attn1
             } else if (l.kind == DOWN) {
                 const int so = side / 2;
                 o.f = e->f32(tag + ".f32", (size_t)Bn * so * so * l.cout);
@@ -796,12 +843,18 @@ int launch_forward(gl_engine* e, int reps, bool fuser_on, bool sd_conv, hipStrea
             }
             h = o;
             h_c = l.cout;
+            if (half_pending && !(j + 1 < b.layers.size() && b.layers[j + 1].kind == ST)) {
+                CK(r.dup_rows(h.f, (size_t)B0 * side * side * h_c * 4));
+                if (h.h) CK(r.dup_rows(h.h, (size_t)B0 * side * side * h_c * 2));
+                half_pending = false;
+            }
         }
         return 0;
     };
 
     for (size_t i = 1; i < e->input_blocks.size(); ++i) {
-        CK(run_block(e->input_blocks[i], "skip." + std::to_string(i), nullptr, i + 1 < e->input_blocks.size() ? &e->input_blocks[i + 1] : &e->middle));
+        CK(run_block(e->input_blocks[i], "skip." + std::to_string(i), nullptr, i + 1 < e->input_blocks.size() ? &e->input_blocks[i + 1] : &e->middle,
+                     share && i == 1));
         skips.push_back({h, side, h_c});
     }
     CK(run_block(e->middle, "mid", nullptr, e->output_blocks.empty() ? nullptr : &e->output_blocks[0]));
@@ -1002,18 +1055,19 @@ extern "C" int gl_unet_forward(gl_engine* e, const float* x, const float* t_dev,
         e->opt_epoch = g_gl_option_epoch;
         e->ovr_epoch = e->ovr.epoch;
     }
-    const auto key = std::make_tuple(Bn, side, e->R, e->Lc, (int)fuser_on, (int)(sd_conv != 0), (int)reps);
+    const bool uniform_t = t_dev == nullptr;
+    const auto key = std::make_tuple(Bn, side, e->R, e->Lc, (int)fuser_on, (int)(sd_conv != 0), (int)reps + (uniform_t ? 16 : 0));
     auto it = e->graphs.find(key);
     if (use_graph && it == e->graphs.end()) {
         // warm-up run allocates every pooled buffer, then the same launch sequence is captured
-        CK(launch_forward(e, reps, fuser_on, sd_conv != 0, st, &e->launches));
+        CK(launch_forward(e, reps, fuser_on, sd_conv != 0, uniform_t, st, &e->launches));
         if (hipStreamSynchronize(st) != hipSuccess) return GL_ERR_BAD_ARG;
         if (e->pool_changed) { e->drop_graphs(); e->pool_changed = false; }
         hipGraph_t graph = nullptr;
         if (e->cap_stream == nullptr && hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking) != hipSuccess) return GL_ERR_UNSUPPORTED;
         if (hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return GL_ERR_UNSUPPORTED;
         e->capturing = true;
-        const int rc = launch_forward(e, reps, fuser_on, sd_conv != 0, e->cap_stream, nullptr);
+        const int rc = launch_forward(e, reps, fuser_on, sd_conv != 0, uniform_t, e->cap_stream, nullptr);
         e->capturing = false;
         const hipError_t ec = hipStreamEndCapture(e->cap_stream, &graph);
         if (rc != 0 || ec != hipSuccess || graph == nullptr) {
@@ -1029,7 +1083,7 @@ extern "C" int gl_unet_forward(gl_engine* e, const float* x, const float* t_dev,
     if (use_graph) {
         if (hipGraphLaunch(it->second, st) != hipSuccess) return GL_ERR_UNSUPPORTED;
     } else {
-        CK(launch_forward(e, reps, fuser_on, sd_conv != 0, st, &e->launches));
+        CK(launch_forward(e, reps, fuser_on, sd_conv != 0, uniform_t, st, &e->launches));
         if (e->pool_changed) { e->drop_graphs(); e->pool_changed = false; }
     }
     if (eps != eps_i && hipMemcpyAsync(eps, eps_i, ne * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return GL_ERR_BAD_ARG;

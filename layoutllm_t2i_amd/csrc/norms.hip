@@ -492,13 +492,12 @@ __global__ __launch_bounds__(NT) void gn_bundle_kernel(const void* __restrict__ 
 // input row so that a consumer can re-evaluate the normalisation in fp32 (rela_merge).
 // Optional second source (fp16 rows x2, rows2 per sample): sample b's output rows are [rows_in rows of x | rows2 rows of x2],
 // i.e. the [x ; objs] concatenation of GatedSelfAttentionDense (attention.py:230) is normalised in ONE launch.
-template <bool XF32, int NV>
+template <bool XF32, int NV, bool YF32 = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__ xv, int ldx, half_t* __restrict__ y,
                                                         int ldy, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int nrows, int rows_in,
                                                         int rows_out, int row_off, int C, float eps,
-                                                        float* __restrict__ stats, const half_t* __restrict__ x2, int ldx2, int rows2,
-                                                        int y_f32) {
+                                                        float* __restrict__ stats, const half_t* __restrict__ x2, int ldx2, int rows2) {
     const int lane = threadIdx.x & 63;
     const int orow = blockIdx.x * 4 + (threadIdx.x >> 6);        // index over B * (rows_in + rows2)
     if (orow >= nrows) return;
@@ -567,19 +566,20 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
             const float4 b1 = *reinterpret_cast<const float4*>(beta + vec * 8 + 4);
             const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
             const float bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-            if (y_f32) {          // wave-uniform: fp32 rows (an encoder's last_hidden_state leaves the library unrounded)
+            if constexpr (YF32) {     // fp32 rows (an encoder's last_hidden_state leaves the library unrounded); a separate instantiation, so
+                                      // that the fp16 form below compiles exactly as before (rela_merge_ln_kernel must round identically)
                 float* yf = reinterpret_cast<float*>(y) + ((size_t)bidx * rows_out + row_off + i_in) * ldy + vec * 8;
                 float o[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = fmaf((v[i][j] - mean) * rstd, g[j], bt[j]);
                 *reinterpret_cast<float4*>(yf) = make_float4(o[0], o[1], o[2], o[3]);
                 *reinterpret_cast<float4*>(yf + 4) = make_float4(o[4], o[5], o[6], o[7]);
-                continue;
-            }
-            half8_t ov;
+            } else {
+                half8_t ov;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) ov[j] = (half_t)fmaf((v[i][j] - mean) * rstd, g[j], bt[j]);   // explicit: rela_merge_ln_kernel rounds identically
-            st16(yr + vec * 8, *reinterpret_cast<uint4*>(&ov));
+                for (int j = 0; j < 8; ++j) ov[j] = (half_t)fmaf((v[i][j] - mean) * rstd, g[j], bt[j]);   // explicit: rela_merge_ln_kernel rounds identically
+                st16(yr + vec * 8, *reinterpret_cast<uint4*>(&ov));
+            }
         }
     }
 }
@@ -753,13 +753,18 @@ extern "C" int gl_layernorm(const void* x, int32_t ldx, int32_t x_f32, void* y, 
     const dim3 grid(gl_cdiv(nrows, 4)), blk(256);
     const int y_f32 = (x_f32 >> 1) & 1;
     x_f32 &= 1;
-#define GL_LN(F, V) layernorm_kernel<F, V><<<grid, blk, 0, st>>>(x, ldx, yp, ldy, gamma, beta, nrows, rows_in, rows_out, row_off, C, eps, stats, x2p, ldx2, rows2, y_f32)
-    if (x_f32) {
+#define GL_LN(F, V) layernorm_kernel<F, V><<<grid, blk, 0, st>>>(x, ldx, yp, ldy, gamma, beta, nrows, rows_in, rows_out, row_off, C, eps, stats, x2p, ldx2, rows2)
+#define GL_LNF(V) layernorm_kernel<true, V, true><<<grid, blk, 0, st>>>(x, ldx, yp, ldy, gamma, beta, nrows, rows_in, rows_out, row_off, C, eps, stats, x2p, ldx2, rows2)
+    if (y_f32) {
+        if (!x_f32) return GL_ERR_UNSUPPORTED;            // fp32 rows out of an fp32 stream only
+        if (nv == 1) GL_LNF(1); else if (nv == 2) GL_LNF(2); else if (nv == 3) GL_LNF(3); else GL_LNF(4);
+    } else if (x_f32) {
         if (nv == 1) GL_LN(true, 1); else if (nv == 2) GL_LN(true, 2); else if (nv == 3) GL_LN(true, 3); else GL_LN(true, 4);
     } else {
         if (nv == 1) GL_LN(false, 1); else if (nv == 2) GL_LN(false, 2); else if (nv == 3) GL_LN(false, 3); else GL_LN(false, 4);
     }
 #undef GL_LN
+#undef GL_LNF
     GL_CHECK_LAUNCH();
     return 0;
 }

@@ -60,6 +60,7 @@ class PyRefEngine:
         # the engine's precision mode (gl_set_option keys 41 / 42, both on by default): split-fp16 1x1 convs + GroupNorm on the fp32
         # stream, and the ResBlock's first conv writing fp32
         self.precise, self.h1_f32 = True, True
+        self.share_prefix = True              # gl_set_option 44
         # constant gates of rela_fuse, per-step gates of the fuser (scale * tanh(alpha))
         for l in self.st_layers:
             t = l.prefix + ".transformer_blocks.0"
@@ -178,8 +179,9 @@ class PyRefEngine:
         """fp32 residual-stream tensor + (where a down / up conv consumes it, or in the fp16-copy mode) its fp16 copy"""
         return self.buf(tag + ".f32", (M, C), F32), (self.buf(tag, (M, C)) if need_h else None)
 
-    def _res_block(self, l: Layer, h, skip, Bn, side, emb_out, out_tag, need_h=True):
-        """h = (fp32, fp16) stream pair; skip = (fp32, fp16) pair popped from the skip stack or None."""
+    def _res_block(self, l: Layer, h, skip, Bn, side, emb_out, out_tag, need_h=True, out=None):
+        """h = (fp32, fp16) stream pair; skip = (fp32, fp16) pair popped from the skip stack or None; out = (fp32, fp16 or None)
+        row views to write into (the half-batch shared prefix writes the first half of full-size tensors)."""
         W, p = self.W, l.prefix
         HW = side * side
         h32, h16 = h
@@ -207,13 +209,13 @@ class PyRefEngine:
         else:
             assert skip is None
             sk = h32
-        o32, o16 = self._stream(out_tag, Bn * HW, l.cout, need_h)
+        o32, o16 = out if out is not None else self._stream(out_tag, Bn * HW, l.cout, need_h)
         ops.conv3x3(t2, W[p + ".out_layers.3.w"], o32, Bn, side, side, W[p + ".out_layers.3.b"], epi=EPI_RES, res=sk, out16=o16)
         return o32, o16
 
-    def _self_attention(self, src, rows_per_b, Nq, Nk, C, d, wp, tagp):
+    def _self_attention(self, src, rows_per_b, Nq, Nk, C, d, wp, tagp, Bn=None):
         """src [Bn*rows_per_b, C] (already normalised) -> attention output [Bn*Nq, C] (before to_out)."""
-        Bn, H = self.cond["Bn"], self.cfg.num_heads
+        Bn, H = (self.cond["Bn"] if Bn is None else Bn), self.cfg.num_heads
         vt = self.buf(tagp + ".vt", (Bn, H, d, ops.vt_ld(max(Nk, rows_per_b))))
         if C % 32 == 0:      # same rule as engine.hip: V^T straight from the QKV GEMM epilogue (that form never splits K)
             qkv = ops.gemm(src, self.W[wp + ".qkv.w"], self.buf(tagp + ".qkv", (Bn * rows_per_b, 3 * C)), vt=vt, vt_col0=2 * C, vt_rows=rows_per_b)
@@ -234,8 +236,9 @@ class PyRefEngine:
             return ops.gemm(hg, W[p + ".ff2.w"], out, W[p + ".ff2.b"], EPI_RES, res=res, hilo_out=hilo_out)
         return ops.gemm(hg, W[p + ".ff2.w"], out, W[p + ".ff2.b"], EPI_GATE_RES, res=res, gate=gate)
 
-    def _spatial_transformer(self, l: Layer, li: int, x_in, Bn, side, fuser_on, out_tag, need_h=True):
-        """x_in = (fp32, fp16) stream pair.  Inside the block x lives in fp32 only (two ping-pong buffers)."""
+    def _spatial_transformer(self, l: Layer, li: int, x_in, Bn, side, fuser_on, out_tag, need_h=True, share_half=False):
+        """x_in = (fp32, fp16) stream pair.  Inside the block x lives in fp32 only (two ping-pong buffers).  share_half: x_in holds only
+        the first Bn / 2 samples (shared cond / uncond prefix): GroupNorm .. attn1 run on those, then x_in and x are duplicated."""
         W, c, cfg = self.W, self.cond, self.cfg
         p = l.prefix
         t = p + ".transformer_blocks.0"
@@ -245,17 +248,26 @@ class PyRefEngine:
         mo, R, Lc = c["mo"], c["R"], c["Lc"]
         xin32, xin16 = x_in
         xa, xb = self.buf("st.xa", (M, C), F32), self.buf("st.xb", (M, C), F32)
+        B1 = Bn // 2 if share_half else Bn
+        M1 = B1 * N
+        xa1, xb1 = xa[:M1], xb[:M1]
         if self.precise:     # Normalize on the fp32 stream, [hi | lo] rows, both halves against proj_in's weight
-            g0 = self._groupnorm(xin32, None, Bn, N, p + ".norm", 1e-6, False, "st.gn", hilo=True)
-            x = ops.gemm(g0, W[p + ".proj_in.w"], xa, W[p + ".proj_in.b"], hilo_a=True)
+            g0 = self._groupnorm(xin32[:M1], None, B1, N, p + ".norm", 1e-6, False, "st.gn", hilo=True)
+            x = ops.gemm(g0, W[p + ".proj_in.w"], xa1, W[p + ".proj_in.b"], hilo_a=True)
         else:
-            g0 = self._groupnorm(xin16, None, Bn, N, p + ".norm", 1e-6, False, "st.gn")
-            x = ops.gemm(g0, W[p + ".proj_in.w"], xa, W[p + ".proj_in.b"])
-        nxt = lambda cur: xb if cur is xa else xa
+            g0 = self._groupnorm(xin16[:M1], None, B1, N, p + ".norm", 1e-6, False, "st.gn")
+            x = ops.gemm(g0, W[p + ".proj_in.w"], xa1, W[p + ".proj_in.b"])
         # --- attn1 (attention.py:395)
-        n1 = ops.layernorm(x, self.buf("st.ln", (M, C)), W[t + ".norm1.g"], W[t + ".norm1.b"], Bn, N)
-        att = self._self_attention(n1, N, N, N, C, d, t + ".attn1", "st.sa")
-        x = ops.gemm(att, W[t + ".attn1.o.w"], nxt(x), W[t + ".attn1.o.b"], EPI_RES, res=x)
+        n1 = ops.layernorm(x, self.buf("st.ln", (M1, C)), W[t + ".norm1.g"], W[t + ".norm1.b"], B1, N)
+        att = self._self_attention(n1, N, N, N, C, d, t + ".attn1", "st.sa", Bn=B1)
+        x = ops.gemm(att, W[t + ".attn1.o.w"], xb1, W[t + ".attn1.o.b"], EPI_RES, res=x)
+        if share_half:
+            xb[M1:].copy_(xb[:M1])
+            xin32[M1:].copy_(xin32[:M1])
+            if xin16 is not None:
+                xin16[M1:].copy_(xin16[:M1])
+        x = xb
+        nxt = lambda cur: xb if cur is xa else xa
         # --- gated self-attention fuser over [x ; objs] (attention.py:226-234); exact identity at scale 0
         if fuser_on:
             f = t + ".fuser"
@@ -305,9 +317,13 @@ class PyRefEngine:
 
     # ------------------------------------------------------------------ one forward (eager launch sequence)
     def _launch_forward(self, x_lat: torch.Tensor, t_buf: torch.Tensor, reps: int, fuser_on: bool, sd_conv: bool,
-                        eps_out: torch.Tensor) -> None:
+                        eps_out: torch.Tensor, uniform_t: bool = False) -> None:
         W, cfg, c = self.W, self.cfg, self.cond
         Bn, side = c["Bn"], c["hw"]
+        ib0 = self.plan.input_blocks
+        # same rule as engine.hip (gl_set_option 44): the [cond ; uncond] halves share everything before the first conditioning-dependent op
+        share = self.share_prefix and reps == 2 and uniform_t and Bn % 2 == 0 and len(ib0) > 1 and bool(ib0[1].layers) and ib0[1].layers[0].kind == "res"
+        B0 = Bn // 2 if share else Bn
         mc = cfg.model_channels
         st_index = {l.prefix: i for i, l in enumerate(self.st_layers)}
         # time embedding (openaimodel.py:428-429) and all 22 emb_layers in one GEMM (:172-178, :220)
@@ -316,26 +332,44 @@ class PyRefEngine:
         e2 = ops.gemm(e1, W["time_embed.2.w"], self.buf("te.e2", (Bn, 4 * mc)), W["time_embed.2.b"], EPI_SILU)
         emb_out = ops.gemm(e2, W["emb_all.w"], self.buf("te.out", (Bn, self.P.emb_total)), W["emb_all.b"])
         # first conv on the zero-padded NHWC latent (openaimodel.py:299, :393-405)
-        xin = ops.pack_latent(x_lat, CIN_PAD, reps, self.buf("in.x", (Bn * side * side, CIN_PAD)))
+        xin = ops.pack_latent(x_lat, CIN_PAD, 1 if share else reps, self.buf("in.x", (B0 * side * side, CIN_PAD)))
         fc = "sd_first_conv" if sd_conv else "input_blocks.0.0"
         M0 = Bn * side * side
+        Mh = B0 * side * side
         # fp16 copies of stream tensors only where a down / up conv reads them (same rule as engine.hip)
         first_kind = lambda blk: blk.layers[0].kind if blk is not None and blk.layers else None
         wants_h = lambda kind: (not self.precise) or kind in ("down", "up")
         ib = self.plan.input_blocks
         h = self._stream("skip.0", M0, mc, wants_h(first_kind(ib[1] if len(ib) > 1 else None)))
-        ops.conv3x3(xin, W[fc + ".w"], h[0], Bn, side, side, W[fc + ".b"], out16=h[1])
+        ops.conv3x3(xin, W[fc + ".w"], h[0][:Mh], B0, side, side, W[fc + ".b"], out16=None if h[1] is None else h[1][:Mh])
+
+        def dup(pair, rows):
+            for t_ in pair:
+                if t_ is not None:
+                    t_[rows:].copy_(t_[:rows])
+        if share:
+            dup(h, Mh)
         skips: List[Tuple[Tuple[torch.Tensor, torch.Tensor], int]] = [(h, side)]
 
-        def run_block(b: Block, h, side, bi: str, skip=None, nxt_block=None):
+        def run_block(b: Block, h, side, bi: str, skip=None, nxt_block=None, half_first=False):
+            half_pending = False
             for j, l in enumerate(b.layers):
                 tag = f"{bi}.{j}"
                 need_h = wants_h(b.layers[j + 1].kind if j + 1 < len(b.layers) else first_kind(nxt_block))
                 if l.kind == "res":
-                    h = self._res_block(l, h, skip, Bn, side, emb_out, tag, need_h)
+                    if half_first and j == 0:
+                        rows = B0 * side * side
+                        full = self._stream(tag, Bn * side * side, l.cout, need_h)
+                        hv = (h[0][:rows], None if h[1] is None else h[1][:rows])
+                        self._res_block(l, hv, skip, B0, side, emb_out, tag, need_h, out=(full[0][:rows], None if full[1] is None else full[1][:rows]))
+                        h = full
+                        half_pending = True
+                    else:
+                        h = self._res_block(l, h, skip, Bn, side, emb_out, tag, need_h)
                     skip = None
                 elif l.kind == "st":
-                    h = self._spatial_transformer(l, st_index[l.prefix], h, Bn, side, fuser_on, tag, need_h)
+                    h = self._spatial_transformer(l, st_index[l.prefix], h, Bn, side, fuser_on, tag, need_h, share_half=half_pending)
+                    half_pending = False
                 elif l.kind == "down":
                     o = self._stream(tag, Bn * (side // 2) ** 2, l.cout, need_h)
                     ops.conv3x3(h[1], W[l.prefix + ".w"], o[0], Bn, side, side, W[l.prefix + ".b"], stride=2, out16=o[1])
@@ -346,11 +380,14 @@ class PyRefEngine:
                     ops.conv3x3(h[1], W[l.prefix + ".w"], o[0], Bn, side, side, W[l.prefix + ".b"], upsample2x=True, out16=o[1])
                     h = o
                     side *= 2
+                if half_pending and not (j + 1 < len(b.layers) and b.layers[j + 1].kind == "st"):
+                    dup(h, B0 * side * side)
+                    half_pending = False
             return h, side
 
         ob = self.plan.output_blocks
         for i, b in enumerate(ib[1:], start=1):
-            h, side = run_block(b, h, side, f"skip.{i}", nxt_block=ib[i + 1] if i + 1 < len(ib) else self.plan.middle)
+            h, side = run_block(b, h, side, f"skip.{i}", nxt_block=ib[i + 1] if i + 1 < len(ib) else self.plan.middle, half_first=share and i == 1)
             skips.append((h, side))
         h, side = run_block(self.plan.middle, h, side, "mid", nxt_block=ob[0] if ob else None)
         for i, b in enumerate(ob):
@@ -386,18 +423,20 @@ class PyRefEngine:
         x_static = self.buf("in.xlat", tuple(x_lat.shape), F32)
         if x_lat.data_ptr() != x_static.data_ptr():
             x_static.copy_(x_lat)
+        uniform_t = not torch.is_tensor(t)
         if not self.use_graphs:
-            self._launch_forward(x_static, t_buf, reps, fuser_on, sd_conv, eps_out)
+            self._launch_forward(x_static, t_buf, reps, fuser_on, sd_conv, eps_out, uniform_t)
             return eps_out
-        key = (Bn, side, c["R"], c["Lc"], c["mo"], fuser_on, sd_conv, reps, eps_out.data_ptr(), tuple(x_lat.shape), self.precise, self.h1_f32)
+        key = (Bn, side, c["R"], c["Lc"], c["mo"], fuser_on, sd_conv, reps, eps_out.data_ptr(), tuple(x_lat.shape), self.precise, self.h1_f32,
+               self.share_prefix, uniform_t)
         g = self._graphs.get(key)
         if g is None:
             # warm-up run allocates every pooled buffer, then capture the same launch sequence
-            self._launch_forward(x_static, t_buf, reps, fuser_on, sd_conv, eps_out)
+            self._launch_forward(x_static, t_buf, reps, fuser_on, sd_conv, eps_out, uniform_t)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                self._launch_forward(x_static, t_buf, reps, fuser_on, sd_conv, eps_out)
+                self._launch_forward(x_static, t_buf, reps, fuser_on, sd_conv, eps_out, uniform_t)
             self._graphs[key] = g
         g.replay()
         return eps_out

@@ -299,3 +299,38 @@ def test_precision_modes_match_python_sequence_and_precise_is_closer_to_the_orac
     print("[precision modes] rel-L2 vs fp32 oracle (fp16-rounded weights):", {k: f"{v:.3e}" for k, v in errs.items()})
     assert errs["precise"] < errs["precise_h1_fp16"] < errs["fp16_copies"], errs
     assert errs["precise"] < 0.75 * errs["fp16_copies"], errs
+
+
+def test_shared_cond_uncond_prefix_matches_python_sequence_and_the_unshared_forward():
+    """gl_set_option 44 (default on): a reps = 2 forward computes conv_in, the first ResBlock and proj_in .. attn1 of the first
+    transformer ONCE on the shared latents.  Bitwise equal to the Python launch sequence doing the same; within fp32-summation-order
+    rounding of the forward that computes both halves (other tile / split-K choices at half the rows); per-sample timesteps (a device
+    tensor) and reps = 1 take the unshared path."""
+    eng, ref = engines(TINY)
+    B, hw = 2, 16
+    inp = {k: T(v) for k, v in recipe.synth_inputs(TINY, B, hw, n_boxes=4, n_rel=3, seed=21).items()}
+    z = torch.zeros_like
+    cat = lambda p, q: torch.cat([p, q], 0)
+    for e in (eng, ref):
+        e.set_conditioning(cat(inp["context"], inp["uc"]), cat(inp["relations"], inp["relations"]), cat(inp["boxes"], z(inp["boxes"])),
+                           cat(inp["masks"], z(inp["masks"])), cat(inp["positive_embeddings"], z(inp["positive_embeddings"])), hw)
+    x = inp["x"].to(DEV)
+    n_shared = None
+    for fs, sdc in ((1.0, False), (0.0, True)):
+        a = eng.forward(x, 481.0, fs, sdc, 2).clone()
+        assert same(a, ref.forward(x, 481.0, fs, sdc, 2).clone()), fs
+        n_shared = eng.num_launches()
+        ops.set_option(44, 0)
+        try:
+            ref.share_prefix = False
+            b = eng.forward(x, 481.0, fs, sdc, 2).clone()
+            assert same(b, ref.forward(x, 481.0, fs, sdc, 2).clone()), fs
+        finally:
+            ops.set_option(44, 1)
+            ref.share_prefix = True
+        r = float((a - b).norm() / b.norm())
+        assert r < 1e-3 and not torch.equal(a[:B], a[B:]), r           # cond != uncond after the shared prefix
+    # a per-sample timestep tensor: not shared (the halves may differ in t)
+    tt = torch.tensor([481.0, 481.0, 481.0, 481.0])
+    c = eng.forward(x, tt, 0.0, True, 2).clone()
+    assert same(c, ref.forward(x, tt, 0.0, True, 2).clone()) and float((c - b).norm() / b.norm()) < 1e-6
