@@ -82,6 +82,7 @@ def parse():
     ap.add_argument("--latent", type=int, default=0, help="override: latent side (64 = 512x512, 96 = 768x768)")
     ap.add_argument("--plms-steps", type=int, default=50)
     ap.add_argument("--boxes", type=int, default=0, help="override: grounding boxes per image")
+    ap.add_argument("--no-cpu-config1", action="store_true", help="skip the end-to-end config-1 CPU run (22 oracle forwards, ~90 s)")
     ap.add_argument("--cpu-config1", action="store_true",
                     help="also run BASELINE configs[0] end to end on the CPU oracle (S=10, 22 forwards, ~2 min)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -315,7 +316,7 @@ def main():
     achieved = flops / (gpu_ms * 1e-3) / 1e12 if gpu_ms > 0 else float("nan")
     # HBM traffic per forward launch: measured in separate rocprofv3 --pmc passes (profiles/r1_traffic.json)
     traffic = None
-    tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_traffic.json") for r in (3, 2, 1)) if os.path.exists(q)), None)
+    tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_traffic.json") for r in (4, 3, 2, 1)) if os.path.exists(q)), None)
     if tpath and side == 64 and not args.tiny and B == 4:
         traffic = round(json.load(open(tpath))["traffic_bytes_per_forward"])
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -351,6 +352,14 @@ def main():
                                   "avg_us": round(k_us, 1), "flops": k_flops, "achieved": round(k_tf, 1), "unit": "TFLOP/s",
                                   "frac": round(k_tf / MFMA_PEAK_TFLOPS, 4), "launches_per_forward": 7}
         del xa, wa, oa
+        # per kernel CLASS of one fuser-off forward: every distinct shape x its multiplicity timed standalone with HIP events IN THIS RUN
+        # (tools/kbench.class_summary): fraction of the dense-fp16 MFMA peak for the 3x3 convs, the plain GEMMs and attention
+        if B == 4:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import kbench as _kb
+            roofline["classes"] = _kb.class_summary(iters=6, peak_tflops=MFMA_PEAK_TFLOPS)
+            roofline["classes_note"] = ("standalone op-level launches of every conv / plain-GEMM / attention shape of one fuser-off 2B=8 forward "
+                                        "(multiplicity-weighted), HIP events on the launch stream, measured in this run")
 
     images = args.steps * B * world
     value = images / elapsed
@@ -456,7 +465,8 @@ def main():
                       f"{ {k: round(v, 2) for k, v in kinds.items()} } s; extrapolated to {n_on} on + {n_off} off step-evaluations x 2 passes "
                       f"per image; the oracle executes the fuser at scale 0 like the reference does; VAE decode not included",
             "seconds_per_forward": round(sum(kinds.values()) / 4, 2)}
-        if args.cpu_config1:
+        if not args.no_cpu_config1 and not args.tiny and args.config in (0, 2):
+            # (default since round 4: the CPU number is then not only an extrapolation)
             # BASELINE.json configs[0] / BASELINE.md section 4: txt2img plumbing case, B=1, 64x64, S=10 -> 22 forwards, fp32, end to end
             c1 = {k: torch.from_numpy(v) for k, v in recipe.synth_inputs(cfg, 1, 64, n_boxes=2, n_rel=3, seed=1234).items()}
 

@@ -48,7 +48,8 @@ if "attn" in which:
         vt = torch.empty(B2, 8, d, ops.vt_ld(N), dtype=torch.float16, device=DEV)
         ops.transpose_v(v, N * C, C, vt, B2, 8, d, N)
         o = torch.empty(B2, N, C, dtype=torch.float16, device=DEV)
-        jobs.append(lambda q=q, k=k, vt=vt, o=o, d=d, N=N, C=C: ops.attention(q, N * C, C, k, N * C, C, vt, o, N * C, C, B2, 8, d, N, N, d ** -0.5))
+        jobs.append(lambda q=q, k=k, vt=vt, o=o, d=d, N=N, C=C: ops.attention(q, N * C, C, k, N * C, C, vt, o, N * C, C, B2, 8, d, N, N, d ** -0.5,
+                                                                                q_prescaled=bool(int(os.environ.get("PROBE_PRE", "1")))))   # the engine's form
 for j in jobs:
     for _ in range(REP):
         j()

@@ -99,6 +99,57 @@ def collect():
     return gemms, convs, attns, gns, lns
 
 
+def class_summary(iters=8, peak_tflops=2500.0):
+    """Per kernel CLASS of one fuser-off UNet forward (every distinct conv / plain-GEMM / attention shape x its multiplicity): FLOPs,
+    standalone op-level time (HIP events on the current stream, fp16 outputs) and the fraction of the dense-fp16 MFMA peak -- what
+    bench.py reports as ``roofline.classes``, measured in the run itself."""
+    init_device()
+    gemms, convs, attns, _, _ = collect()
+    h = lambda *s: torch.randn(*s, device=DEV).to(torch.float16)
+    out = {}
+    fl_c = t_c = 0.0
+    for (side, cin, cout, stride, up), n in convs.items():
+        x, w = h(B2 * side * side, cin), h(cout, 9 * cin) * ((9 * cin) ** -0.5)
+        ho = side * 2 if up else side // stride
+        o = torch.empty(B2 * ho * ho, cout, dtype=torch.float16, device=DEV)
+        bias = torch.zeros(cout, device=DEV)
+        t_c += n * timeit(lambda: ops.conv3x3(x, w, o, B2, side, side, bias, stride=stride, upsample2x=bool(up)), iters)
+        fl_c += n * 2.0 * B2 * ho * ho * cout * 9 * cin
+    fl_g = t_g = 0.0
+    for key, n in gemms.items():
+        if len(key) > 4:
+            continue                                    # fuser-only shapes
+        M, N, K, epi = key[:4]
+        a, w, bias = h(M, K), h(N, K) * (K ** -0.5), torch.zeros(N, device=DEV)
+        if epi == "geglu":
+            o = torch.empty(M, N // 2, dtype=torch.float16, device=DEV)
+            fn = lambda: ops.gemm(a, w, o, bias, EPI_GEGLU)
+        elif epi == "res":
+            o, r = torch.empty(M, N, dtype=torch.float32, device=DEV), torch.randn(M, N, device=DEV)
+            fn = lambda: ops.gemm(a, w, o, bias, EPI_RES, res=r)      # the engine's form: fp32 residual stream in and out
+        else:
+            o = torch.empty(M, N, dtype=torch.float16, device=DEV)
+            fn = lambda: ops.gemm(a, w, o, bias)
+        t_g += n * timeit(fn, iters)
+        fl_g += n * 2.0 * M * N * K
+    fl_a = t_a = 0.0
+    for key, n in attns.items():
+        if len(key) > 3:
+            continue
+        d, Nq, Nk = key[:3]
+        H, C = 8, 8 * d
+        q, k, v = h(B2, Nq, C), h(B2, Nk, C), h(B2, Nk, C)
+        vt = torch.empty(B2, H, d, ops.vt_ld(Nk), dtype=torch.float16, device=DEV)
+        ops.transpose_v(v, Nk * C, C, vt, B2, H, d, Nk)
+        o = torch.empty(B2, Nq, C, dtype=torch.float16, device=DEV)
+        t_a += n * timeit(lambda: ops.attention(q, Nq * C, C, k, Nk * C, C, vt, o, Nq * C, C, B2, H, d, Nq, Nk, d ** -0.5, q_prescaled=True), iters)
+        fl_a += n * 4.0 * B2 * H * Nq * Nk * d
+    for name, fl, t in (("conv3x3", fl_c, t_c), ("plain_gemm", fl_g, t_g), ("attention", fl_a, t_a)):
+        out[name] = {"tflop_per_forward": round(fl / 1e12, 3), "ms_per_forward": round(t * 1e3, 3), "achieved_tflops": round(fl / t / 1e12, 1),
+                     "frac": round(fl / t / 1e12 / peak_tflops, 4)}
+    return out
+
+
 def main():
     which = set(sys.argv[1:]) or {"gemm", "conv", "attn", "norm"}
     init_device()
