@@ -28,7 +28,7 @@ def c64(lo, hi):
 
 
 def case():
-    k = rng.choice(["gemm", "gemm", "skinny", "res32", "conv", "attn", "attn_pre", "gn", "gn1", "ln", "ff", "qkv", "merge_ln"])
+    k = rng.choice(["gemm", "gemm", "skinny", "res32", "conv", "attn", "attn_pre", "gn", "gn1", "gn32", "hilo_a", "hilo_out", "ln", "ff", "qkv", "merge_ln"])
     if k == "gemm":
         return T.test_gemm_bias, (rng.randint(1, 3000), 8 * rng.randint(1, 200), c64(64, 1536))
     if k == "skinny":
@@ -60,6 +60,18 @@ def case():
             if C1 + C2 <= 2560 and _lib.lib().gl_groupnorm_launches(C1 + C2, HW) == 1:
                 return T.test_groupnorm_single_launch_form_matches_two_launch_form, (C1, C2, HW)
         return None
+    if k == "gn32":
+        # round 4: fp32 inputs (the residual stream), [hi | lo] output and the raw [hi | lo] split of the input, every launch form
+        C1 = 32 * rng.choice([2, 8, 10, 20, 30, 40, 60, 80])
+        C2 = rng.choice([0, 0, 320, 640])
+        if (C1 + C2) % 32 or C1 + C2 > 2560:
+            C2 = 0
+        return T.test_groupnorm_fp32_stream_hilo_and_raw_split, (C1, C2, rng.choice([16, 36, 64, 100, 144, 256, 576, 1024, 2304]), rng.random() < 0.5)
+    if k == "hilo_a":
+        # split-fp16 activations against one copy of W (kwrap): 4-wave, 8-wave, split-K and skinny dispatch
+        return T.test_gemm_split_fp16_activation, (rng.randint(1, 3000), 32 * rng.randint(1, 40), c64(64, 1536), rng.random() < 0.5)
+    if k == "hilo_out":
+        return T.test_gemm_hilo_output, (rng.randint(1, 2500), 8 * rng.randint(4, 170), c64(64, 2560))
     if k == "ln":
         return T.test_layernorm, (8 * rng.randint(1, 256),)
     if k == "ff":
