@@ -90,6 +90,8 @@ typedef struct gl_gemm_args {
      * [W | W] without storing W twice.  kwrap % 64 == 0, kwrap < K <= 2 * kwrap.  ldw == 0: the row stride is K (kwrap == 0)
      * or kwrap.  gl_gemm only (ignored by gl_conv3x3). */
     int32_t ldw, kwrap;
+    int32_t rowbias_f32;                /* != 0: rowbias is fp32 [B, N] (ld_rowbias in floats) instead of fp16: the ResBlock's emb_layers output is
+                                           added to the conv result unrounded (openaimodel.py:220-226) */
 } gl_gemm_args;
 
 /*
@@ -213,6 +215,10 @@ int gl_groupnorm_launches_ex(int32_t C, int32_t HW, int32_t x_f32);
 int gl_layernorm(const void* x, int32_t ldx, int32_t x_f32, void* y, int32_t ldy, const float* gamma, const float* beta,
                  int32_t B, int32_t rows_in, int32_t rows_out, int32_t row_off, int32_t C, float eps, float* stats,
                  const void* x2, int32_t ldx2, int32_t rows2, void* stream);
+/* x_f32 bit 2 (value 4): the second source x2 is fp32 (ldx2 in floats) -- the fuser's fuser.linear(objs) rows enter LayerNorm unrounded.
+ * gl_layernorm_stats: only the per-row (mean, rstd) of fp32 rows [rows, C] (the same two-pass arithmetic as gl_layernorm), for consumers that
+ * re-evaluate the normalisation themselves in fp32 (gl_rela_pool_ln3, gl_rela_merge): rela_fuse's LayerNorm3 output is then never stored. */
+int gl_layernorm_stats(const float* x, int32_t ldx, int32_t rows, int32_t C, float eps, float* stats, void* stream);
 
 /*
  * RelationCrossAttention (attention.py:315-359) in closed form:
@@ -232,6 +238,12 @@ int gl_layernorm(const void* x, int32_t ldx, int32_t x_f32, void* y, int32_t ldy
 int gl_rela_pool(const void* hid, int32_t B, int32_t H, int32_t W, int32_t C, const int32_t* rects,
                  const int32_t* nvalid, const int32_t* poison, int32_t max_objs, void* feat, const float* ln_gamma,
                  const float* ln_beta, void* ln_out, void* stream);
+/* gl_rela_pool_ln3 (round 4): gl_rela_pool on the fp32 stream: x fp32 [B, H*W, C] with the per-row (mean, rstd) of rela_fuse's LayerNorm3
+ * (gl_layernorm_stats) and its gamma / beta; the pooled row is gamma * mean_rect((x - mean_r) * rstd_r) + beta in fp32 -- hid = LN3(x)
+ * (attention.py:317) is neither rounded to fp16 nor stored. */
+int gl_rela_pool_ln3(const float* x, const float* ln3_stats, const float* ln3_gamma, const float* ln3_beta, int32_t B, int32_t H,
+                     int32_t W, int32_t C, const int32_t* rects, const int32_t* nvalid, const int32_t* poison, int32_t max_objs,
+                     void* feat, const float* ln_gamma, const float* ln_beta, void* ln_out, void* stream);
 int gl_rela_merge(const void* x, int32_t x_f32, const void* hid, const float* ln_stats, const float* gamma,
                   const float* beta, const void* f, int32_t B, int32_t H, int32_t W, int32_t C,
                   const int32_t* rects, const int32_t* nvalid, const int32_t* poison, int32_t max_objs,

@@ -43,6 +43,7 @@ class GemmArgs(C.Structure):
         ("out2", vp), ("ldc2", i32),
         ("vt", vp), ("vt_col0", i32), ("vt_rows", i32), ("vt_d", i32), ("vt_ld", i32), ("vt_H", i32),
         ("ldw", i32), ("kwrap", i32),
+        ("rowbias_f32", i32),
     ]
 
 
@@ -146,6 +147,8 @@ PROTOTYPES = {
     "gl_groupnorm_launches_ex": (i32, [i32, i32, i32]),
     "gl_sizeof_gn_args": (i32, []),
     "gl_layernorm": (i32, [vp, i32, i32, vp, i32, fp, fp, i32, i32, i32, i32, i32, f32, fp, vp, i32, i32, vp]),
+    "gl_layernorm_stats": (i32, [fp, i32, i32, i32, f32, fp, vp]),
+    "gl_rela_pool_ln3": (i32, [fp, fp, fp, fp, i32, i32, i32, i32, vp, vp, vp, i32, vp, fp, fp, vp, vp]),
     "gl_rela_pool": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, fp, fp, vp, vp]),
     "gl_rela_merge": (i32, [vp, i32, vp, fp, fp, fp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, fp, fp, vp, vp]),
     "gl_posnet_input": (i32, [fp, fp, fp, fp, fp, i32, i32, i32, vp, vp]),

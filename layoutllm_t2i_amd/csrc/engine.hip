@@ -413,16 +413,17 @@ struct Run {
         a.g.epi = epi; a.g.out_mode = out_mode; a.g.out = out; a.g.ldc = a.g.N; a.g.hw = nchw_hw;
         a.g.res = res; a.g.ldres = ldres; a.g.res_f32 = res_f32;
         a.g.rowbias = rowbias; a.g.ld_rowbias = ld_rowbias; a.g.rows_per_sample = rows_per_sample;
+        a.g.rowbias_f32 = rowbias != nullptr && g_precise != 0;      // precise mode: the emb_layers output stays fp32
         a.g.out2 = out2; a.g.ldc2 = a.g.N;
         a.g.workspace = ws; a.g.workspace_bytes = WS_BYTES;
         ++launches;
         return gl_conv3x3(&a, st);
     }
     int ln(const void* x, int ldx, int x_f32, half_t* y, int ldy, const std::string& p, int B, int rows_in, int rows_out, int row_off,
-           int C, float* stats = nullptr, const half_t* x2 = nullptr, int rows2 = 0) {
+           int C, float* stats = nullptr, const void* x2 = nullptr, int rows2 = 0, int x2_f32 = 0) {
         ++launches;
-        return gl_layernorm(x, ldx, x_f32, y, ldy, e->Wf(p + ".g"), e->Wf(p + ".b"), B, rows_in, rows_out, row_off, C, 1e-5f, stats, x2, C, rows2,
-                            st);
+        return gl_layernorm(x, ldx, x_f32 | (x2_f32 ? 4 : 0), y, ldy, e->Wf(p + ".g"), e->Wf(p + ".b"), B, rows_in, rows_out, row_off, C, 1e-5f, stats,
+                            x2, C, rows2, st);
     }
     // x_f32: the sources are fp32 stream tensors; out_lo / raw: the split-fp16 side outputs of gl_groupnorm_ex
     int gn(const void* x1, int C1, const void* x2, int C2, int x_f32, int B, int HW, const std::string& p, float eps, int silu, half_t* out,
@@ -557,7 +558,7 @@ int feed_forward(Run& r, const half_t* xn, const float* res, const std::string& 
 
 // ResBlock._forward (openaimodel.py:211-231); skip = the popped skip-stack tensor of an output block (th.cat folded in).
 // need_h: the output also gets an fp16 copy (its consumer is a down / up conv, or the round-3 fp16-copy mode is on).
-int res_block(Run& r, const LayerD& l, Stream2 h, const Stream2* skip, int skip_c, int side, const half_t* emb_out, const std::string& tag,
+int res_block(Run& r, const LayerD& l, Stream2 h, const Stream2* skip, int skip_c, int side, const void* emb_out, const std::string& tag,
               bool need_h, Stream2* out) {
     gl_engine* e = r.e;
     const int Bn = e->Bn, HW = side * side, M = Bn * HW;
@@ -581,7 +582,9 @@ int res_block(Run& r, const LayerD& l, Stream2 h, const Stream2* skip, int skip_
     void* h1 = h1f ? (void*)e->f32("rb.h1f", (size_t)M * l.cout) : (void*)e->h16("rb.h1", (size_t)M * l.cout);
     CKP(h1);
     CK(r.conv(t, p + ".in_layers.2.w", p + ".in_layers.2.b", Bn, side, side, l.cin, 1, 0, h1, h1f ? GL_OUT_F32_ROWMAJOR : GL_OUT_F16_ROWMAJOR,
-              GL_EPI_ROWBIAS, nullptr, 0, 0, emb_out + off, e->emb_total, HW));
+              GL_EPI_ROWBIAS, nullptr, 0, 0,
+              precise ? (const void*)(reinterpret_cast<const float*>(emb_out) + off) : (const void*)(reinterpret_cast<const half_t*>(emb_out) + off),
+              e->emb_total, HW));
     CK(r.gn(h1, l.cout, nullptr, 0, h1f ? 1 : 0, Bn, HW, p + ".out_layers.0", 1e-5f, 1, t2));
     const float* sk = h.f;
     if (has_skip_conv) {
@@ -664,7 +667,11 @@ int spatial_transformer(Run& r, const LayerD& l, int li, Stream2 xin, int side, 
         const int rows = N + ((mo + 7) & ~7);
         half_t* cat = e->h16("st.cat", (size_t)Bn * rows * C);
         CKP(cat);
-        CK(r.ln(x, C, 1, cat, C, f + ".norm1", Bn, N, rows, 0, C, nullptr, e->h16("hoist.objs." + sl, (size_t)Bn * mo * C), mo));
+        if (precise) {
+            CK(r.ln(x, C, 1, cat, C, f + ".norm1", Bn, N, rows, 0, C, nullptr, e->f32("hoist.objs32." + sl, (size_t)Bn * mo * C), mo, 1));
+        } else {
+            CK(r.ln(x, C, 1, cat, C, f + ".norm1", Bn, N, rows, 0, C, nullptr, e->h16("hoist.objs." + sl, (size_t)Bn * mo * C), mo));
+        }
         CK(self_attention(r, cat, rows, N, N + mo, C, d, f + ".attn", "st.fa", &att));
         float* y = nxt(x);
         CK(r.gemm(att, C, f + ".attn.o.w", M, y, C, GL_OUT_F32_ROWMAJOR, f + ".attn.o.b", GL_EPI_GATE_RES, x, C, 1, gates + 0));
@@ -693,9 +700,17 @@ int spatial_transformer(Run& r, const LayerD& l, int li, Stream2 xin, int side, 
         half_t* hg = e->h16("rl.ffh", (size_t)Mo * 4 * C);
         half_t* f2 = e->h16("rl.f2", (size_t)Mo * C);
         CKP(rects); CKP(nvalid); CKP(poison); CKP(stats); CKP(hid); CKP(feat); CKP(fn); CKP(q); CKP(ar); CKP(f1); CKP(hg); CKP(f2);
-        CK(r.ln(x, C, 1, hid, C, rf + ".norm3", Bn, N, N, 0, C, stats));
-        ++r.launches;
-        CK(gl_rela_pool(hid, Bn, side, side, C, rects, nvalid, poison, mo, feat, e->Wf(rf + ".norm1.g"), e->Wf(rf + ".norm1.b"), fn, r.st));
+        if (precise) {
+            // LayerNorm3 is never materialised: its per-row statistics, then the box means of LN3(x) and (in rela_merge) LN3(x) itself in fp32
+            r.launches += 2;
+            CK(gl_layernorm_stats(x, C, M, C, 1e-5f, stats, r.st));
+            CK(gl_rela_pool_ln3(x, stats, e->Wf(rf + ".norm3.g"), e->Wf(rf + ".norm3.b"), Bn, side, side, C, rects, nvalid, poison, mo, feat,
+                                e->Wf(rf + ".norm1.g"), e->Wf(rf + ".norm1.b"), fn, r.st));
+        } else {
+            CK(r.ln(x, C, 1, hid, C, rf + ".norm3", Bn, N, N, 0, C, stats));
+            ++r.launches;
+            CK(gl_rela_pool(hid, Bn, side, side, C, rects, nvalid, poison, mo, feat, e->Wf(rf + ".norm1.g"), e->Wf(rf + ".norm1.b"), fn, r.st));
+        }
         CK(r.gemm(fn, C, rf + ".attn.q.w", Mo, q, C));
         const half_t* kv = e->h16("hoist.kvrel." + sl, (size_t)Bn * R * 2 * C);
         const int ldvt = vt_ld(R);
@@ -764,13 +779,14 @@ int launch_forward(gl_engine* e, int reps, bool fuser_on, bool sd_conv, bool uni
     half_t* te = e->h16("te.sin", (size_t)Bn * mc);
     half_t* e1 = e->h16("te.e1", (size_t)Bn * 4 * mc);
     half_t* e2 = e->h16("te.e2", (size_t)Bn * 4 * mc);
-    half_t* emb_out = e->h16("te.out", (size_t)Bn * e->emb_total);
+    // (precise mode: the 22 emb_layers outputs stay fp32 -- they are added to every element of a ResBlock's first conv result)
+    void* emb_out = g_precise ? (void*)e->f32("te.out32", (size_t)Bn * e->emb_total) : (void*)e->h16("te.out", (size_t)Bn * e->emb_total);
     CKP(te); CKP(e1); CKP(e2); CKP(emb_out);
     ++r.launches;
     CK(gl_timestep_embedding(t_buf, Bn, mc, te, st));
     CK(r.gemm(te, mc, "time_embed.0.w", Bn, e1, 4 * mc, GL_OUT_F16_ROWMAJOR, "time_embed.0.b", GL_EPI_SILU));
     CK(r.gemm(e1, 4 * mc, "time_embed.2.w", Bn, e2, 4 * mc, GL_OUT_F16_ROWMAJOR, "time_embed.2.b", GL_EPI_SILU));
-    CK(r.gemm(e2, 4 * mc, "emb_all.w", Bn, emb_out, e->emb_total, GL_OUT_F16_ROWMAJOR, "emb_all.b"));
+    CK(r.gemm(e2, 4 * mc, "emb_all.w", Bn, emb_out, e->emb_total, g_precise ? GL_OUT_F32_ROWMAJOR : GL_OUT_F16_ROWMAJOR, "emb_all.b"));
     // first conv on the zero-padded NHWC latent (openaimodel.py:299, :393-405)
     half_t* xin = e->h16("in.x", (size_t)Bn * side * side * CIN_PAD);
     CKP(xin);
@@ -982,9 +998,12 @@ extern "C" int gl_set_conditioning(gl_engine* e, const float* context, const flo
         const std::string sl = std::to_string(li);
         const int C = l.cin, d = l.d_head;
         // fuser.linear(objs) (attention.py:228)
+        // (both forms are kept hoisted: fp32 rows for the precise mode's LayerNorm over [x ; objs], fp16 rows for the fp16-copy mode)
         half_t* o = e->h16("hoist.objs." + sl, (size_t)Bn * mo * C);
-        CKP(o);
+        float* o32 = e->f32("hoist.objs32." + sl, (size_t)Bn * mo * C);
+        CKP(o); CKP(o32);
         CK(r.gemm(objs, cfg.pos_out_dim, t + ".fuser.linear.w", Bn * mo, o, C, GL_OUT_F16_ROWMAJOR, t + ".fuser.linear.b"));
+        CK(r.gemm(objs, cfg.pos_out_dim, t + ".fuser.linear.w", Bn * mo, o32, C, GL_OUT_F32_ROWMAJOR, t + ".fuser.linear.b"));
         // attn2 K/V of the text context (attention.py:124-125)
         half_t* kv = e->h16("hoist.kvctx." + sl, (size_t)Bn * Lc * 2 * C);
         const int ldc_ = vt_ld(Lc);

@@ -56,10 +56,17 @@ __device__ __forceinline__ void fin8_load(const gl_gemm_args& p, int m, int n, F
         }
     } else if (epi == GL_EPI_ROWBIAS) {
         const int sidx = m / p.rows_per_sample;
-        uint4 raw = ld16(reinterpret_cast<const half_t*>(p.rowbias) + (size_t)sidx * p.ld_rowbias + n);
-        const half8_t rv = *reinterpret_cast<half8_t*>(&raw);
+        if (p.rowbias_f32) {
+            const float* rp = reinterpret_cast<const float*>(p.rowbias) + (size_t)sidx * p.ld_rowbias + n;
+            const float4 r0 = *reinterpret_cast<const float4*>(rp);
+            const float4 r1 = *reinterpret_cast<const float4*>(rp + 4);
+            a.r[0] = r0.x; a.r[1] = r0.y; a.r[2] = r0.z; a.r[3] = r0.w; a.r[4] = r1.x; a.r[5] = r1.y; a.r[6] = r1.z; a.r[7] = r1.w;
+        } else {
+            uint4 raw = ld16(reinterpret_cast<const half_t*>(p.rowbias) + (size_t)sidx * p.ld_rowbias + n);
+            const half8_t rv = *reinterpret_cast<half8_t*>(&raw);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) a.r[j] = (float)rv[j];
+            for (int j = 0; j < 8; ++j) a.r[j] = (float)rv[j];
+        }
     }
 }
 

@@ -492,7 +492,7 @@ __global__ __launch_bounds__(NT) void gn_bundle_kernel(const void* __restrict__ 
 // input row so that a consumer can re-evaluate the normalisation in fp32 (rela_merge).
 // Optional second source (fp16 rows x2, rows2 per sample): sample b's output rows are [rows_in rows of x | rows2 rows of x2],
 // i.e. the [x ; objs] concatenation of GatedSelfAttentionDense (attention.py:230) is normalised in ONE launch.
-template <bool XF32, int NV, bool YF32 = false>
+template <bool XF32, int NV, bool YF32 = false, bool X2F32 = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__ xv, int ldx, half_t* __restrict__ y,
                                                         int ldy, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int nrows, int rows_in,
@@ -515,10 +515,18 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
         for (int j = 0; j < 8; ++j) v[i][j] = 0.0f;
         if (vec < nvec) {
             if (second) {
-                uint4 raw = ld16(x2 + (size_t)row * ldx2 + vec * 8);
-                const half8_t hv = *reinterpret_cast<half8_t*>(&raw);
+                if constexpr (X2F32) {     // fp32 second source (its own instantiation: the fp16 form compiles unchanged)
+                    const float* xr = reinterpret_cast<const float*>(x2) + (size_t)row * ldx2 + vec * 8;
+                    const float4 a = *reinterpret_cast<const float4*>(xr);
+                    const float4 c = *reinterpret_cast<const float4*>(xr + 4);
+                    v[i][0] = a.x; v[i][1] = a.y; v[i][2] = a.z; v[i][3] = a.w;
+                    v[i][4] = c.x; v[i][5] = c.y; v[i][6] = c.z; v[i][7] = c.w;
+                } else {
+                    uint4 raw = ld16(x2 + (size_t)row * ldx2 + vec * 8);
+                    const half8_t hv = *reinterpret_cast<half8_t*>(&raw);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[i][j] = (float)hv[j];
+                    for (int j = 0; j < 8; ++j) v[i][j] = (float)hv[j];
+                }
             } else if constexpr (XF32) {
                 const float* xr = reinterpret_cast<const float*>(xv) + (size_t)row * ldx + vec * 8;
                 const float4 a = *reinterpret_cast<const float4*>(xr);
@@ -581,6 +589,52 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
                 st16(yr + vec * 8, *reinterpret_cast<uint4*>(&ov));
             }
         }
+    }
+}
+
+// per-row (mean, rstd) only, of fp32 rows: the statistics half of layernorm_kernel<true, NV> (same loads, same two-pass sums, same
+// wave reductions -> the same bits), for consumers that re-evaluate the normalisation in fp32 themselves (rela_pool_ln3, rela_merge)
+template <int NV>
+__global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ x, int ldx, int nrows, int C, float eps, float* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const int nvec = C / 8;
+    float v[NV][8];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int vec = lane + 64 * i;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[i][j] = 0.0f;
+        if (vec < nvec) {
+            const float* xr = x + (size_t)row * ldx + vec * 8;
+            const float4 a = *reinterpret_cast<const float4*>(xr);
+            const float4 c = *reinterpret_cast<const float4*>(xr + 4);
+            v[i][0] = a.x; v[i][1] = a.y; v[i][2] = a.z; v[i][3] = a.w;
+            v[i][4] = c.x; v[i][5] = c.y; v[i][6] = c.z; v[i][7] = c.w;
+        }
+    }
+    float a = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a += v[i][j];
+    const float mean = wave_sum(a) / (float)C;
+    float ss = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if (lane + 64 * i < nvec) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float dlt = v[i][j] - mean;
+                ss = fmaf(dlt, dlt, ss);
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)C + eps);
+    if (lane == 0) {
+        stats[(size_t)row * 2] = mean;
+        stats[(size_t)row * 2 + 1] = rstd;
     }
 }
 
@@ -751,11 +805,15 @@ extern "C" int gl_layernorm(const void* x, int32_t ldx, int32_t x_f32, void* y, 
     hipStream_t st = (hipStream_t)stream;
     const int nv = gl_cdiv(C / 8, 64);
     const dim3 grid(gl_cdiv(nrows, 4)), blk(256);
-    const int y_f32 = (x_f32 >> 1) & 1;
+    const int y_f32 = (x_f32 >> 1) & 1, x2_f32 = (x_f32 >> 2) & 1;
     x_f32 &= 1;
 #define GL_LN(F, V) layernorm_kernel<F, V><<<grid, blk, 0, st>>>(x, ldx, yp, ldy, gamma, beta, nrows, rows_in, rows_out, row_off, C, eps, stats, x2p, ldx2, rows2)
 #define GL_LNF(V) layernorm_kernel<true, V, true><<<grid, blk, 0, st>>>(x, ldx, yp, ldy, gamma, beta, nrows, rows_in, rows_out, row_off, C, eps, stats, x2p, ldx2, rows2)
-    if (y_f32) {
+#define GL_LN2(V) layernorm_kernel<true, V, false, true><<<grid, blk, 0, st>>>(x, ldx, yp, ldy, gamma, beta, nrows, rows_in, rows_out, row_off, C, eps, stats, x2p, ldx2, rows2)
+    if (x2_f32 && x2 != nullptr) {
+        if (!x_f32 || y_f32 || (ldx2 % 4) != 0) return GL_ERR_UNSUPPORTED;   // fp32 [x ; x2] rows -> fp16 (the fuser's LayerNorm)
+        if (nv == 1) GL_LN2(1); else if (nv == 2) GL_LN2(2); else if (nv == 3) GL_LN2(3); else GL_LN2(4);
+    } else if (y_f32) {
         if (!x_f32) return GL_ERR_UNSUPPORTED;            // fp32 rows out of an fp32 stream only
         if (nv == 1) GL_LNF(1); else if (nv == 2) GL_LNF(2); else if (nv == 3) GL_LNF(3); else GL_LNF(4);
     } else if (x_f32) {
@@ -765,6 +823,20 @@ extern "C" int gl_layernorm(const void* x, int32_t ldx, int32_t x_f32, void* y, 
     }
 #undef GL_LN
 #undef GL_LNF
+#undef GL_LN2
+    GL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gl_layernorm_stats(const float* x, int32_t ldx, int32_t rows, int32_t C, float eps, float* stats, void* stream) {
+    if (!x || !stats || rows <= 0 || C <= 0 || (C % 8) || C > 2048 || (ldx % 4)) return GL_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int nv = gl_cdiv(C / 8, 64);
+    const dim3 grid(gl_cdiv(rows, 4)), blk(256);
+    if (nv == 1) ln_stats_kernel<1><<<grid, blk, 0, st>>>(x, ldx, rows, C, eps, stats);
+    else if (nv == 2) ln_stats_kernel<2><<<grid, blk, 0, st>>>(x, ldx, rows, C, eps, stats);
+    else if (nv == 3) ln_stats_kernel<3><<<grid, blk, 0, st>>>(x, ldx, rows, C, eps, stats);
+    else ln_stats_kernel<4><<<grid, blk, 0, st>>>(x, ldx, rows, C, eps, stats);
     GL_CHECK_LAUNCH();
     return 0;
 }

@@ -20,7 +20,13 @@ constexpr int RP_NT = 1024;          // rela_pool block size
 // grid (max_objs, B), block RP_NT: thread -> (pixel plane, 8-channel vector).  Only the used slots of the conditional samples
 // have work (32 blocks at B = 4 with 8 boxes), each over a rectangle of up to H*W pixels: 1024 threads per block keep 4x the
 // loads in flight per box (21.6 -> ~9 us at 64x64x320)
-__global__ __launch_bounds__(RP_NT) void rela_pool_kernel(const half_t* __restrict__ hid, int H, int W, int C,
+// LN3 (round 4): the source is the fp32 stream x itself with the per-row (mean, rstd) of LayerNorm3 (gl_layernorm_stats); the pooled mean of
+// hid = LN3(x) over a rectangle is then gamma * mean_rect((x - mean_r) * rstd_r) + beta, evaluated in fp32 -- hid is never rounded to fp16
+// (nor stored at all).
+template <bool LN3>
+__global__ __launch_bounds__(RP_NT) void rela_pool_kernel(const half_t* __restrict__ hid, const float* __restrict__ x32,
+                                                        const float* __restrict__ ln3_stats, const float* __restrict__ ln3_g,
+                                                        const float* __restrict__ ln3_b, int H, int W, int C,
                                                         const int* __restrict__ rects, const int* __restrict__ nvalid,
                                                         const int* __restrict__ poison, int max_objs,
                                                         half_t* __restrict__ feat, const float* __restrict__ ln_g,
@@ -55,6 +61,37 @@ __global__ __launch_bounds__(RP_NT) void rela_pool_kernel(const half_t* __restri
 #pragma unroll
                 for (int j = 0; j < 8; ++j) s[j] = 0.0f;
                 int q = plane;
+                if constexpr (LN3) {
+                    // 2 pixels x (two 16-byte loads + the row's statistics) in flight per thread
+                    for (; q + nplanes < npix; q += 2 * nplanes) {
+                        float4 xa[2], xb[2];
+                        float2 ms[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int qq = q + u * nplanes;
+                            const size_t row = ((size_t)b * H + top + qq / rw) * W + left + qq % rw;
+                            const float* xr = x32 + row * C + vec * 8;
+                            xa[u] = *reinterpret_cast<const float4*>(xr);
+                            xb[u] = *reinterpret_cast<const float4*>(xr + 4);
+                            ms[u] = *reinterpret_cast<const float2*>(ln3_stats + row * 2);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const float xv[8] = {xa[u].x, xa[u].y, xa[u].z, xa[u].w, xb[u].x, xb[u].y, xb[u].z, xb[u].w};
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) s[j] += (xv[j] - ms[u].x) * ms[u].y;
+                        }
+                    }
+                    for (; q < npix; q += nplanes) {
+                        const size_t row = ((size_t)b * H + top + q / rw) * W + left + q % rw;
+                        const float* xr = x32 + row * C + vec * 8;
+                        const float4 a4 = *reinterpret_cast<const float4*>(xr), b4 = *reinterpret_cast<const float4*>(xr + 4);
+                        const float2 m2 = *reinterpret_cast<const float2*>(ln3_stats + row * 2);
+                        const float xv[8] = {a4.x, a4.y, a4.z, a4.w, b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) s[j] += (xv[j] - m2.x) * m2.y;
+                    }
+                } else {
                 // 4 independent 16-byte loads in flight per thread (rectangles can span 2k+ pixels)
                 for (; q + 3 * nplanes < npix; q += 4 * nplanes) {
                     uint4 raw[4];
@@ -80,6 +117,7 @@ __global__ __launch_bounds__(RP_NT) void rela_pool_kernel(const half_t* __restri
 #pragma unroll
                     for (int j = 0; j < 8; ++j) s[j] += (float)hv[j];
                 }
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) lacc[plane * C + vec * 8 + j] = s[j];
             }
@@ -95,6 +133,7 @@ __global__ __launch_bounds__(RP_NT) void rela_pool_kernel(const half_t* __restri
             float s = 0.0f;
             for (int pl = 0; pl < nplanes; ++pl) s += lacc[pl * C + c];
             v = s * inv;
+            if constexpr (LN3) v = fmaf(v, ln3_g[c], ln3_b[c]);
         } else if (mode == 2) {
             v = __builtin_nanf("");
         }
@@ -304,9 +343,22 @@ extern "C" int gl_rela_pool(const void* hid, int32_t B, int32_t H, int32_t W, in
                             const float* ln_beta, void* ln_out, void* stream) {
     if (!hid || !rects || !nvalid || !poison || !feat || C <= 0 || (C % 8) || C > RELA_MAX_C) return GL_ERR_BAD_ARG;
     if (ln_out != nullptr && (!ln_gamma || !ln_beta)) return GL_ERR_BAD_ARG;
-    rela_pool_kernel<<<dim3(max_objs, B), dim3(RP_NT), 0, (hipStream_t)stream>>>(
-        reinterpret_cast<const half_t*>(hid), H, W, C, rects, nvalid, poison, max_objs, reinterpret_cast<half_t*>(feat), ln_gamma,
-        ln_beta, reinterpret_cast<half_t*>(ln_out));
+    rela_pool_kernel<false><<<dim3(max_objs, B), dim3(RP_NT), 0, (hipStream_t)stream>>>(
+        reinterpret_cast<const half_t*>(hid), nullptr, nullptr, nullptr, nullptr, H, W, C, rects, nvalid, poison, max_objs,
+        reinterpret_cast<half_t*>(feat), ln_gamma, ln_beta, reinterpret_cast<half_t*>(ln_out));
+    GL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gl_rela_pool_ln3(const float* x, const float* ln3_stats, const float* ln3_gamma, const float* ln3_beta, int32_t B, int32_t H,
+                                int32_t W, int32_t C, const int32_t* rects, const int32_t* nvalid, const int32_t* poison, int32_t max_objs,
+                                void* feat, const float* ln_gamma, const float* ln_beta, void* ln_out, void* stream) {
+    if (!x || !ln3_stats || !ln3_gamma || !ln3_beta || !rects || !nvalid || !poison || !feat || C <= 0 || (C % 8) || C > RELA_MAX_C)
+        return GL_ERR_BAD_ARG;
+    if (ln_out != nullptr && (!ln_gamma || !ln_beta)) return GL_ERR_BAD_ARG;
+    rela_pool_kernel<true><<<dim3(max_objs, B), dim3(RP_NT), 0, (hipStream_t)stream>>>(
+        nullptr, x, ln3_stats, ln3_gamma, ln3_beta, H, W, C, rects, nvalid, poison, max_objs, reinterpret_cast<half_t*>(feat), ln_gamma, ln_beta,
+        reinterpret_cast<half_t*>(ln_out));
     GL_CHECK_LAUNCH();
     return 0;
 }

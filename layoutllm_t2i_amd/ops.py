@@ -107,7 +107,8 @@ def _fill_epilogue(g: GemmArgs, epi, out, N_out, bias, res, gate, rowbias, rows_
         _req(gate, F32, "gate", 4)
         g.gate = gate.data_ptr()
     if rowbias is not None:
-        _req(rowbias, F16, "rowbias", 8)
+        g.rowbias_f32 = int(rowbias.dtype == F32)
+        _req(rowbias, F32 if g.rowbias_f32 else F16, "rowbias", 16 if g.rowbias_f32 else 8)
         g.rowbias, g.ld_rowbias, g.rows_per_sample = rowbias.data_ptr(), _rows(rowbias, "rowbias")[2], rows_per_sample
 
 
@@ -284,10 +285,12 @@ def layernorm(x: torch.Tensor, y: torch.Tensor, gamma: torch.Tensor, beta: torch
         if stats.numel() < 2 * B * rows_in:
             raise ValueError("stats buffer too small")
     ldx2 = 0
+    x2f32 = False
     if x2 is not None:
-        _req(x2, F16, "x2")
+        x2f32 = x2.dtype == F32
+        _req(x2, F32 if x2f32 else F16, "x2")
         ldx2 = _rows(x2, "x2")[2]
-    check(_lib.lib().gl_layernorm(x.data_ptr(), ldx, int(xf32) | (2 if yf32 else 0), y.data_ptr(), ldy, gamma.data_ptr(), beta.data_ptr(), B, rows_in,
+    check(_lib.lib().gl_layernorm(x.data_ptr(), ldx, int(xf32) | (2 if yf32 else 0) | (4 if x2f32 else 0), y.data_ptr(), ldy, gamma.data_ptr(), beta.data_ptr(), B, rows_in,
                                   rows_out, row_off, Cc, eps, _ptr(stats), _ptr(x2), ldx2, rows2, _stream()), "gl_layernorm")
     return y
 
@@ -304,6 +307,36 @@ def rela_pool(hid, B, H, W, Cc, rects, nvalid, poison, max_objs, feat, ln_gamma=
         _req(ln_beta, F32, "ln_beta")
     check(_lib.lib().gl_rela_pool(hid.data_ptr(), B, H, W, Cc, rects.data_ptr(), nvalid.data_ptr(), poison.data_ptr(),
                                   max_objs, feat.data_ptr(), _ptr(ln_gamma), _ptr(ln_beta), _ptr(ln_out), _stream()), "gl_rela_pool")
+    return feat
+
+
+def layernorm_stats(x: torch.Tensor, stats: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """per-row (mean, rstd) of fp32 rows [rows, C] -> stats fp32 [rows, 2] (gl_layernorm_stats: gl_layernorm's statistics alone)."""
+    _req(x, F32, "x")
+    _req(stats, F32, "stats", 8)
+    rows, Cc, ldx = _rows(x, "x")
+    if stats.numel() < 2 * rows:
+        raise ValueError("stats buffer too small")
+    check(_lib.lib().gl_layernorm_stats(x.data_ptr(), ldx, rows, Cc, eps, stats.data_ptr(), _stream()), "gl_layernorm_stats")
+    return stats
+
+
+def rela_pool_ln3(x, ln3_stats, ln3_gamma, ln3_beta, B, H, W, Cc, rects, nvalid, poison, max_objs, feat, ln_gamma=None, ln_beta=None, ln_out=None):
+    """rela_pool on the fp32 stream: feat[b, i] = mean over box i of LN3(x), LN3 re-evaluated in fp32 from ``ln3_stats`` (gl_rela_pool_ln3)."""
+    _req(x, F32, "x")
+    _req(ln3_stats, F32, "ln3_stats", 8)
+    _req(ln3_gamma, F32, "ln3_gamma")
+    _req(ln3_beta, F32, "ln3_beta")
+    _req(feat, F16, "feat")
+    for t, n in ((rects, "rects"), (nvalid, "nvalid"), (poison, "poison")):
+        _req(t, torch.int32, n, 4)
+    if ln_out is not None:
+        _req(ln_out, F16, "ln_out")
+        _req(ln_gamma, F32, "ln_gamma")
+        _req(ln_beta, F32, "ln_beta")
+    check(_lib.lib().gl_rela_pool_ln3(x.data_ptr(), ln3_stats.data_ptr(), ln3_gamma.data_ptr(), ln3_beta.data_ptr(), B, H, W, Cc, rects.data_ptr(),
+                                      nvalid.data_ptr(), poison.data_ptr(), max_objs, feat.data_ptr(), _ptr(ln_gamma), _ptr(ln_beta), _ptr(ln_out),
+                                      _stream()), "gl_rela_pool_ln3")
     return feat
 
 

@@ -115,6 +115,7 @@ class PyRefEngine:
             C, d = l.cin, l.d_head
             # fuser.linear(objs) (attention.py:228)
             c[f"objs.{li}"] = ops.gemm(objs, W[f"{t}.fuser.linear.w"], self.buf(f"hoist.objs.{li}", (Bn * mo, C)), W[f"{t}.fuser.linear.b"])
+            c[f"objs32.{li}"] = ops.gemm(objs, W[f"{t}.fuser.linear.w"], self.buf(f"hoist.objs32.{li}", (Bn * mo, C), F32), W[f"{t}.fuser.linear.b"])
             # attn2 K/V of the text context (attention.py:124-125)
             kv = ops.gemm(ctx16, W[f"{t}.attn2.kv.w"], self.buf(f"hoist.kvctx.{li}", (Bn * Lc, 2 * C)))
             vt = self.buf(f"hoist.vtctx.{li}", (Bn, H, d, ops.vt_ld(Lc)))
@@ -273,7 +274,7 @@ class PyRefEngine:
             f = t + ".fuser"
             rows = N + ((mo + 7) & ~7)          # same padding as engine.hip (pad rows are masked keys / unused queries)
             cat = self.buf("st.cat", (Bn * rows, C), zero=True)
-            ops.layernorm(x, cat, W[f + ".norm1.g"], W[f + ".norm1.b"], Bn, N, rows, 0, x2=c[f"objs.{li}"], rows2=mo)
+            ops.layernorm(x, cat, W[f + ".norm1.g"], W[f + ".norm1.b"], Bn, N, rows, 0, x2=c[f"objs32.{li}" if self.precise else f"objs.{li}"], rows2=mo)
             att = self._self_attention(cat, rows, N, N + mo, C, d, f + ".attn", "st.fa")
             x = ops.gemm(att, W[f + ".attn.o.w"], nxt(x), W[f + ".attn.o.b"], EPI_GATE_RES, res=x,
                          gate=self._gates[f + ".tanh_attn"])
@@ -283,11 +284,16 @@ class PyRefEngine:
         r = t + ".rela_fuse"
         rects, nvalid, poison = c[f"rects.{side}"], c[f"nvalid.{side}"], c[f"poison.{side}"]
         stats = self.buf("st.lnstats", (M, 2), F32)
-        hid = ops.layernorm(x, self.buf("st.hid", (M, C)), W[r + ".norm3.g"], W[r + ".norm3.b"], Bn, N, stats=stats)
         Mo = Bn * mo
         fn = self.buf("rl.ln", (Mo, C))
-        feat = ops.rela_pool(hid, Bn, side, side, C, rects, nvalid, poison, mo, self.buf("rl.feat", (Mo, C)),
-                             ln_gamma=W[r + ".norm1.g"], ln_beta=W[r + ".norm1.b"], ln_out=fn)
+        if self.precise:     # LayerNorm3 never materialised: statistics only, box means of LN3(x) in fp32 from the stream
+            ops.layernorm_stats(x, stats)
+            feat = ops.rela_pool_ln3(x, stats, W[r + ".norm3.g"], W[r + ".norm3.b"], Bn, side, side, C, rects, nvalid, poison, mo,
+                                     self.buf("rl.feat", (Mo, C)), ln_gamma=W[r + ".norm1.g"], ln_beta=W[r + ".norm1.b"], ln_out=fn)
+        else:
+            hid = ops.layernorm(x, self.buf("st.hid", (M, C)), W[r + ".norm3.g"], W[r + ".norm3.b"], Bn, N, stats=stats)
+            feat = ops.rela_pool(hid, Bn, side, side, C, rects, nvalid, poison, mo, self.buf("rl.feat", (Mo, C)),
+                                 ln_gamma=W[r + ".norm1.g"], ln_beta=W[r + ".norm1.b"], ln_out=fn)
         q = ops.gemm(fn, W[r + ".attn.q.w"], self.buf("rl.q", (Mo, C)))
         kv = c[f"kvrel.{li}"]
         ar = self.buf("rl.att", (Mo, C))
@@ -330,7 +336,8 @@ class PyRefEngine:
         te = ops.timestep_embedding(t_buf, mc, self.buf("te.sin", (Bn, mc)))
         e1 = ops.gemm(te, W["time_embed.0.w"], self.buf("te.e1", (Bn, 4 * mc)), W["time_embed.0.b"], EPI_SILU)
         e2 = ops.gemm(e1, W["time_embed.2.w"], self.buf("te.e2", (Bn, 4 * mc)), W["time_embed.2.b"], EPI_SILU)
-        emb_out = ops.gemm(e2, W["emb_all.w"], self.buf("te.out", (Bn, self.P.emb_total)), W["emb_all.b"])
+        emb_out = ops.gemm(e2, W["emb_all.w"], self.buf("te.out32" if self.precise else "te.out", (Bn, self.P.emb_total), F32 if self.precise else F16),
+                           W["emb_all.b"])
         # first conv on the zero-padded NHWC latent (openaimodel.py:299, :393-405)
         xin = ops.pack_latent(x_lat, CIN_PAD, 1 if share else reps, self.buf("in.x", (B0 * side * side, CIN_PAD)))
         fc = "sd_first_conv" if sd_conv else "input_blocks.0.0"

@@ -100,10 +100,10 @@ def oracle_one(sd, cfg, inp, k, cond, tval, fuser_scale=1.0, first_conv=None):
 
 
 # measured on MI355X (round 2): see DESIGN.md section 4; asserts are <= 1.5x these
-# measured on MI355X (round 4: split-fp16 1x1 convs + GroupNorm on the fp32 stream): rel-L2 6.66e-4 .. 7.49e-4, 26.8 .. 30.0 % outside over
-# all (batch, mode) cases and both 768px rows; round 3 (fp16 copies): 1.11e-3 .. 1.23e-3, 44 .. 48 %.  Bounds = 1.1x the worst case.
-BOUND_FULL = 8.3e-4
-FRAC_FULL = 0.33             # elements outside north_star's rtol 1e-3 / atol 1e-4
+# measured on MI355X (round 4: split-fp16 1x1 convs, GroupNorm on the fp32 stream, fp32 emb rows / fuser objs / LN3 pooling): rel-L2 6.54e-4 .. 7.34e-4,
+# 26.0 .. 28.9 % outside over all (batch, mode) cases and both 768px rows; round 3 (fp16 copies): 1.11e-3 .. 1.23e-3, 44 .. 48 %.  Bounds = 1.1x the worst case.
+BOUND_FULL = 8.1e-4
+FRAC_FULL = 0.32             # elements outside north_star's rtol 1e-3 / atol 1e-4
 
 
 @pytest.mark.parametrize("B", [4, 8, 16], ids=["configs1_2B8", "configs3_2B16", "configs4_2B32"])

@@ -869,6 +869,74 @@ def test_rela_pool_merge(C, hw):
     check(y, _rela_closed_form(x, hid, f.view(B, mo, C), rects, nvalid, poison, B, hw, hw, C, mo), f"rela_merge_{C}_{hw}")
 
 
+@pytest.mark.parametrize("C,hw", [(64, 8), (320, 32), (1280, 8), (640, 16)])
+def test_rela_pool_on_the_fp32_stream_and_layernorm_stats(C, hw):
+    """round 4: gl_layernorm_stats = the statistics gl_layernorm stores (bitwise), and gl_rela_pool_ln3 = box means of LN3(x) evaluated in
+    fp32 from the stream x and those statistics -- against torch fp32 (mean over the rectangle of layer_norm(x)) and against the fp16-hid
+    form it replaces (which differs by the rounding of hid it no longer has)."""
+    B, mo = 2, 30
+    boxes = np.zeros((B, mo, 4), np.float32)
+    masks = np.zeros((B, mo), np.float32)
+    boxes[0, :4] = [(0.0, 0.0, 0.5, 0.5), (0.25, 0.25, 1.0, 1.0), (0.6, 0.1, 0.9, 0.45), (0.13, 0.55, 0.41, 0.99)]
+    masks[0, :4] = 1
+    boxes[1, :2] = [(0.1, 0.2, 0.8, 0.9), (0.5, 0.5, 1.2, 1.3)]
+    masks[1, :2] = 1
+    rects, nvalid, poison = host.box_rects(boxes, masks, hw, hw)
+    dr, dn, dp = (torch.from_numpy(a).to(DEV) for a in (rects, nvalid, poison))
+    x = rnd(f"px{C}{hw}", (B * hw * hw, C)) * 1.7 + 0.4
+    g3, b3 = 1 + 0.1 * rnd(f"pg{C}", (C,)), 0.1 * rnd(f"pb{C}", (C,))
+    xd = x.to(DEV)
+    stats = torch.empty(B * hw * hw, 2, dtype=torch.float32, device=DEV)
+    ops.layernorm_stats(xd, stats)
+    stats_ln = torch.empty_like(stats)
+    hid = ops.layernorm(xd, torch.empty(B * hw * hw, C, dtype=torch.float16, device=DEV), g3.to(DEV), b3.to(DEV), B, hw * hw, stats=stats_ln)
+    assert torch.equal(stats, stats_ln)
+    feat = torch.full((B * mo + 1, C), 7.0, dtype=torch.float16, device=DEV)
+    g1, b1 = (1 + 0.1 * rnd(f"p1g{C}", (C,))).to(DEV), (0.1 * rnd(f"p1b{C}", (C,))).to(DEV)
+    fn = torch.empty(B * mo, C, dtype=torch.float16, device=DEV)
+    ops.rela_pool_ln3(xd, stats, g3.to(DEV), b3.to(DEV), B, hw, hw, C, dr, dn, dp, mo, feat[:B * mo], ln_gamma=g1, ln_beta=b1, ln_out=fn)
+    hv = F.layer_norm(x.double(), (C,), g3.double(), b3.double(), 1e-5).view(B, hw, hw, C)
+    ref = torch.zeros(B, mo, C, dtype=torch.float64)
+    for b in range(B):
+        for i in range(int(nvalid[b])):
+            t, bo, l, r = [int(v) for v in rects[b, i]]
+            ref[b, i] = hv[b, t:bo, l:r].reshape(-1, C).mean(0)
+    check(feat[:B * mo], ref.view(B * mo, C).float(), f"rela_pool_ln3_{C}_{hw}")
+    assert float((feat[B * mo:].float() - 7.0).abs().max()) == 0.0
+    old = torch.empty(B * mo, C, dtype=torch.float16, device=DEV)
+    ops.rela_pool(hid, B, hw, hw, C, dr, dn, dp, mo, old)
+    assert float((old.float() - feat[:B * mo].float()).abs().max()) < 4e-3
+    fn_sep = ops.layernorm(feat[:B * mo].contiguous(), torch.empty_like(fn), g1, b1, B, mo)        # fused norm1 of the pooled rows
+    assert float((fn.float() - fn_sep.float()).abs().max()) < 4e-3
+
+
+def test_layernorm_fp32_second_source_and_fp32_rowbias():
+    """round 4: the fuser's LayerNorm over [x ; objs] with objs in fp32 (gl_layernorm x_f32 bit 2), and GL_EPI_ROWBIAS with an fp32 row bias
+    (the emb_layers output): both against torch fp32 on the UNROUNDED second operand."""
+    B, rows, ro, C = 2, 70, 6, 320
+    x = rnd("l2x", (B * rows, C)) * 1.3 + 0.2
+    o = rnd("l2o", (B * ro, C)) * 2.0 - 0.3
+    gam, bet = 1 + 0.1 * rnd("l2g", (C,)), 0.1 * rnd("l2b", (C,))
+    y = torch.zeros(B * (rows + 8), C, dtype=torch.float16, device=DEV)
+    ops.layernorm(x.to(DEV), y, gam.to(DEV), bet.to(DEV), B, rows, rows + 8, 0, x2=o.to(DEV), rows2=ro)
+    cat = torch.cat([x.view(B, rows, C), o.view(B, ro, C)], 1)
+    ref = F.layer_norm(cat, (C,), gam, bet, 1e-5)
+    check(y.view(B, rows + 8, C)[:, :rows + ro], ref, "layernorm_x2_fp32")
+    y16 = torch.zeros_like(y)
+    ops.layernorm(x.to(DEV), y16, gam.to(DEV), bet.to(DEV), B, rows, rows + 8, 0, x2=o.half().to(DEV), rows2=ro)
+    assert torch.equal(y16.view(B, rows + 8, C)[:, :rows], y.view(B, rows + 8, C)[:, :rows])        # the x rows do not depend on the form of x2
+    # fp32 row bias through the conv epilogue
+    Bc, hw, Cin, Cout = 2, 8, 64, 128
+    xi, xid = h16(rnd("rb32x", (Bc * hw * hw, Cin)))
+    w = rnd("rb32w", (Cout, Cin, 3, 3), 1 / math.sqrt(9 * Cin)).half().float()
+    bias = rnd("rb32b", (Cout,), 0.1)
+    rb = rnd("rb32r", (Bc, Cout)) * 1.5
+    out = torch.empty(Bc * hw * hw, Cout, dtype=torch.float32, device=DEV)
+    ops.conv3x3(xid, pack_conv3x3(w).to(DEV), out, Bc, hw, hw, bias.to(DEV), epi=EPI_ROWBIAS, rowbias=rb.to(DEV), rows_per_sample=hw * hw)
+    refc = F.conv2d(xi.view(Bc, hw, hw, Cin).permute(0, 3, 1, 2), w, bias, padding=1) + rb[:, :, None, None]
+    check(out, refc.permute(0, 2, 3, 1).reshape(Bc * hw * hw, Cout), "conv_rowbias_fp32", rtol=2e-5, atol=2e-6)
+
+
 def test_rela_merge_fp32_stream_recomputes_ln():
     """x / y in fp32 and hid = LN3(x) re-evaluated in fp32 from gl_layernorm's (mean, rstd): the result must match the
     fp32 closed form to fp32 rounding -- no fp16 rounding of x, hid or y on the residual stream."""
