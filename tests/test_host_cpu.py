@@ -347,3 +347,41 @@ def test_relation_phrases_batched_equals_per_prompt():
         assert float(out[i, n:].abs().max() if n < 4 else 0.0) == 0.0
     assert float(out[1].abs().max()) == 0.0                       # no relation -> all-zero rows (interface.py:241-243)
     assert torch.equal(out[2, 0], out[2, 0]) and out[2, 3, 0] == out[2, 1, 0]   # PAD, r1, r2, r1 (truncated at 4)
+
+
+def test_text_encoder_state_dict_spellings_and_tokenize_conditioning_host_logic():
+    """SURVEY 8f-2 host side (no GPU): the three state-dict key spellings of a CLIP text tower normalise to ``text_model.*``; the
+    sharded entry's string half (tokenize_conditioning) turns prompts / relation phrases / grounding phrases into token rows and
+    index tables that reproduce the reference flow's structure: 'PAD' + every relation twice truncated to max_relations
+    (interface.py:226-243), boxes / masks padded to 30 slots (:460-475), one row per DISTINCT phrase."""
+    import torch
+    import stubs
+    from layoutllm_t2i_amd import interface as itf
+    from layoutllm_t2i_amd.text_encoder import HipCLIPTextEncoder, normalise_text_state_dict
+    sd = stubs.toy_text_tower_state_dict(0, hidden=64, heads=1, layers=1, inter=64, vocab=100, positions=16)
+    for spell in (lambda k: k, lambda k: "transformer." + k, lambda k: k[len("text_model."):]):
+        n = normalise_text_state_dict({spell(k): v for k, v in sd.items()})
+        assert set(n) == set(sd) and all(torch.equal(n[k], sd[k]) for k in sd)
+    assert HipCLIPTextEncoder.accepts({"transformer." + k: v for k, v in sd.items()}) and not HipCLIPTextEncoder.accepts({"dummy": torch.zeros(1)})
+    extra = dict(sd, **{"text_model.embeddings.position_ids": torch.arange(16)[None], "vision_model.x": torch.zeros(1), "text_projection.weight": torch.zeros(2, 2)})
+    assert set(normalise_text_state_dict(extra)) == set(sd)            # only the text tower's tensors, no position_ids buffer
+
+    class Enc:                                   # tokenizer side of HipCLIPTextEncoder only (no GPU here)
+        max_length, tokenizer = 77, stubs.ToyTokenizer()
+        tokenize = HipCLIPTextEncoder.tokenize
+    stubs.install_fake_sng_parser()
+    prompts = ["cat sitting on mat and dog under a tree", "a quiet empty street", "bird on wire"]
+    phrases = [["cat", "mat", "a big dog"], None, ["bird", "bird"]]
+    boxes = [[[0.1, 0.1, 0.5, 0.55], [0.05, 0.6, 0.95, 0.95], [0.55, 0.2, 0.9, 0.7]], [[0.0, 0.5, 1.0, 1.0]], [[0.1, 0.2, 0.3, 0.4], [0.6, 0.2, 0.8, 0.4]]]
+    tok = itf.tokenize_conditioning((None, None, Enc(), None, {"max_relations": 4}), prompts, phrases, boxes, stubs.ToyProcessor())
+    assert tok["cap_ids"].shape == (3, 77) and tok["uc_ids"].shape == (1, 77) and int(tok["uc_ids"][0, 0]) == 98 and int(tok["uc_ids"][0, 1]) == 99
+    # prompt 0 has two relations -> PAD, r1, r2, r1 (truncated to 4); prompts 1 and 2 one each -> PAD, r, r (the stub parser's rule)
+    assert tok["rel_owner"].tolist() == [0, 0, 0, 0, 1, 1, 1, 2, 2, 2] and tok["rel_slot"].tolist() == [0, 1, 2, 3, 0, 1, 2, 0, 1, 2]
+    assert tok["rel_ids"].shape == (10, 77) and torch.equal(tok["rel_ids"][0], tok["rel_ids"][4])         # both start with "PAD"
+    assert torch.equal(tok["rel_ids"][5], tok["rel_ids"][6]) and torch.equal(tok["rel_ids"][8], tok["rel_ids"][9])
+    assert torch.equal(tok["rel_ids"][1], tok["rel_ids"][3]) and not torch.equal(tok["rel_ids"][1], tok["rel_ids"][2])
+    assert tok["phrase_ids"].shape[0] == 4                                                                  # cat, mat, a big dog, bird
+    assert tok["phrase_index"][0, :4].tolist() == [0, 1, 2, -1] and tok["phrase_index"][1, :2].tolist() == [-1, -1]
+    assert tok["phrase_index"][2, :3].tolist() == [3, 3, -1]
+    assert tok["masks"].sum(-1).tolist() == [3.0, 1.0, 2.0] and torch.equal(tok["boxes"][2, 1], torch.tensor(boxes[2][1]))
+    assert tok["boxes"].shape == (3, 30, 4) and float(tok["boxes"][1, 1:].abs().max()) == 0.0
