@@ -11,6 +11,9 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+if os.environ.get("GL_PROBE_LIB"):          # A/B against another build of the library (a different process per build)
+    import layoutllm_t2i_amd._lib as _L
+    _L.LIB_PATH = os.environ["GL_PROBE_LIB"]
 from layoutllm_t2i_amd import ops, recipe
 from layoutllm_t2i_amd.arch import UNetConfig
 from layoutllm_t2i_amd.engine import UNetEngine
