@@ -32,9 +32,12 @@
 
 namespace {
 
-template <int BN>
+template <int BM_, int BN>
 struct G8 {
-    static constexpr int BM = 256;
+    static constexpr int BM = BM_;                     // 256, or 128 for grids that would otherwise leave CUs idle or split K (32x32 maps at 2B = 8)
+    static constexpr int NA = BM / 64;                 // A units (8 rows x 128 B, one LDS-DMA instruction) per wave and K-tile: 4 / 2
+    static constexpr int MI = BM / 64;                 // 16-row MFMA tiles per wave: 4 / 2
+    static constexpr int MH = BM / 128;                // 32-row epilogue passes per wave: 2 / 1
     static constexpr int BK = 64;
     static constexpr int PW = BN / 2;                  // output columns per wave (N half)
     static constexpr int TN = PW / 16;                 // 16-column MFMA tiles per wave: 5 / 4
@@ -46,9 +49,10 @@ struct G8 {
     static constexpr int B_UNITS = BN / 8;             // 1-KiB wave instructions per B tile: 20 / 16
     static constexpr int NB0 = (B_UNITS + 7) / 8;      // B instructions of a group-0 wave: 3 / 2
     static constexpr int NB1 = B_UNITS / 4 - NB0;      // ... of a group-1 wave: 2 / 2
-    static constexpr int NI0 = 4 + NB0;                // LDS-DMA instructions per K-tile, group-0 wave
-    static constexpr int NI1 = 4 + NB1;
-    static_assert(PW % 16 == 0 && B_UNITS % 4 == 0 && NB1 >= 1, "tile shape");
+    static constexpr int NI0 = NA + NB0;               // LDS-DMA instructions per K-tile, group-0 wave
+    static constexpr int NI1 = NA + NB1;
+    static_assert(PW % 16 == 0 && B_UNITS % 4 == 0 && NB1 >= 1 && (BM == 256 || BM == 128), "tile shape");
+    static_assert(NA + 1 >= 3, "the first phase issues three instructions (X_FIRST): two A units + one B unit at least");
     static_assert(STAGE % 128 == 0, "stage alignment (the k-half XOR of the fragment offsets relies on it)");
 };
 
@@ -74,9 +78,10 @@ __device__ __forceinline__ f32x4 mfma16(half8_t a, half8_t b, f32x4 c) {
 // cost of fetching operand bytes from the cost of issuing / landing LDS-DMA instructions)
 __device__ unsigned long long g8_stamps[4 * 4096];
 
-template <int BN, bool CONV, int DBG = 0>
+template <int BM, int BN, bool CONV, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom cg, int splitk, int kt_per_split, int order_flags) {
-    using C = G8<BN>;
+    using C = G8<BM, BN>;
+    constexpr int NA = C::NA, MI = C::MI, MH = C::MH;
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
     if constexpr (DBG & 1) ts0 = __builtin_readcyclecounter();
     constexpr int TN = C::TN, PW = C::PW;
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2;             // N half; also the stagger group (waves w and w + 4 share a SIMD)
-    const int wm = wave & 3;               // 64-row slice of the block tile
+    const int wm = wave & 3;               // (BM / 4)-row slice of the block tile
     const int M = p.M, N = p.N, K = p.K;
 
     // tile order: as gemm_conv.hip (XCD-contiguous runs of logical tiles, M-tiles fastest when the weights are the larger operand)
@@ -118,14 +123,15 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
     //      Group-of-32 index rho0 = 16 * wave + 8 * j over the 128 "first half" (or "second half") rows of the tile.
     const int srow = lane >> 3;            // row within the unit
     const int sslot = lane & 7;            // LDS chunk slot within the 128-byte row
-    int a_dst[4];                          // wave-uniform LDS byte offset of the unit inside a stage
-    const half_t* aptr[4];
+    int a_dst[NA];                         // wave-uniform LDS byte offset of the unit inside a stage
+    const half_t* aptr[NA];
     unsigned amask = 0u;
-    unsigned cmask[4];
+    unsigned cmask[NA];
     const int k_first = kt_begin * 64;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int trow0 = 64 * (wave >> 1) + 16 * (wave & 1) + 8 * (u & 1) + 32 * (u >> 1);
+    for (int u = 0; u < NA; ++u) {
+        // a wave pair stages 16 * NA consecutive rows
+        const int trow0 = (16 * NA) * (wave >> 1) + 16 * (wave & 1) + 8 * (u & 1) + 32 * (u >> 1);
         a_dst[u] = trow0 * 128;
         const int r = trow0 + srow;
         const int gc = (sslot ^ ((r >> 1) & 7)) << 3;
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
             if (A2g != nullptr && is_kt * 64 == p.ksplit && is_kt != kt_begin) {
                 // two-source A: crossing into the second matrix, once per block, before the first unit of that K-tile
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < NA; ++u) {
                     const int r = (a_dst[u] >> 7) + srow;
                     const int m = m0 + r;
                     if (m < M) aptr[u] = A2g + (size_t)m * p.lda2 + ((sslot ^ ((r >> 1) & 7)) << 3);
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
     // instruction itself goes out between the MFMAs of the following cluster.
     auto unit_src = [&](const int i) __attribute__((always_inline)) -> const half_t* {
         const half_t* src;
-        if (i < 4) {
+        if (i < NA) {
             const int u = i;
             if constexpr (CONV) {
                 // masked taps (the halo) read the zero page: branch-free 64-bit select (v_bfi), no exec games
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
             }
             if constexpr (DBG & 2) src = zsrc;
         } else {
-            const int j = i - 4;
+            const int j = i - NA;
             src = ((bmask >> (j < C::NB0 ? j : 0)) & 1u) ? bptr[j < C::NB0 ? j : 0] + is_boff : zsrc;
             if constexpr (DBG & 4) src = zsrc;
         }
@@ -254,10 +260,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
     };
     auto unit_fire = [&](const int st, const int i, const half_t* src) __attribute__((always_inline)) {
         unsigned char* sbase = smem + st * C::STAGE;
-        if (i < 4) {
+        if (i < NA) {
             glds16(src, reinterpret_cast<half_t*>(sbase + a_dst[i]));
         } else {
-            const int j = i - 4;
+            const int j = i - NA;
             if (j < nb) glds16(src, reinterpret_cast<half_t*>(sbase + C::A_BYTES + (bunit0 + j) * 1024));     // wave-uniform
         }
     };
@@ -271,19 +277,19 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
     auto issue_all = [&](const int st) __attribute__((always_inline)) {
         issue_begin();
 #pragma unroll
-        for (int i = 0; i < 4 + C::NB0; ++i) issue_unit(st, i);
+        for (int i = 0; i < NA + C::NB0; ++i) issue_unit(st, i);
         issue_advance();
     };
 
     // ---- fragment read offsets (bytes inside a stage): row = base16 + (lane & 15), logical chunk = 4 * kk + (lane >> 4)
     const int lr = lane & 15, lq = lane >> 4;
     const int fsw = ((lq ^ ((lr >> 1) & 7)) << 4);
-    const int a_off = (64 * wm + lr) * 128 + fsw;                       // kk = 1: ^ 64
+    const int a_off = ((BM / 4) * wm + lr) * 128 + fsw;                       // kk = 1: ^ 64
     const int b_off = C::A_BYTES + (PW * grp + lr) * 128 + fsw;
 
-    f32x4 acc[4][TN];
+    f32x4 acc[MI][TN];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
@@ -309,18 +315,18 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
     // The ONE counted wait per K-tile sits at the end of phase 1's read section: everything but the X_FIRST instructions
     // this wave has issued for K-tile t+2 so far must have landed, i.e. all of K-tile t+1.
     constexpr int X_FIRST = 3;
-    constexpr int NMF = 4 * TN;                    // MFMAs per phase: 20 / 16
+    constexpr int NMF = MI * TN;                   // MFMAs per phase: 20 / 16 (10 / 8 at BM = 128)
     constexpr int GAP = NMF / 4;                   // an LDS-DMA instruction after every GAP MFMAs
     int st_rd = 0, st_is = 2;
     // one K-tile; MORE (compile-time) = K-tile t+2 exists and is issued here: two copies of the body, no branches inside
     auto ktile = [&](auto more_c) __attribute__((always_inline)) {
         constexpr bool MORE = decltype(more_c)::value;
         const unsigned char* rbase = smem + st_rd * C::STAGE;
-        half8_t af[4], bf[TN];
+        half8_t af[MI], bf[TN];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
                 af[mi] = *reinterpret_cast<const half8_t*>(rbase + ((a_off ^ (kk << 6)) + mi * 2048));
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni)
@@ -330,7 +336,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
                 if (kk == 0) issue_begin();
 #pragma unroll
                 for (int q = 0; q < 3; ++q) nsrc[q] = unit_src(3 * kk + q);
-                if (C::NB0 == 3 && kk == 1) nsrc[3] = unit_src(6);
+                if (NA + C::NB0 == 7 && kk == 1) nsrc[3] = unit_src(6);
             }
             if (kk == 1) {
                 if constexpr (MORE) wait_vm<X_FIRST>();
@@ -356,7 +362,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
                     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);         // VMEM read (the LDS-DMA)
                 }
                 __builtin_amdgcn_sched_group_barrier(0x008, NMF - 3 * GAP, 0);
-                if (C::NB0 == 3 && kk == 1) unit_fire(st_is, 6, nsrc[3]);      // group-0 waves' third B unit (wave-uniform branch)
+                if (NA + C::NB0 == 7 && kk == 1) unit_fire(st_is, 6, nsrc[3]);      // group-0 waves' third B unit (wave-uniform branch)
             }
             __builtin_amdgcn_s_setprio(0);
             if constexpr (MORE) {
@@ -395,15 +401,15 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
     constexpr int NQ = ITEMS / 64;
     const bool vt_wave = p.vt != nullptr && nbase >= p.vt_col0;
     const bool generic = splitk == 1 && !vt_wave && epi != GL_EPI_GEGLU;
-    Fin8Aux aux[2][NQ];
+    Fin8Aux aux[MH][NQ];
     if (generic) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < MH; ++h)
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const int idx = lane + 64 * q;
                 const int r = idx / CG8, c = (idx - r * CG8) * 8;
-                const int m = m0 + 64 * wm + 32 * h + r, n = nbase + c;
+                const int m = m0 + (BM / 4) * wm + 32 * h + r, n = nbase + c;
                 if (m < M && n < N) fin8_load(p, m, n, aux[h][q]);
             }
     }
@@ -428,8 +434,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
         }
     }
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int mbase = m0 + 64 * wm + 32 * h;
+    for (int h = 0; h < MH; ++h) {
+        const int mbase = m0 + (BM / 4) * wm + 32 * h;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -548,36 +554,36 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
 constexpr int G8_MAX_DEVICES = 64;
 const half_t* g8_zero_page[G8_MAX_DEVICES] = {};   // per DEVICE: address of this translation unit's zero page on that device (gl8_init; __device__ symbols are per device)
 
-template <int BN, bool CONV>
+template <int BM, int BN, bool CONV>
 int launch8(const gl_gemm_args& g, const ConvGeom& cg_in, int zs, int kper, int order_m, hipStream_t st) {
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= G8_MAX_DEVICES) return GL_ERR_BAD_ARG;
     if (!g8_zero_page[dev]) return GL_ERR_BAD_ARG;     // gl_init() was not called on this device
     ConvGeom cg = cg_in;
     cg.zero = g8_zero_page[dev];
-    const int mt = gl_cdiv(g.M, 256), nt = gl_cdiv(g.N, BN);
+    const int mt = gl_cdiv(g.M, BM), nt = gl_cdiv(g.N, BN);
     dim3 grid(mt * nt, 1, zs);
     bool done = false;
-    if constexpr (BN == 160) {
+    if constexpr (BN == 160 && BM == 256) {
         void (*k)(gl_gemm_args, ConvGeom, int, int, int) = nullptr;
-        if (g8_dbg == 1) k = gemm8_kernel<BN, CONV, 1>;
-        if (g8_dbg == 3) k = gemm8_kernel<BN, CONV, 3>;
+        if (g8_dbg == 1) k = gemm8_kernel<BM, BN, CONV, 1>;
+        if (g8_dbg == 3) k = gemm8_kernel<BM, BN, CONV, 3>;
         if (k) {
-            k<<<grid, dim3(512), G8<BN>::LDS, st>>>(g, cg, zs, kper, order_m);
+            k<<<grid, dim3(512), G8<BM, BN>::LDS, st>>>(g, cg, zs, kper, order_m);
             done = true;
         }
     }
-    if (!done) gemm8_kernel<BN, CONV><<<grid, dim3(512), G8<BN>::LDS, st>>>(g, cg, zs, kper, order_m);
+    if (!done) gemm8_kernel<BM, BN, CONV><<<grid, dim3(512), G8<BM, BN>::LDS, st>>>(g, cg, zs, kper, order_m);
     GL_CHECK_LAUNCH();
     return 0;
 }
 
-template <int BN, bool CONV>
+template <int BM, int BN, bool CONV>
 int set_attr8() {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm8_kernel<BN, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, G8<BN>::LDS);
-    if constexpr (BN == 160) {
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm8_kernel<BN, CONV, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, G8<BN>::LDS);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm8_kernel<BN, CONV, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, G8<BN>::LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm8_kernel<BM, BN, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, G8<BM, BN>::LDS);
+    if constexpr (BN == 160 && BM == 256) {
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm8_kernel<BM, BN, CONV, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, G8<BM, BN>::LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm8_kernel<BM, BN, CONV, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, G8<BM, BN>::LDS);
     }
     return e == hipSuccess ? 0 : (int)e;
 }
@@ -600,9 +606,12 @@ int gl8_supported(const gl_gemm_args& g, bool conv, int* bn_out) {
     return 1;
 }
 
-int gl8_launch(const gl_gemm_args& g, const ConvGeom& cg, bool conv, int bn, int zs, int kper, int order_m, hipStream_t st) {
-    if (bn == 160) return conv ? launch8<160, true>(g, cg, zs, kper, order_m, st) : launch8<160, false>(g, cg, zs, kper, order_m, st);
-    if (bn == 128) return conv ? launch8<128, true>(g, cg, zs, kper, order_m, st) : launch8<128, false>(g, cg, zs, kper, order_m, st);
+// bm: 256, or 128 (half-height tiles: twice the blocks for grids that would leave CUs idle or split K)
+int gl8_launch(const gl_gemm_args& g, const ConvGeom& cg, bool conv, int bm, int bn, int zs, int kper, int order_m, hipStream_t st) {
+    if (bm == 256 && bn == 160) return conv ? launch8<256, 160, true>(g, cg, zs, kper, order_m, st) : launch8<256, 160, false>(g, cg, zs, kper, order_m, st);
+    if (bm == 256 && bn == 128) return conv ? launch8<256, 128, true>(g, cg, zs, kper, order_m, st) : launch8<256, 128, false>(g, cg, zs, kper, order_m, st);
+    if (bm == 128 && bn == 160) return conv ? launch8<128, 160, true>(g, cg, zs, kper, order_m, st) : launch8<128, 160, false>(g, cg, zs, kper, order_m, st);
+    if (bm == 128 && bn == 128) return conv ? launch8<128, 128, true>(g, cg, zs, kper, order_m, st) : launch8<128, 128, false>(g, cg, zs, kper, order_m, st);
     return GL_ERR_UNSUPPORTED;
 }
 
@@ -613,10 +622,14 @@ int gl8_init(void) {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= G8_MAX_DEVICES) return GL_ERR_BAD_ARG;
     if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero16)) != hipSuccess) return GL_ERR_BAD_ARG;
     g8_zero_page[dev] = reinterpret_cast<const half_t*>(zp);
-    if ((e = set_attr8<160, false>())) return e;
-    if ((e = set_attr8<160, true>())) return e;
-    if ((e = set_attr8<128, false>())) return e;
-    if ((e = set_attr8<128, true>())) return e;
+    if ((e = set_attr8<256, 160, false>())) return e;
+    if ((e = set_attr8<256, 160, true>())) return e;
+    if ((e = set_attr8<256, 128, false>())) return e;
+    if ((e = set_attr8<256, 128, true>())) return e;
+    if ((e = set_attr8<128, 160, false>())) return e;
+    if ((e = set_attr8<128, 160, true>())) return e;
+    if ((e = set_attr8<128, 128, false>())) return e;
+    if ((e = set_attr8<128, 128, true>())) return e;
     return 0;
 }
 

@@ -52,6 +52,7 @@ namespace {
 #define g_opt_g8_minkt gl_opt(34)  // default 11;     // split-K of the 8-wave kernel: at least this many K-tiles per slice
 std::atomic<uint64_t> g8_launches{0};   // launches that went to the 8-wave kernel (tests read it: gl_debug_read(9))
 #define g_opt_g8_shortk gl_opt(37)  // default 1: 8-wave kernel also for short-K multi-round grids that fill >= 80 % of their rounds
+#define g_opt_g8_bm128 gl_opt(46)  // default set in misc.hip: half-height (128-row) tiles of the 8-wave kernel for under-filled grids: bit 0 convs, bit 1 plain GEMMs
 #define g_opt_g8_minnk gl_opt(35)  // default 5;      // 8-wave kernel only for K >= 64 * this
 
 template <int BM, int BN, int BKT, int NW = 4>
@@ -784,16 +785,35 @@ int dispatch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     if (g_opt_g8) {
         int bn = 0;
         if (gl8_supported(g, CONV, &bn)) {
-            const int tiles = gl_cdiv(g.M, 256) * gl_cdiv(g.N, bn);
             const int nk = g.K / 64;
             // One block per CU: when the 256-row grid underfills the chip (32x32 levels and below), K is cut into slices up to ONE
             // round of blocks (256), never below g_opt_g8_minkt K-tiles per slice (prologue + epilogue cost ~4 K-tiles of time).
-            int splitk = 1;
-            if (tiles < g_opt_g8_tiles && g.workspace && g.epi != GL_EPI_GEGLU && g.vt == nullptr) {
-                splitk = 256 / tiles;
-                if (splitk > nk / g_opt_g8_minkt) splitk = nk / g_opt_g8_minkt;
-                while (splitk > 1 && (int64_t)splitk * g.M * g.N * 4 > g.workspace_bytes) --splitk;
-                if (splitk < 1) splitk = 1;
+            auto plan_split = [&](const int tiles_) {
+                int sk = 1;
+                if (tiles_ < g_opt_g8_tiles && g.workspace && g.epi != GL_EPI_GEGLU && g.vt == nullptr) {
+                    sk = 256 / tiles_;
+                    if (sk > nk / g_opt_g8_minkt) sk = nk / g_opt_g8_minkt;
+                    while (sk > 1 && (int64_t)sk * g.M * g.N * 4 > g.workspace_bytes) --sk;
+                    if (sk < 1) sk = 1;
+                }
+                return sk;
+            };
+            int bm = 256;
+            int tiles = gl_cdiv(g.M, 256) * gl_cdiv(g.N, bn);
+            int splitk = plan_split(tiles);
+            // Half-height (128-row) tiles where the 256-row grid covers at most half the chip (32x32 maps and below at 2B = 8): twice the
+            // blocks, so half the K slices (none at 32x32) and a smaller or no reduction.  The 128-row main loop issues the same B-side
+            // LDS-DMA per K-tile for half the MFMAs and runs ~1.4x slower per FLOP, so it only pays where the per-block fixed costs and
+            // the reduction dominate (profiles/r4_bm128_shapes.txt): every plain GEMM on such a grid (-20...-32 % at 8192 rows, -3...-17 %
+            // at 2048), and the convs whose 256-row plan leaves <= 16 K-tiles per slice (8x8 maps, stride-2 convs: -3...-10 %; long-K 3x3
+            // convs at 16x16 / 32x32 lose 8-25 %).  Key 46: bit 0 convs (by that rule), bit 1 plain GEMMs, bit 2 every conv (A/B).
+            if (tiles * 2 <= 256 && g.epi != GL_EPI_GEGLU && g.vt == nullptr) {
+                const bool want = CONV ? ((g_opt_g8_bm128 & 4) || ((g_opt_g8_bm128 & 1) && nk / splitk <= 16)) : ((g_opt_g8_bm128 & 2) != 0);
+                if (want) {
+                    bm = 128;
+                    tiles = gl_cdiv(g.M, 128) * gl_cdiv(g.N, bn);
+                    splitk = plan_split(tiles);
+                }
             }
             // plain GEMMs: measured per shape (profiles/r3_g8_probe.txt) -- multi-round grids with a short K stay on the 4-wave kernels
             // (several resident blocks hide each other's prologue / epilogue), split-K slices need >= 20 K-tiles to pay for the reduction
@@ -813,7 +833,7 @@ int dispatch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
                 const int kper = gl_cdiv(nk, splitk);
                 const int zs = gl_cdiv(nk, kper);
                 const int order_m = g_opt_order == 1 ? ((CONV ? 9L : 1L) * g.N > (long)g.M) : (g_opt_order == 2);
-                const int e = gl8_launch(g, cg, CONV, bn, zs, kper, order_m | (CONV && g_opt_g8_tapmajor ? 2 : 0), st);
+                const int e = gl8_launch(g, cg, CONV, bm, bn, zs, kper, order_m | (CONV && g_opt_g8_tapmajor ? 2 : 0), st);
                 if (e) return e;
                 g8_launches.fetch_add(1, std::memory_order_relaxed);
                 if (zs > 1) {

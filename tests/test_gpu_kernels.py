@@ -251,9 +251,16 @@ def test_gemm_conv_8wave_variant():
     forced wherever it applies via gl_set_option(30, 2) -- by default it serves the 64x64 / 32x32 levels of the full-size UNet,
     shapes too large for a CPU reference here.  Every epilogue it has: bias / SiLU / residual (fp16 and fp32 stream, with the
     fp16 copy) / gate / row bias / GEGLU / V^T tail / two-source A / split-K partials; convs stride 1, stride 2, nearest-2x;
-    ragged M and N tails.  gl_debug_read(9) proves the launches went to it."""
+    ragged M and N tails.  gl_debug_read(9) proves the launches went to it.  Run twice: with 256-row tiles only (key 46 = 0) and with the
+    half-height 128-row tiles wherever the grid is small enough for them (46 = 7; every shape here except GEGLU and the V^T tail)."""
+    for half_height in (0, 7):
+        _gemm_conv_8wave_variant(half_height)
+
+
+def _gemm_conv_8wave_variant(half_height):
     ops.set_option(30, 2)
     ops.set_option(24, 0)
+    ops.set_option(46, half_height)
 
     def on8(n, fn, *a):
         ops.set_option(24, 0)          # (some of the called tests restore the skinny-GEMM default on exit)
@@ -290,9 +297,12 @@ def test_gemm_conv_8wave_variant():
         on8(1, test_conv3x3, "s1", 1280, 1280, 16)      # split-K conv (few tiles, 180 K-tiles)
         on8(1, test_conv3x3, "s1", 64, 128, 24)         # 1152 rows: ragged last tile; K = 9 tiles
         on8(2, test_conv3x3_epilogues, 16)
+        on8(1, test_gemm_bias, 1300, 640, 640)          # 128-row tiles: ragged last tile of 11
+        on8(1, test_conv3x3, "s1", 128, 256, 20)        # 800 rows: 6.25 tiles of 128
     finally:
         ops.set_option(30, 1)
         ops.set_option(24, 64)
+        ops.set_option(46, 3)
 
 
 def test_gemm_conv_ksplit_variant():
