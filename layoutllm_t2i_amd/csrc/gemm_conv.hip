@@ -53,6 +53,7 @@ namespace {
 std::atomic<uint64_t> g8_launches{0};   // launches that went to the 8-wave kernel (tests read it: gl_debug_read(9))
 #define g_opt_g8_shortk gl_opt(37)  // default 1: 8-wave kernel also for short-K multi-round grids that fill >= 80 % of their rounds
 #define g_opt_g8_bm128 gl_opt(46)  // default set in misc.hip: half-height (128-row) tiles of the 8-wave kernel for under-filled grids: bit 0 convs, bit 1 plain GEMMs
+#define g_opt_g8_minblk gl_opt(47)  // default 100: plain GEMMs use the 8-wave kernel from this many blocks (tiles x slices) on
 #define g_opt_g8_minnk gl_opt(35)  // default 5;      // 8-wave kernel only for K >= 64 * this
 
 template <int BM, int BN, int BKT, int NW = 4>
@@ -818,7 +819,9 @@ int dispatch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
             // plain GEMMs: measured per shape (profiles/r3_g8_probe.txt) -- multi-round grids with a short K stay on the 4-wave kernels
             // (several resident blocks hide each other's prologue / epilogue), split-K slices need >= 20 K-tiles to pay for the reduction
             if (!CONV && splitk > 1 && nk / splitk < 20) splitk = nk / 20 > 0 ? nk / 20 : 1;
-            bool enough = tiles * splitk >= g_opt_g8_tiles && nk >= g_opt_g8_minnk;
+            // (plain GEMMs: the deep ring pays from ~100 blocks on -- 2048 x 1280 x 1280 on 128 half-height tiles 18.8 -> 17.0 us against the
+            // 4-wave 64 x 128 tiles, M = 512 shapes -15...-23 %; key 47.  The split-K decision above keeps its own threshold, key 31.)
+            bool enough = tiles * splitk >= (CONV ? g_opt_g8_tiles : (g_opt_g8_minblk < g_opt_g8_tiles ? g_opt_g8_minblk : g_opt_g8_tiles)) && nk >= g_opt_g8_minnk;
             if (!CONV && enough) {
                 // multi-round grids with a short K: nothing hides a block's prologue / epilogue at one block per CU, so the last, partly
                 // filled round must not cost more than the deeper loop wins -- only grids that fill >= 80 % of their rounds (measured
