@@ -494,7 +494,8 @@ int gl_sizeof_gn_args(void);
  * of the half-sized launches).
  * key 46 = half-height (128-row) tiles of the 8-wave GEMM / conv kernel where the 256-row grid would cover at most half the chip (32x32
  * maps and below at 2B = 8): bit 0 = convs whose 256-row plan leaves <= 16 K-tiles per split-K slice, bit 1 = plain GEMMs, bit 2 = every
- * conv (A/B); default 3, 0 = 256-row tiles only.  Results differ from the 256-row plan only through the number of split-K slices.
+ * conv (A/B), bit 3 = multi-round plain GEMMs whose 256-row grid ends in a mostly empty round while the 128-row grid fills its rounds;
+ * default 11, 0 = 256-row tiles only.  Results differ from the 256-row plan only through the number of split-K slices.
  * key 47 = plain GEMMs use the 8-wave kernel from this many blocks (tiles x K slices) on (default 100; the split-K decision keeps key 31). */
 int gl_set_option(int key, int value);
 /* gl_set_option writes the PROCESS defaults (op-level calls and every handle without an override see them).  A handle can

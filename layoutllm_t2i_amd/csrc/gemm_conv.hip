@@ -816,6 +816,16 @@ int dispatch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
                     splitk = plan_split(tiles);
                 }
             }
+            // multi-round plain GEMMs whose 256-row grid ends in a mostly empty round (8192 x 1920 x 640: 384 tiles = 1.5 rounds) while the
+            // 128-row grid fills its rounds (768 = 3.0): half-height tiles as well (key 46 bit 3)
+            if (!CONV && (g_opt_g8_bm128 & 8) && bm == 256 && splitk == 1 && tiles > 256 && g.epi != GL_EPI_GEGLU) {
+                const int t128 = gl_cdiv(g.M, 128) * gl_cdiv(g.N, bn);
+                auto fills = [](const int b) { return b * 5 >= ((b + 255) / 256) * 256 * 4; };
+                if (!fills(tiles) && fills(t128) && t128 <= 2048) {
+                    bm = 128;
+                    tiles = t128;
+                }
+            }
             // plain GEMMs: measured per shape (profiles/r3_g8_probe.txt) -- multi-round grids with a short K stay on the 4-wave kernels
             // (several resident blocks hide each other's prologue / epilogue), split-K slices need >= 20 K-tiles to pay for the reduction
             if (!CONV && splitk > 1 && nk / splitk < 20) splitk = nk / 20 > 0 ? nk / 20 : 1;

@@ -249,7 +249,7 @@ static gl_opts make_default_opts() {
     o.v[41] = 1;
     o.v[42] = 1;
     o.v[44] = 1;
-    o.v[46] = 3;
+    o.v[46] = 11;
     o.v[47] = 100;
     return o;
 }

@@ -252,8 +252,9 @@ def test_gemm_conv_8wave_variant():
     shapes too large for a CPU reference here.  Every epilogue it has: bias / SiLU / residual (fp16 and fp32 stream, with the
     fp16 copy) / gate / row bias / GEGLU / V^T tail / two-source A / split-K partials; convs stride 1, stride 2, nearest-2x;
     ragged M and N tails.  gl_debug_read(9) proves the launches went to it.  Run twice: with 256-row tiles only (key 46 = 0) and with the
-    half-height 128-row tiles wherever the grid is small enough for them (46 = 7; every shape here except GEGLU and the V^T tail)."""
-    for half_height in (0, 7):
+    half-height 128-row tiles wherever the dispatch rules allow them (46 = 15: small grids -- every shape here except GEGLU and the V^T tail --
+    and multi-round grids with a mostly empty last round: the 8192 x 1920 x 640 QKV projection with its V^T tail)."""
+    for half_height in (0, 15):
         _gemm_conv_8wave_variant(half_height)
 
 
@@ -298,11 +299,12 @@ def _gemm_conv_8wave_variant(half_height):
         on8(1, test_conv3x3, "s1", 64, 128, 24)         # 1152 rows: ragged last tile; K = 9 tiles
         on8(2, test_conv3x3_epilogues, 16)
         on8(1, test_gemm_bias, 1300, 640, 640)          # 128-row tiles: ragged last tile of 11
+        on8(2, test_gemm_qkv_writes_v_transposed, 8, 1024, 640, 8)     # 384 tiles of 256 rows = 1.5 rounds -> 768 half-height tiles
         on8(1, test_conv3x3, "s1", 128, 256, 20)        # 800 rows: 6.25 tiles of 128
     finally:
         ops.set_option(30, 1)
         ops.set_option(24, 64)
-        ops.set_option(46, 3)
+        ops.set_option(46, 11)
 
 
 def test_gemm_conv_ksplit_variant():
