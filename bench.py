@@ -327,7 +327,7 @@ def main():
                 "flops_per_launch": round(flops / max(n_fwd, 1)), "flop_model": "SURVEY 8d minimal (32 F_full + 70 F_off per image at S=50; F_full=%.4f, F_off=%.4f TFLOP/sample-forward at this latent)" % (F_FULL / 1e12, F_OFF / 1e12)}
 
     # ---- the single hottest kernel shape, timed standalone with HIP events on the launch stream: the implicit-GEMM
-    # 3x3 conv 320 -> 320 at the 64x64 level of the 2B batch (gemm8_kernel<160,true>, 7 launches per forward; that instantiation is
+    # 3x3 conv 320 -> 320 at the 64x64 level of the 2B batch (gemm8_kernel<256,160,true>, 7 launches per forward; that instantiation is
     # the top line of profiles/r3_kernel_stats.csv, where its average covers all conv shapes incl. the split-K ones)
     if rank == 0 and side == 64 and not args.tiny and not args.no_hot_kernel:
         from layoutllm_t2i_amd import ops as _o
@@ -348,7 +348,7 @@ def main():
         k_us = k0.elapsed_time(k1) / nrep * 1e3
         k_flops = 2.0 * Bn * side * side * 320 * 9 * 320
         k_tf = k_flops / (k_us * 1e-6) / 1e12
-        roofline["hot_kernel"] = {"kernel": "gemm8_kernel<160,true> (8-wave deep-pipelined implicit-GEMM) as 3x3 conv 320->320 @64x64, 2B=%d" % Bn,
+        roofline["hot_kernel"] = {"kernel": "gemm8_kernel<256,160,true> (8-wave deep-pipelined implicit-GEMM) as 3x3 conv 320->320 @64x64, 2B=%d" % Bn,
                                   "avg_us": round(k_us, 1), "flops": k_flops, "achieved": round(k_tf, 1), "unit": "TFLOP/s",
                                   "frac": round(k_tf / MFMA_PEAK_TFLOPS, 4), "launches_per_forward": 7}
         del xa, wa, oa
