@@ -8,6 +8,9 @@
 // the wave cycles waiting / stalled).  Here:
 //   * block tile 256 x BN (BN = 160 for the UNet's N = 320 k channel widths, 128 otherwise), BK = 64, 512 threads = 8 waves,
 //     one block per CU; wave tile 64 x BN/2 from v_mfma_f32_16x16x32_f16 (BN/2 = 80 is not a multiple of 32);
+//     a HALF-HEIGHT form (BM = 128: wave tile 32 x BN/2, two A staging units per wave instead of four, one epilogue pass) doubles the
+//     block count of launches whose 256-row grid cannot fill the chip -- ~1.4x slower per FLOP in the main loop (same B-side LDS-DMA and
+//     barriers per K-tile for half the MFMAs), faster wherever per-block fixed costs and the split-K reduction dominate (gemm_conv.hip);
 //   * a THREE-stage LDS ring (3 x 52 KiB at BN = 160) filled by global_load_lds_dwordx4; loads of K-tile t+2 are issued
 //     while K-tile t is consumed and are NEVER drained inside the loop: s_waitcnt vmcnt(N) with N counted so that exactly
 //     the pieces the NEXT phase reads have landed, then a raw s_barrier (a __syncthreads() would emit vmcnt(0));
