@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GL_ABI_VERSION 12
+#define GL_ABI_VERSION 13
 
 /* error codes (negative; positive values are hipError_t) */
 #define GL_ERR_BAD_ARG (-1)
@@ -234,19 +234,23 @@ int gl_layernorm_stats(const float* x, int32_t ldx, int32_t rows, int32_t C, flo
  *                   gamma / beta, so that it enters the stream unrounded.  With ln2_out != NULL (fp32 stream + ln_stats
  *                   form only, max_objs <= 32) the same launch also writes ln2_out = LayerNorm(y; ln2_gamma, ln2_beta,
  *                   eps 1e-5) in fp16 -- the norm2 in front of attn2 (attention.py:400) -- bit-identical to gl_layernorm(y).
+ * slots (ABI 13): rows per sample of feat / ln_out / f, 0 < slots <= max_objs (0 = max_objs).  The reference runs the relation chain
+ * (attention.py:348-351) over all max_objs = 30 rows of every sample although only the first nvalid[b] enter the result; a caller that knows
+ * max_b nvalid[b] <= slots computes just `slots` rows per sample -- the rows are independent of one another, so the used ones are unchanged.
+ * rects stays [B, max_objs, 4] and 1/max_objs stays the reference's divisor.
  */
 int gl_rela_pool(const void* hid, int32_t B, int32_t H, int32_t W, int32_t C, const int32_t* rects,
-                 const int32_t* nvalid, const int32_t* poison, int32_t max_objs, void* feat, const float* ln_gamma,
+                 const int32_t* nvalid, const int32_t* poison, int32_t max_objs, int32_t slots, void* feat, const float* ln_gamma,
                  const float* ln_beta, void* ln_out, void* stream);
 /* gl_rela_pool_ln3 (round 4): gl_rela_pool on the fp32 stream: x fp32 [B, H*W, C] with the per-row (mean, rstd) of rela_fuse's LayerNorm3
  * (gl_layernorm_stats) and its gamma / beta; the pooled row is gamma * mean_rect((x - mean_r) * rstd_r) + beta in fp32 -- hid = LN3(x)
  * (attention.py:317) is neither rounded to fp16 nor stored. */
 int gl_rela_pool_ln3(const float* x, const float* ln3_stats, const float* ln3_gamma, const float* ln3_beta, int32_t B, int32_t H,
                      int32_t W, int32_t C, const int32_t* rects, const int32_t* nvalid, const int32_t* poison, int32_t max_objs,
-                     void* feat, const float* ln_gamma, const float* ln_beta, void* ln_out, void* stream);
+                     int32_t slots, void* feat, const float* ln_gamma, const float* ln_beta, void* ln_out, void* stream);
 int gl_rela_merge(const void* x, int32_t x_f32, const void* hid, const float* ln_stats, const float* gamma,
                   const float* beta, const void* f, int32_t B, int32_t H, int32_t W, int32_t C,
-                  const int32_t* rects, const int32_t* nvalid, const int32_t* poison, int32_t max_objs,
+                  const int32_t* rects, const int32_t* nvalid, const int32_t* poison, int32_t max_objs, int32_t slots,
                   void* y, const float* ln2_gamma, const float* ln2_beta, void* ln2_out, void* stream);
 
 /*

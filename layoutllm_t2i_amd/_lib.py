@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgligen_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 # enum gl_epilogue / gl_out_mode
 EPI_BIAS, EPI_SILU, EPI_GEGLU, EPI_RES, EPI_GATE_RES, EPI_ROWBIAS = range(6)
@@ -148,9 +148,9 @@ PROTOTYPES = {
     "gl_sizeof_gn_args": (i32, []),
     "gl_layernorm": (i32, [vp, i32, i32, vp, i32, fp, fp, i32, i32, i32, i32, i32, f32, fp, vp, i32, i32, vp]),
     "gl_layernorm_stats": (i32, [fp, i32, i32, i32, f32, fp, vp]),
-    "gl_rela_pool_ln3": (i32, [fp, fp, fp, fp, i32, i32, i32, i32, vp, vp, vp, i32, vp, fp, fp, vp, vp]),
-    "gl_rela_pool": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, fp, fp, vp, vp]),
-    "gl_rela_merge": (i32, [vp, i32, vp, fp, fp, fp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, fp, fp, vp, vp]),
+    "gl_rela_pool_ln3": (i32, [fp, fp, fp, fp, i32, i32, i32, i32, vp, vp, vp, i32, i32, vp, fp, fp, vp, vp]),
+    "gl_rela_pool": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, i32, i32, vp, fp, fp, vp, vp]),
+    "gl_rela_merge": (i32, [vp, i32, vp, fp, fp, fp, vp, i32, i32, i32, i32, vp, vp, vp, i32, i32, vp, fp, fp, vp, vp]),
     "gl_posnet_input": (i32, [fp, fp, fp, fp, fp, i32, i32, i32, vp, vp]),
     "gl_timestep_embedding": (i32, [fp, i32, i32, vp, vp]),
     "gl_silu_f16": (i32, [vp, vp, i64, vp]),

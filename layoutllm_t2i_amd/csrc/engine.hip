@@ -33,6 +33,7 @@ constexpr int64_t WS_BYTES = 96ll << 20; // split-K fp32 partial tiles
 #define g_force_fuser gl_opt(20)  // default 0;                   // test knob (gl_set_option 20): execute the fuser even at scale 0 (zero gates)
 #define g_precise gl_opt(41)      // default 1;                   // split-fp16 activations for the 1x1 convs + GroupNorm on the fp32 stream
 #define g_h1_f32 gl_opt(42)       // default 1;                   // with key 41: the ResBlock's first conv writes fp32 for out_layers' GroupNorm
+#define g_rela_compact gl_opt(43) // default 1;                   // the relation chain runs on max_b nvalid[b] (rounded up to 8) rows per sample instead of max_objs = 30
 #define g_share gl_opt(44)        // default 1;                   // 2B = [cond ; uncond] forwards: everything before the first conditioning-dependent op
                                                                   // (conv_in, the first ResBlock, proj_in .. attn1 of the first transformer) runs ONCE on
                                                                   // the B shared latents and is duplicated
@@ -140,6 +141,7 @@ struct gl_engine {
     size_t gate_pin_bytes = 0;
     int gate_pin_next = 0;
     int launches = 0;
+    int rel_slots = 0;                 // rows per sample of the relation chain (gl_set_conditioning: max nvalid over samples and levels, rounded up to 8)
     int opt_epoch = 0;                 // gl_set_option generation the captured graphs were built under
     int ovr_epoch = 0;                 // ... and the generation of this handle's own overrides
     gl_opt_overrides ovr;              // per-handle option overrides (gl_set_handle_option)
@@ -689,7 +691,8 @@ int spatial_transformer(Run& r, const LayerD& l, int li, Stream2 xin, int side, 
         const int* rects = reinterpret_cast<const int*>(e->buf("cond.rects." + ss, (size_t)Bn * mo * 16));
         const int* nvalid = reinterpret_cast<const int*>(e->buf("cond.nvalid." + ss, (size_t)Bn * 4));
         const int* poison = reinterpret_cast<const int*>(e->buf("cond.poison." + ss, (size_t)Bn * 4));
-        const int Mo = Bn * mo;
+        const int ms = e->rel_slots > 0 ? e->rel_slots : mo;      // rows per sample of the chain (feat .. f2); rects keep max_objs slots
+        const int Mo = Bn * ms;
         float* stats = e->f32("st.lnstats", (size_t)M * 2);
         half_t* hid = e->h16("st.hid", (size_t)M * C);
         half_t* feat = e->h16("rl.feat", (size_t)Mo * C);
@@ -704,28 +707,28 @@ int spatial_transformer(Run& r, const LayerD& l, int li, Stream2 xin, int side, 
             // LayerNorm3 is never materialised: its per-row statistics, then the box means of LN3(x) and (in rela_merge) LN3(x) itself in fp32
             r.launches += 2;
             CK(gl_layernorm_stats(x, C, M, C, 1e-5f, stats, r.st));
-            CK(gl_rela_pool_ln3(x, stats, e->Wf(rf + ".norm3.g"), e->Wf(rf + ".norm3.b"), Bn, side, side, C, rects, nvalid, poison, mo, feat,
+            CK(gl_rela_pool_ln3(x, stats, e->Wf(rf + ".norm3.g"), e->Wf(rf + ".norm3.b"), Bn, side, side, C, rects, nvalid, poison, mo, ms, feat,
                                 e->Wf(rf + ".norm1.g"), e->Wf(rf + ".norm1.b"), fn, r.st));
         } else {
             CK(r.ln(x, C, 1, hid, C, rf + ".norm3", Bn, N, N, 0, C, stats));
             ++r.launches;
-            CK(gl_rela_pool(hid, Bn, side, side, C, rects, nvalid, poison, mo, feat, e->Wf(rf + ".norm1.g"), e->Wf(rf + ".norm1.b"), fn, r.st));
+            CK(gl_rela_pool(hid, Bn, side, side, C, rects, nvalid, poison, mo, ms, feat, e->Wf(rf + ".norm1.g"), e->Wf(rf + ".norm1.b"), fn, r.st));
         }
         CK(r.gemm(fn, C, rf + ".attn.q.w", Mo, q, C));
         const half_t* kv = e->h16("hoist.kvrel." + sl, (size_t)Bn * R * 2 * C);
         const int ldvt = vt_ld(R);
         const half_t* vtr = e->h16("hoist.vtrel." + sl, (size_t)Bn * H * d * ldvt);
         CKP(kv); CKP(vtr);
-        CK(r.attn(q, (int64_t)mo * C, C, kv, (int64_t)R * 2 * C, 2 * C, vtr, ldvt, ar, (int64_t)mo * C, C, Bn, H, d, mo, R));
+        CK(r.attn(q, (int64_t)ms * C, C, kv, (int64_t)R * 2 * C, 2 * C, vtr, ldvt, ar, (int64_t)ms * C, C, Bn, H, d, ms, R));
         CK(r.gemm(ar, C, rf + ".attn.o.w", Mo, f1, C, GL_OUT_F16_ROWMAJOR, rf + ".attn.o.b", GL_EPI_GATE_RES, feat, C, 0, gates + 2));
-        CK(r.ln(f1, C, 0, fn, C, rf + ".norm2", Bn, mo, mo, 0, C));
+        CK(r.ln(f1, C, 0, fn, C, rf + ".norm2", Bn, ms, ms, 0, C));
         CK(r.gemm(fn, C, rf + ".ff.ff1.w", Mo, hg, 4 * C, GL_OUT_F16_ROWMAJOR, rf + ".ff.ff1.b", GL_EPI_GEGLU));
         CK(r.gemm(hg, 4 * C, rf + ".ff.ff2.w", Mo, f2, C, GL_OUT_F16_ROWMAJOR, rf + ".ff.ff2.b", GL_EPI_GATE_RES, f1, C, 0, gates + 3));
         float* y = nxt(x);
         ++r.launches;
         // ... and LayerNorm(norm2) of the merged rows in the same launch (the rows attn2's q projection reads)
-        const bool fuse_ln2 = g_fuse_merge_ln && mo <= 32;
-        CK(gl_rela_merge(x, 1, nullptr, stats, e->Wf(rf + ".norm3.g"), e->Wf(rf + ".norm3.b"), f2, Bn, side, side, C, rects, nvalid, poison, mo, y,
+        const bool fuse_ln2 = g_fuse_merge_ln && ms <= 32;
+        CK(gl_rela_merge(x, 1, nullptr, stats, e->Wf(rf + ".norm3.g"), e->Wf(rf + ".norm3.b"), f2, Bn, side, side, C, rects, nvalid, poison, mo, ms, y,
                          fuse_ln2 ? e->Wf(t + ".norm2.g") : nullptr, fuse_ln2 ? e->Wf(t + ".norm2.b") : nullptr, fuse_ln2 ? lnb : nullptr, r.st));
         x = y;
         ln2_done = fuse_ln2;
@@ -1039,6 +1042,26 @@ extern "C" int gl_set_conditioning(gl_engine* e, const float* context, const flo
             rela_rects_kernel<<<dim3((Bn + 63) / 64), dim3(64), 0, st>>>(boxes, masks, Bn, mo, s, s, rects, nvalid, poison);
             GL_CHECK_LAUNCH();
         }
+        // Rows of the relation chain (attention.py:348-351 runs LN / cross-attention / FeedForward over all 30 rows of every sample; only
+        // the first nvalid[b] of them enter the result, and the rows are independent of one another): the largest nvalid over samples and
+        // resolutions, rounded up to 8.  One small device-to-host copy per conditioning (once per image batch, outside any capture).
+        int slots = mo;
+        if (g_rela_compact) {
+            std::vector<int> nv((size_t)Bn);
+            int mx = 0;
+            for (int s_ : sides) {
+                const int* nvalid = reinterpret_cast<const int*>(e->buf("cond.nvalid." + std::to_string(s_), (size_t)Bn * 4));
+                CKP(nvalid);
+                if (hipMemcpyAsync(nv.data(), nvalid, (size_t)Bn * 4, hipMemcpyDeviceToHost, st) != hipSuccess) return GL_ERR_BAD_ARG;
+                if (hipStreamSynchronize(st) != hipSuccess) return GL_ERR_BAD_ARG;
+                for (int v : nv) mx = v > mx ? v : mx;
+            }
+            slots = (mx + 7) & ~7;
+            if (slots < 8) slots = 8;
+            if (slots > mo) slots = mo;
+        }
+        if (slots != e->rel_slots) e->drop_graphs();
+        e->rel_slots = slots;
     }
     if (e->pool_changed) e->drop_graphs();
     e->cond_set = true;

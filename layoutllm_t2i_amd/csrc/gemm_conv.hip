@@ -644,6 +644,9 @@ inline bool skinny_ok(const gl_gemm_args& g) {
     if (!g_opt_skinny || g.M > 1024 || (g.N % 32) != 0 || g.epi == GL_EPI_GEGLU || g.vt != nullptr || g.a2 != nullptr) return false;
     if (g.kwrap != 0 && g.K != 2 * g.kwrap) return false;
     if (g.out_mode == GL_OUT_F32_NCHW || (g.lda % 8) != 0) return false;
+    // a block walks the whole K with four waves: beyond K = 4096 (the relation chain's FF2 at 1280 channels: 31.6 us on 64 rows) the
+    // LDS-staged kernels with split-K are faster (12 + 5 us)
+    if (g.K > 4096 && g.workspace != nullptr) return false;
     const long tiles = (long)gl_cdiv(g.M, 32) * (g.N / 32);
     return tiles * 64L * g.K * 2L <= (long)g_opt_skinny << 20;
 }

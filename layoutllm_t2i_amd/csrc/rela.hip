@@ -28,7 +28,7 @@ __global__ __launch_bounds__(RP_NT) void rela_pool_kernel(const half_t* __restri
                                                         const float* __restrict__ ln3_stats, const float* __restrict__ ln3_g,
                                                         const float* __restrict__ ln3_b, int H, int W, int C,
                                                         const int* __restrict__ rects, const int* __restrict__ nvalid,
-                                                        const int* __restrict__ poison, int max_objs,
+                                                        const int* __restrict__ poison, int max_objs, int slots,
                                                         half_t* __restrict__ feat, const float* __restrict__ ln_g,
                                                         const float* __restrict__ ln_b, half_t* __restrict__ ln_out) {
     __shared__ float lacc[8 * RP_NT];    // [plane][C] partial sums, nplanes * C <= 8 * RP_NT
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(RP_NT) void rela_pool_kernel(const half_t* __restri
     const int i = blockIdx.x;
     const int b = blockIdx.y;
     const int nvec = C / 8;
-    half_t* frow = feat + ((size_t)b * max_objs + i) * C;
+    half_t* frow = feat + ((size_t)b * slots + i) * C;      // rows: `slots` per sample; rects: max_objs per sample
     // mode: 0 = pooled mean, 1 = unused slot (zero row), 2 = NaN row (empty python slice: torch.mean of nothing,
     // attention.py:343, or a poisoned sample)
     int mode = 0;
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(RP_NT) void rela_pool_kernel(const half_t* __restri
         lss = fmaf(d, d, lss);
     }
     const float rstd = rsqrtf(bsum(lss) / (float)C + 1e-5f);
-    half_t* lrow = ln_out + ((size_t)b * max_objs + i) * C;
+    half_t* lrow = ln_out + ((size_t)b * slots + i) * C;
     for (int c = threadIdx.x; c < C; c += RP_NT) lrow[c] = (half_t)((lacc[c] - mean) * rstd * ln_g[c] + ln_b[c]);
 }
 
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void rela_merge_kernel(const void* __restrict_
                                                          const float* __restrict__ beta, const half_t* __restrict__ f,
                                                          int H, int W, int C, const int* __restrict__ rects,
                                                          const int* __restrict__ nvalid, const int* __restrict__ poison,
-                                                         int max_objs, void* __restrict__ yv, size_t total) {
+                                                         int max_objs, int slots, void* __restrict__ yv, size_t total) {
     const int nvec = C / 8;
     const int HW = H * W;
     const float inv_mo = 1.0f / (float)max_objs;
@@ -213,12 +213,12 @@ __global__ __launch_bounds__(256) void rela_merge_kernel(const void* __restrict_
         float acc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
-        const int nv = nvalid[b];
+        const int nv = min(nvalid[b], slots);
         const int* rb = rects + (size_t)b * max_objs * 4;
         for (int i = 0; i < nv; ++i) {
             const int top = rb[4 * i], bottom = rb[4 * i + 1], left = rb[4 * i + 2], right = rb[4 * i + 3];
             if (py >= top && py < bottom && px >= left && px < right) {
-                uint4 rf = ld16(f + ((size_t)b * max_objs + i) * C + vec * 8);
+                uint4 rf = ld16(f + ((size_t)b * slots + i) * C + vec * 8);
                 const half8_t fv = *reinterpret_cast<half8_t*>(&rf);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[j] += (float)fv[j];
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void rela_merge_ln_kernel(const float* __restr
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const half_t* __restrict__ f, int H, int W, int C,
                                                             const int* __restrict__ rects, const int* __restrict__ nvalid,
-                                                            const int* __restrict__ poison, int max_objs, float* __restrict__ y,
+                                                            const int* __restrict__ poison, int max_objs, int slots, float* __restrict__ y,
                                                             const float* __restrict__ g2, const float* __restrict__ b2,
                                                             half_t* __restrict__ ln_out, int ntok) {
     const int lane = threadIdx.x & 63;
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void rela_merge_ln_kernel(const float* __restr
     const int py = p / W, px = p - py * W;
     const float inv_mo = 1.0f / (float)max_objs;
     const float mean3 = ln_stats[(size_t)tok * 2], rstd3 = ln_stats[(size_t)tok * 2 + 1];
-    const int nv = nvalid[b];
+    const int nv = min(nvalid[b], slots);
     const int* rb = rects + (size_t)b * max_objs * 4;
     const bool bad = poison[b] != 0;
     // which boxes cover this pixel: wave-uniform bit mask (max_objs <= 32 checked by the launcher)
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void rela_merge_ln_kernel(const float* __restr
             for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
             for (unsigned m = cover; m != 0; m &= m - 1) {
                 const int bi = __builtin_ctz(m);
-                uint4 rf = ld16(f + ((size_t)b * max_objs + bi) * C + vec * 8);
+                uint4 rf = ld16(f + ((size_t)b * slots + bi) * C + vec * 8);
                 const half8_t fv = *reinterpret_cast<half8_t*>(&rf);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[j] += (float)fv[j];
@@ -339,12 +339,14 @@ __global__ __launch_bounds__(256) void rela_merge_ln_kernel(const float* __restr
 }  // namespace
 
 extern "C" int gl_rela_pool(const void* hid, int32_t B, int32_t H, int32_t W, int32_t C, const int32_t* rects,
-                            const int32_t* nvalid, const int32_t* poison, int32_t max_objs, void* feat, const float* ln_gamma,
+                            const int32_t* nvalid, const int32_t* poison, int32_t max_objs, int32_t slots, void* feat, const float* ln_gamma,
                             const float* ln_beta, void* ln_out, void* stream) {
     if (!hid || !rects || !nvalid || !poison || !feat || C <= 0 || (C % 8) || C > RELA_MAX_C) return GL_ERR_BAD_ARG;
     if (ln_out != nullptr && (!ln_gamma || !ln_beta)) return GL_ERR_BAD_ARG;
-    rela_pool_kernel<false><<<dim3(max_objs, B), dim3(RP_NT), 0, (hipStream_t)stream>>>(
-        reinterpret_cast<const half_t*>(hid), nullptr, nullptr, nullptr, nullptr, H, W, C, rects, nvalid, poison, max_objs,
+    if (slots <= 0) slots = max_objs;
+    if (slots > max_objs) return GL_ERR_BAD_ARG;
+    rela_pool_kernel<false><<<dim3(slots, B), dim3(RP_NT), 0, (hipStream_t)stream>>>(
+        reinterpret_cast<const half_t*>(hid), nullptr, nullptr, nullptr, nullptr, H, W, C, rects, nvalid, poison, max_objs, slots,
         reinterpret_cast<half_t*>(feat), ln_gamma, ln_beta, reinterpret_cast<half_t*>(ln_out));
     GL_CHECK_LAUNCH();
     return 0;
@@ -352,12 +354,14 @@ extern "C" int gl_rela_pool(const void* hid, int32_t B, int32_t H, int32_t W, in
 
 extern "C" int gl_rela_pool_ln3(const float* x, const float* ln3_stats, const float* ln3_gamma, const float* ln3_beta, int32_t B, int32_t H,
                                 int32_t W, int32_t C, const int32_t* rects, const int32_t* nvalid, const int32_t* poison, int32_t max_objs,
-                                void* feat, const float* ln_gamma, const float* ln_beta, void* ln_out, void* stream) {
+                                int32_t slots, void* feat, const float* ln_gamma, const float* ln_beta, void* ln_out, void* stream) {
     if (!x || !ln3_stats || !ln3_gamma || !ln3_beta || !rects || !nvalid || !poison || !feat || C <= 0 || (C % 8) || C > RELA_MAX_C)
         return GL_ERR_BAD_ARG;
     if (ln_out != nullptr && (!ln_gamma || !ln_beta)) return GL_ERR_BAD_ARG;
-    rela_pool_kernel<true><<<dim3(max_objs, B), dim3(RP_NT), 0, (hipStream_t)stream>>>(
-        nullptr, x, ln3_stats, ln3_gamma, ln3_beta, H, W, C, rects, nvalid, poison, max_objs, reinterpret_cast<half_t*>(feat), ln_gamma, ln_beta,
+    if (slots <= 0) slots = max_objs;
+    if (slots > max_objs) return GL_ERR_BAD_ARG;
+    rela_pool_kernel<true><<<dim3(slots, B), dim3(RP_NT), 0, (hipStream_t)stream>>>(
+        nullptr, x, ln3_stats, ln3_gamma, ln3_beta, H, W, C, rects, nvalid, poison, max_objs, slots, reinterpret_cast<half_t*>(feat), ln_gamma, ln_beta,
         reinterpret_cast<half_t*>(ln_out));
     GL_CHECK_LAUNCH();
     return 0;
@@ -365,20 +369,22 @@ extern "C" int gl_rela_pool_ln3(const float* x, const float* ln3_stats, const fl
 
 extern "C" int gl_rela_merge(const void* x, int32_t x_f32, const void* hid, const float* ln_stats, const float* gamma,
                              const float* beta, const void* f, int32_t B, int32_t H, int32_t W, int32_t C,
-                             const int32_t* rects, const int32_t* nvalid, const int32_t* poison, int32_t max_objs, void* y,
+                             const int32_t* rects, const int32_t* nvalid, const int32_t* poison, int32_t max_objs, int32_t slots, void* y,
                              const float* ln2_gamma, const float* ln2_beta, void* ln2_out, void* stream) {
     if (!x || !f || !rects || !nvalid || !poison || !y || C <= 0 || (C % 8)) return GL_ERR_BAD_ARG;
+    if (slots <= 0) slots = max_objs;
+    if (slots > max_objs) return GL_ERR_BAD_ARG;
     if (ln_stats ? (!gamma || !beta) : !hid) return GL_ERR_BAD_ARG;
     if (ln2_out != nullptr) {
         // fused form: fp32 stream + recomputed LN3 only, one wave per token
-        if (!x_f32 || !ln_stats || !ln2_gamma || !ln2_beta || max_objs > 32 || C > 2048) return GL_ERR_UNSUPPORTED;
+        if (!x_f32 || !ln_stats || !ln2_gamma || !ln2_beta || slots > 32 || C > 2048) return GL_ERR_UNSUPPORTED;
         const int ntok = B * H * W;
         const int nv = gl_cdiv(C / 8, 64);
         const dim3 grid(gl_cdiv(ntok, 4)), blk(256);
 #define GL_RM(V)                                                                                                                         \
     rela_merge_ln_kernel<V><<<grid, blk, 0, (hipStream_t)stream>>>(reinterpret_cast<const float*>(x), ln_stats, gamma, beta,              \
                                                                    reinterpret_cast<const half_t*>(f), H, W, C, rects, nvalid, poison,    \
-                                                                   max_objs, reinterpret_cast<float*>(y), ln2_gamma, ln2_beta,             \
+                                                                   max_objs, slots, reinterpret_cast<float*>(y), ln2_gamma, ln2_beta,      \
                                                                    reinterpret_cast<half_t*>(ln2_out), ntok)
         if (nv == 1) GL_RM(1); else if (nv == 2) GL_RM(2); else if (nv == 3) GL_RM(3); else GL_RM(4);
 #undef GL_RM
@@ -392,10 +398,10 @@ extern "C" int gl_rela_merge(const void* x, int32_t x_f32, const void* hid, cons
     const half_t* fp = reinterpret_cast<const half_t*>(f);
     if (x_f32)
         rela_merge_kernel<true><<<dim3(nblk), dim3(256), 0, (hipStream_t)stream>>>(x, hp, ln_stats, gamma, beta, fp, H, W, C, rects,
-                                                                                  nvalid, poison, max_objs, y, total);
+                                                                                  nvalid, poison, max_objs, slots, y, total);
     else
         rela_merge_kernel<false><<<dim3(nblk), dim3(256), 0, (hipStream_t)stream>>>(x, hp, ln_stats, gamma, beta, fp, H, W, C, rects,
-                                                                                   nvalid, poison, max_objs, y, total);
+                                                                                   nvalid, poison, max_objs, slots, y, total);
     GL_CHECK_LAUNCH();
     return 0;
 }

@@ -295,8 +295,9 @@ def layernorm(x: torch.Tensor, y: torch.Tensor, gamma: torch.Tensor, beta: torch
     return y
 
 
-def rela_pool(hid, B, H, W, Cc, rects, nvalid, poison, max_objs, feat, ln_gamma=None, ln_beta=None, ln_out=None):
-    """feat[b, i] = mean of hid over box i; with ``ln_out`` also LayerNorm(feat) (fused norm1 of rela_fuse)."""
+def rela_pool(hid, B, H, W, Cc, rects, nvalid, poison, max_objs, feat, ln_gamma=None, ln_beta=None, ln_out=None, slots=0):
+    """feat[b, i] = mean of hid over box i; with ``ln_out`` also LayerNorm(feat) (fused norm1 of rela_fuse).  ``slots``: rows per sample of
+    feat / ln_out (0 = max_objs; every nvalid[b] must be <= slots)."""
     _req(hid, F16, "hid")
     _req(feat, F16, "feat")
     for t, n in ((rects, "rects"), (nvalid, "nvalid"), (poison, "poison")):
@@ -306,7 +307,7 @@ def rela_pool(hid, B, H, W, Cc, rects, nvalid, poison, max_objs, feat, ln_gamma=
         _req(ln_gamma, F32, "ln_gamma")
         _req(ln_beta, F32, "ln_beta")
     check(_lib.lib().gl_rela_pool(hid.data_ptr(), B, H, W, Cc, rects.data_ptr(), nvalid.data_ptr(), poison.data_ptr(),
-                                  max_objs, feat.data_ptr(), _ptr(ln_gamma), _ptr(ln_beta), _ptr(ln_out), _stream()), "gl_rela_pool")
+                                  max_objs, int(slots), feat.data_ptr(), _ptr(ln_gamma), _ptr(ln_beta), _ptr(ln_out), _stream()), "gl_rela_pool")
     return feat
 
 
@@ -321,7 +322,7 @@ def layernorm_stats(x: torch.Tensor, stats: torch.Tensor, eps: float = 1e-5) -> 
     return stats
 
 
-def rela_pool_ln3(x, ln3_stats, ln3_gamma, ln3_beta, B, H, W, Cc, rects, nvalid, poison, max_objs, feat, ln_gamma=None, ln_beta=None, ln_out=None):
+def rela_pool_ln3(x, ln3_stats, ln3_gamma, ln3_beta, B, H, W, Cc, rects, nvalid, poison, max_objs, feat, ln_gamma=None, ln_beta=None, ln_out=None, slots=0):
     """rela_pool on the fp32 stream: feat[b, i] = mean over box i of LN3(x), LN3 re-evaluated in fp32 from ``ln3_stats`` (gl_rela_pool_ln3)."""
     _req(x, F32, "x")
     _req(ln3_stats, F32, "ln3_stats", 8)
@@ -335,13 +336,13 @@ def rela_pool_ln3(x, ln3_stats, ln3_gamma, ln3_beta, B, H, W, Cc, rects, nvalid,
         _req(ln_gamma, F32, "ln_gamma")
         _req(ln_beta, F32, "ln_beta")
     check(_lib.lib().gl_rela_pool_ln3(x.data_ptr(), ln3_stats.data_ptr(), ln3_gamma.data_ptr(), ln3_beta.data_ptr(), B, H, W, Cc, rects.data_ptr(),
-                                      nvalid.data_ptr(), poison.data_ptr(), max_objs, feat.data_ptr(), _ptr(ln_gamma), _ptr(ln_beta), _ptr(ln_out),
+                                      nvalid.data_ptr(), poison.data_ptr(), max_objs, int(slots), feat.data_ptr(), _ptr(ln_gamma), _ptr(ln_beta), _ptr(ln_out),
                                       _stream()), "gl_rela_pool_ln3")
     return feat
 
 
 def rela_merge(x, hid, f, B, H, W, Cc, rects, nvalid, poison, max_objs, y, ln_stats=None, gamma=None, beta=None,
-               ln2_gamma=None, ln2_beta=None, ln2_out=None):
+               ln2_gamma=None, ln2_beta=None, ln2_out=None, slots=0):
     """y = 0.5 * (x + hid + (1/max_objs) sum_i 1[p in rect_i] f_i); x / y fp16 or fp32 (same dtype).  With ``ln_stats``
     (+ gamma, beta) hid = LayerNorm(x) is re-evaluated in fp32 from the stored (mean, rstd) instead of read from ``hid``.
     With ``ln2_out`` (fp32 stream + ln_stats form) the launch also writes LayerNorm(y; ln2_gamma, ln2_beta) in fp16."""
@@ -359,7 +360,7 @@ def rela_merge(x, hid, f, B, H, W, Cc, rects, nvalid, poison, max_objs, y, ln_st
         for t, n in ((ln2_gamma, "ln2_gamma"), (ln2_beta, "ln2_beta")):
             _req(t, F32, n, 8)
     check(_lib.lib().gl_rela_merge(x.data_ptr(), int(xf32), _ptr(hid), _ptr(ln_stats), _ptr(gamma), _ptr(beta), f.data_ptr(), B, H, W,
-                                   Cc, rects.data_ptr(), nvalid.data_ptr(), poison.data_ptr(), max_objs, y.data_ptr(), _ptr(ln2_gamma),
+                                   Cc, rects.data_ptr(), nvalid.data_ptr(), poison.data_ptr(), max_objs, int(slots), y.data_ptr(), _ptr(ln2_gamma),
                                    _ptr(ln2_beta), _ptr(ln2_out), _stream()),
           "gl_rela_merge")
     return y

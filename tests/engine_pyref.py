@@ -61,6 +61,7 @@ class PyRefEngine:
         # stream, and the ResBlock's first conv writing fp32
         self.precise, self.h1_f32 = True, True
         self.share_prefix = True              # gl_set_option 44
+        self.rela_compact = True              # gl_set_option 43
         # constant gates of rela_fuse, per-step gates of the fuser (scale * tanh(alpha))
         for l in self.st_layers:
             t = l.prefix + ".transformer_blocks.0"
@@ -129,16 +130,20 @@ class PyRefEngine:
         # --- integer rectangles per resolution (host, fp32; attention.py:321-346)
         bx, mk = boxes.cpu().numpy(), masks.cpu().numpy()
         seen = set()
+        nv_max = 0
         for level_hw in self._st_resolutions(hw):
             if level_hw in seen:
                 continue
             seen.add(level_hw)
             rects, nvalid, poison = host.box_rects(bx, mk, level_hw, level_hw)
+            nv_max = max(nv_max, int(nvalid.max()) if nvalid.size else 0)
             # pooled (address-stable) buffers, so captured graphs stay valid across images
             for nm, arr in (("rects", rects), ("nvalid", nvalid), ("poison", poison)):
                 t = self.buf(f"cond.{nm}.{level_hw}", arr.shape, torch.int32)
                 t.copy_(torch.from_numpy(arr))
                 c[f"{nm}.{level_hw}"] = t
+        # rows per sample of the relation chain (engine.hip: rel_slots): the largest nvalid, rounded up to 8
+        c["ms"] = min(mo, max(8, (nv_max + 7) & ~7)) if self.rela_compact else mo
         self.cond = c
         torch.cuda.current_stream().synchronize()
 
@@ -284,28 +289,29 @@ class PyRefEngine:
         r = t + ".rela_fuse"
         rects, nvalid, poison = c[f"rects.{side}"], c[f"nvalid.{side}"], c[f"poison.{side}"]
         stats = self.buf("st.lnstats", (M, 2), F32)
-        Mo = Bn * mo
+        ms = c["ms"]
+        Mo = Bn * ms
         fn = self.buf("rl.ln", (Mo, C))
         if self.precise:     # LayerNorm3 never materialised: statistics only, box means of LN3(x) in fp32 from the stream
             ops.layernorm_stats(x, stats)
             feat = ops.rela_pool_ln3(x, stats, W[r + ".norm3.g"], W[r + ".norm3.b"], Bn, side, side, C, rects, nvalid, poison, mo,
-                                     self.buf("rl.feat", (Mo, C)), ln_gamma=W[r + ".norm1.g"], ln_beta=W[r + ".norm1.b"], ln_out=fn)
+                                     self.buf("rl.feat", (Mo, C)), ln_gamma=W[r + ".norm1.g"], ln_beta=W[r + ".norm1.b"], ln_out=fn, slots=ms)
         else:
             hid = ops.layernorm(x, self.buf("st.hid", (M, C)), W[r + ".norm3.g"], W[r + ".norm3.b"], Bn, N, stats=stats)
             feat = ops.rela_pool(hid, Bn, side, side, C, rects, nvalid, poison, mo, self.buf("rl.feat", (Mo, C)),
-                                 ln_gamma=W[r + ".norm1.g"], ln_beta=W[r + ".norm1.b"], ln_out=fn)
+                                 ln_gamma=W[r + ".norm1.g"], ln_beta=W[r + ".norm1.b"], ln_out=fn, slots=ms)
         q = ops.gemm(fn, W[r + ".attn.q.w"], self.buf("rl.q", (Mo, C)))
         kv = c[f"kvrel.{li}"]
         ar = self.buf("rl.att", (Mo, C))
-        ops.attention(q, mo * C, C, kv, R * 2 * C, 2 * C, c[f"vtrel.{li}"], ar, mo * C, C, Bn, H, d, mo, R, d ** -0.5, q_prescaled=True)
+        ops.attention(q, ms * C, C, kv, R * 2 * C, 2 * C, c[f"vtrel.{li}"], ar, ms * C, C, Bn, H, d, ms, R, d ** -0.5, q_prescaled=True)
         f1 = ops.gemm(ar, W[r + ".attn.o.w"], self.buf("rl.f1", (Mo, C)), W[r + ".attn.o.b"], EPI_GATE_RES, res=feat,
                       gate=self._gates[r + ".tanh_attn"])
-        fn2 = ops.layernorm(f1, self.buf("rl.ln", (Mo, C)), W[r + ".norm2.g"], W[r + ".norm2.b"], Bn, mo)
+        fn2 = ops.layernorm(f1, self.buf("rl.ln", (Mo, C)), W[r + ".norm2.g"], W[r + ".norm2.b"], Bn, ms)
         hg = ops.gemm(fn2, W[r + ".ff.ff1.w"], self.buf("rl.ffh", (Mo, 4 * C)), W[r + ".ff.ff1.b"], EPI_GEGLU)
         f2 = ops.gemm(hg, W[r + ".ff.ff2.w"], self.buf("rl.f2", (Mo, C)), W[r + ".ff.ff2.b"], EPI_GATE_RES, res=f1,
                       gate=self._gates[r + ".tanh_dense"])
         x = ops.rela_merge(x, None, f2, Bn, side, side, C, rects, nvalid, poison, mo, nxt(x), ln_stats=stats,
-                           gamma=W[r + ".norm3.g"], beta=W[r + ".norm3.b"])
+                           gamma=W[r + ".norm3.g"], beta=W[r + ".norm3.b"], slots=ms)
         # --- attn2: text cross-attention with hoisted K/V (attention.py:400)
         n = ops.layernorm(x, self.buf("st.ln", (M, C)), W[t + ".norm2.g"], W[t + ".norm2.b"], Bn, N)
         q2 = ops.gemm(n, W[t + ".attn2.q.w"], self.buf("st.q2", (M, C)))
@@ -434,7 +440,7 @@ class PyRefEngine:
         if not self.use_graphs:
             self._launch_forward(x_static, t_buf, reps, fuser_on, sd_conv, eps_out, uniform_t)
             return eps_out
-        key = (Bn, side, c["R"], c["Lc"], c["mo"], fuser_on, sd_conv, reps, eps_out.data_ptr(), tuple(x_lat.shape), self.precise, self.h1_f32,
+        key = (Bn, side, c["R"], c["Lc"], c["mo"], c["ms"], fuser_on, sd_conv, reps, eps_out.data_ptr(), tuple(x_lat.shape), self.precise, self.h1_f32,
                self.share_prefix, uniform_t)
         g = self._graphs.get(key)
         if g is None:

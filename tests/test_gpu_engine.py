@@ -334,3 +334,32 @@ def test_shared_cond_uncond_prefix_matches_python_sequence_and_the_unshared_forw
     tt = torch.tensor([481.0, 481.0, 481.0, 481.0])
     c = eng.forward(x, tt, 0.0, True, 2).clone()
     assert same(c, ref.forward(x, tt, 0.0, True, 2).clone()) and float((c - b).norm() / b.norm()) < 1e-6
+
+
+def test_relation_chain_on_used_rows_matches_python_sequence_and_the_30_row_chain():
+    """gl_set_option 43 (default on): the relation chain (norm1 / cross-attention / FeedForward of rela_fuse) runs on max nvalid (rounded
+    up to 8) rows per sample instead of all 30 (attention.py:348-351 computes 30, uses nvalid).  Bitwise equal to the Python launch sequence
+    doing the same; equal to the 30-row chain up to the tile / split-K choice of GEMMs with fewer rows; 26 boxes fall back to 30 rows."""
+    eng, ref = engines(TINY)
+    B, hw = 2, 16
+    z = torch.zeros_like
+    cat = lambda p, q: torch.cat([p, q], 0)
+    try:
+        for n_boxes in (3, 11, 26):
+            inp = {k: T(v) for k, v in recipe.synth_inputs(TINY, B, hw, n_boxes=n_boxes, n_rel=3, seed=40 + n_boxes).items()}
+            x = inp["x"].to(DEV)
+            outs = []
+            for opt in (1, 0):
+                ops.set_option(43, opt)
+                ref.rela_compact = bool(opt)
+                for e in (eng, ref):
+                    e.set_conditioning(cat(inp["context"], inp["uc"]), cat(inp["relations"], inp["relations"]), cat(inp["boxes"], z(inp["boxes"])),
+                                       cat(inp["masks"], z(inp["masks"])), cat(inp["positive_embeddings"], z(inp["positive_embeddings"])), hw)
+                a = eng.forward(x, 481.0, 1.0, False, 2).clone()
+                assert same(a, ref.forward(x, 481.0, 1.0, False, 2).clone()), (n_boxes, opt)
+                outs.append(a)
+            r = float((outs[0] - outs[1]).norm() / outs[1].norm())
+            assert r < 2e-4, (n_boxes, r)
+    finally:
+        ops.set_option(43, 1)
+        ref.rela_compact = True

@@ -922,6 +922,45 @@ def test_rela_pool_on_the_fp32_stream_and_layernorm_stats(C, hw):
     assert float((fn.float() - fn_sep.float()).abs().max()) < 4e-3
 
 
+@pytest.mark.parametrize("C,hw,slots", [(320, 16, 8), (640, 8, 16), (64, 12, 8)])
+def test_rela_chain_rows_per_sample(C, hw, slots):
+    """ABI 13: ``slots`` rows per sample for feat / ln_out / f while rects keep max_objs = 30 slots and 1/30 stays the divisor: the pooled
+    rows and the merged stream are BITWISE those of the 30-row form (rows are independent; the reference computes all 30, attention.py:348-351)."""
+    B, mo = 3, 30
+    boxes = np.zeros((B, mo, 4), np.float32)
+    masks = np.zeros((B, mo), np.float32)
+    boxes[0, :4] = [(0.0, 0.0, 0.5, 0.5), (0.25, 0.25, 1.0, 1.0), (0.6, 0.1, 0.9, 0.45), (0.13, 0.55, 0.41, 0.99)]
+    masks[0, :4] = 1
+    boxes[1, :7] = [(0.1 * i, 0.05 * i, 0.1 * i + 0.4, 0.05 * i + 0.5) for i in range(7)]
+    masks[1, :7] = 1                                   # sample 2: no boxes at all (the uncond half)
+    rects, nvalid, poison = host.box_rects(boxes, masks, hw, hw)
+    assert int(nvalid.max()) <= slots
+    dr, dn, dp = (torch.from_numpy(a).to(DEV) for a in (rects, nvalid, poison))
+    x = (rnd(f"sx{C}{hw}", (B * hw * hw, C)) * 1.7 + 0.4).to(DEV)
+    g3, b3 = (1 + 0.1 * rnd(f"sg{C}", (C,))).to(DEV), (0.1 * rnd(f"sb{C}", (C,))).to(DEV)
+    g1, b1 = (1 + 0.1 * rnd(f"s1g{C}", (C,))).to(DEV), (0.1 * rnd(f"s1b{C}", (C,))).to(DEV)
+    stats = torch.empty(B * hw * hw, 2, dtype=torch.float32, device=DEV)
+    ops.layernorm_stats(x, stats)
+    out = {}
+    for ms in (mo, slots):
+        feat = torch.full((B * ms + 1, C), 7.0, dtype=torch.float16, device=DEV)
+        fn = torch.full((B * ms, C), 7.0, dtype=torch.float16, device=DEV)
+        ops.rela_pool_ln3(x, stats, g3, b3, B, hw, hw, C, dr, dn, dp, mo, feat[:B * ms], ln_gamma=g1, ln_beta=b1, ln_out=fn, slots=ms if ms != mo else 0)
+        assert float((feat[B * ms:].float() - 7.0).abs().max()) == 0.0                                  # nothing past the last row
+        f = (feat[:B * ms].float() * 0.5 + fn.float()).half()                                            # stand-in for the chain's output rows
+        y = torch.empty_like(x)
+        ops.rela_merge(x, None, f, B, hw, hw, C, dr, dn, dp, mo, y, ln_stats=stats, gamma=g3, beta=b3, slots=ms if ms != mo else 0)
+        g2, b2 = g1, b1
+        y2, ln2 = torch.empty_like(x), torch.empty(B * hw * hw, C, dtype=torch.float16, device=DEV)
+        ops.rela_merge(x, None, f, B, hw, hw, C, dr, dn, dp, mo, y2, ln_stats=stats, gamma=g3, beta=b3, ln2_gamma=g2, ln2_beta=b2, ln2_out=ln2,
+                       slots=ms if ms != mo else 0)
+        out[ms] = (feat[:B * ms].view(B, ms, C)[:, :slots].clone(), fn.view(B, ms, C)[:, :slots].clone(), y, y2, ln2)
+    for a, b in zip(out[mo], out[slots]):
+        assert torch.equal(a, b)
+    with pytest.raises(Exception):
+        ops.rela_merge(x, None, f, B, hw, hw, C, dr, dn, dp, mo, y, ln_stats=stats, gamma=g3, beta=b3, slots=mo + 1)
+
+
 def test_layernorm_fp32_second_source_and_fp32_rowbias():
     """round 4: the fuser's LayerNorm over [x ; objs] with objs in fp32 (gl_layernorm x_f32 bit 2), and GL_EPI_ROWBIAS with an fp32 row bias
     (the emb_layers output): both against torch fp32 on the UNROUNDED second operand."""

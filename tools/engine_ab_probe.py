@@ -40,10 +40,16 @@ if any(o is None for _, o in variants):
     from engine_pyref import PyRefEngine
     engines["pyref"] = PyRefEngine(P)
 x = inp["x"].to(dev)
-for e in engines.values():
+
+
+def condition(e):
     e.set_conditioning(cat(inp["context"], inp["uc"]), cat(inp["relations"], inp["relations"]), cat(inp["boxes"], z(inp["boxes"])),
                        cat(inp["masks"], z(inp["masks"])), cat(inp["positive_embeddings"], z(inp["positive_embeddings"])), 64)
-DEFAULTS = {17: 1, 21: 1, 13: 3, 7: 300, 8: 1, 5: -1, 6: 16, 3: 0, 10: -1, 2: 0, 4: 400, 16: 16, 23: 1, 24: 64, 25: 1, 27: 1, 29: 1, 30: 1, 31: 200, 33: 0, 34: 11, 35: 5, 37: 1, 41: 1, 42: 1, 44: 1, 46: 11, 47: 100}
+
+
+for e in engines.values():
+    condition(e)
+DEFAULTS = {17: 1, 21: 1, 13: 3, 7: 300, 8: 1, 5: -1, 6: 16, 3: 0, 10: -1, 2: 0, 4: 400, 16: 16, 23: 1, 24: 64, 25: 1, 27: 1, 29: 1, 30: 1, 31: 200, 33: 0, 34: 11, 35: 5, 37: 1, 41: 1, 42: 1, 43: 1, 44: 1, 46: 11, 47: 100}
 res = {n: {1.0: [], 0.0: []} for n, _ in variants}
 launches = {}
 for rnd in range(5):
@@ -51,6 +57,8 @@ for rnd in range(5):
         e = engines["pyref"] if opts is None else eng
         for k, v in (opts or []):
             ops.set_option(k, v)
+        if opts is not None:
+            condition(e)                 # some options act when the conditioning is set (key 43: rows of the relation chain)
         for fs in (1.0, 0.0):
             e.forward(x, 481.0, fs, False, 2)          # (re-)capture under these options
             torch.cuda.synchronize()
