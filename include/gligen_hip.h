@@ -496,6 +496,9 @@ int gl_sizeof_gn_args(void);
  * conditioning-dependent op -- conv_in, the first ResBlock, proj_in .. attn1 of the first transformer block -- ONCE on the shared
  * latents and duplicates it for the uncond half (1 default; 0 = both halves computed; results equal up to the tile / split-K choice
  * of the half-sized launches).
+ * key 43 = the relation chain of rela_fuse (attention.py:348-351) runs on max_b nvalid[b] rows per sample (rounded up to 8) instead of all
+ * max_objs = 30 (1 default; read when gl_set_conditioning runs, which then copies the nvalid counts back to the host once); the used rows
+ * are unchanged up to the tile / split-K choice of GEMMs with fewer rows.
  * key 46 = half-height (128-row) tiles of the 8-wave GEMM / conv kernel where the 256-row grid would cover at most half the chip (32x32
  * maps and below at 2B = 8): bit 0 = convs whose 256-row plan leaves <= 16 K-tiles per split-K slice, bit 1 = plain GEMMs, bit 2 = every
  * conv (A/B), bit 3 = multi-round plain GEMMs whose 256-row grid ends in a mostly empty round while the 128-row grid fills its rounds;
