@@ -42,7 +42,42 @@ MFMA_PEAK_TFLOPS = 2500.0
 CONFIGS = {2: (1, 4, 64, 8), 3: (2, 2, 96, 16), 4: (3, 8, 64, 8), 5: (4, 16, 64, 8)}
 
 
-def random_clip_vit_l14_state_dict(dev, gen):
+def conditioning_encode_ms(dev, B, boxes, rank):
+    """f-2 timed beside the step, per rank: what interface.prepare_conditioning / get_clip_features_batched run on the HIP text
+    tower for one batch -- B captions + the empty prompt + B x 3 relation phrases as 77-token rows (last_hidden_state), and the B x boxes
+    grounding phrases as short rows (pooler_output) -- on random-init weights of openai/clip-vit-large-patch14's text tower and synthetic token ids
+    (tokenisation is host string work and not part of it).  The benchmark step itself starts from conditioning TENSORS, as the metric does."""
+    from layoutllm_t2i_amd.clip import ClipTowers
+    g = torch.Generator(device=dev)
+    g.manual_seed(977 + rank)
+    sd = {k: v for k, v in random_clip_vit_l14_state_dict(dev, g, vision=False).items()}
+    towers = ClipTowers(sd, text_heads=12, device=dev)
+
+    def ids(n, length, lo, hi):
+        t = torch.randint(1, 49406, (n, length), generator=g, device=dev)
+        t[:, 0] = 49406
+        for r_ in range(n):
+            e_ = lo + (r_ * 5) % max(1, hi - lo)
+            t[r_, e_:] = 49407
+        return t.cpu()
+    rows77 = ids(B + 1 + 3 * B, 77, 4, 40)
+    phrases = ids(B * boxes, 8, 2, 7)
+    ts = []
+    for it in range(4):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        towers.text_hidden_states(rows77)
+        towers.text_hidden_states(phrases)
+        e1.record()
+        torch.cuda.synchronize()
+        if it:
+            ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    return {"ms_per_batch": round(ts[len(ts) // 2], 2), "rows_77_tokens": int(rows77.shape[0]), "phrase_rows": int(phrases.shape[0]),
+            "note": "HIP CLIP text tower (random-init ViT-L/14 text weights, synthetic ids), this rank, outside the timed step"}
+
+
+def random_clip_vit_l14_state_dict(dev, gen, vision=True):
     """Random-init weights with transformers.CLIPModel's key names and openai/clip-vit-large-patch14's shapes (vision 24 x 1024 /
     16 heads / 4096, 257 positions; text 12 x 768 / 12 heads / 3072, 77 positions, vocab 49408; projection 768)."""
     sd = {}
@@ -57,14 +92,17 @@ def random_clip_vit_l14_state_dict(dev, gen):
                 sd[f"{p}.self_attn.{w}.weight"], sd[f"{p}.self_attn.{w}.bias"] = r(c, c) * (0.7 / c ** 0.5), 0.02 * r(c)
             sd[f"{p}.mlp.fc1.weight"], sd[f"{p}.mlp.fc1.bias"] = r(inter, c) / c ** 0.5, 0.02 * r(inter)
             sd[f"{p}.mlp.fc2.weight"], sd[f"{p}.mlp.fc2.bias"] = r(c, inter) * (0.5 / inter ** 0.5), 0.02 * r(c)
-    tower("vision_model", 24, 1024, 4096)
+    if vision:
+        tower("vision_model", 24, 1024, 4096)
     tower("text_model", 12, 768, 3072)
-    sd["vision_model.embeddings.patch_embedding.weight"] = r(1024, 3, 14, 14) / 588 ** 0.5
-    sd["vision_model.embeddings.class_embedding"] = r(1024)
-    sd["vision_model.embeddings.position_embedding.weight"] = 0.3 * r(257, 1024)
-    for ln, c in (("vision_model.pre_layrnorm", 1024), ("vision_model.post_layernorm", 1024), ("text_model.final_layer_norm", 768)):
+    if vision:
+        sd["vision_model.embeddings.patch_embedding.weight"] = r(1024, 3, 14, 14) / 588 ** 0.5
+        sd["vision_model.embeddings.class_embedding"] = r(1024)
+        sd["vision_model.embeddings.position_embedding.weight"] = 0.3 * r(257, 1024)
+    for ln, c in ((("vision_model.pre_layrnorm", 1024), ("vision_model.post_layernorm", 1024)) if vision else ()) + (("text_model.final_layer_norm", 768),):
         sd[ln + ".weight"], sd[ln + ".bias"] = 1 + 0.1 * r(c), 0.05 * r(c)
-    sd["visual_projection.weight"] = r(768, 1024) / 32.0
+    if vision:
+        sd["visual_projection.weight"] = r(768, 1024) / 32.0
     sd["text_model.embeddings.token_embedding.weight"] = 0.5 * r(49408, 768)
     sd["text_model.embeddings.position_embedding.weight"] = 0.3 * r(77, 768)
     sd["text_projection.weight"] = r(768, 768) / 768 ** 0.5
@@ -392,6 +430,8 @@ def main():
         "roofline": roofline,
         "setup_s": round(setup_s, 1),
     }
+    if not args.tiny:
+        result["conditioning_encode"] = conditioning_encode_ms(dev, B, args.boxes, rank)
     if bcast_ms is not None:
         result["weight_broadcast_ms"] = round(bcast_ms, 1)
         result["weight_bytes"] = packed.nbytes()
