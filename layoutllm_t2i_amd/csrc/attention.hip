@@ -428,8 +428,9 @@ template <int DQK>
 int launch_attn_auto(const gl_attn_args& a, hipStream_t st) {
     if constexpr (DQK <= 80) {
         // 8 waves (256 queries) per block halve the K / V^T tile traffic per query: 355 -> 326 us at d = 40,
-        // N = 4096 (with the XCD-aware block order); no effect on the 77-key text cross-attention
-        if ((g_attn_qt2 == 3 && a.Nq >= 256) || (g_attn_qt2 == 0 && a.Nq >= 512 && a.Nk >= 512))
+        // N = 4096 (with the XCD-aware block order)
+        // (round 4: also for the 77-key text cross-attention -- forward -0.03 ms; key 3 = 5 restores the Nk >= 512 condition)
+        if ((g_attn_qt2 == 3 && a.Nq >= 256) || (g_attn_qt2 == 0 && a.Nq >= 512) || (g_attn_qt2 == 5 && a.Nq >= 512 && a.Nk >= 512))
             return launch_attn<DQK, 1, 8>(a, st);
     }
     return launch_attn<DQK, 1>(a, st);
