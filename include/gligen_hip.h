@@ -85,10 +85,11 @@ typedef struct gl_gemm_args {
      * out but as gl_attention's V^T operand, vt[((b * vt_H + h) * vt_d + c) * vt_ld + key] with b = m / vt_rows,
      * key = m % vt_rows, (h, c) = divmod(n - vt_col0, vt_d).  fp16 row-major out, epi BIAS only, vt_col0 % 64 == 0. */
     void* vt;           int32_t vt_col0, vt_rows, vt_d, vt_ld, vt_H;
-    /* weight reuse along K (split-fp16 activations): with kwrap != 0 the weight is [N, kwrap] (row stride ldw) and
-     * column k of the product reads w[n * ldw + (k mod kwrap)], i.e. A = [hi | lo] (K = 2 * kwrap) is multiplied against
-     * [W | W] without storing W twice.  kwrap % 64 == 0, kwrap < K <= 2 * kwrap.  ldw == 0: the row stride is K (kwrap == 0)
-     * or kwrap.  gl_gemm only (ignored by gl_conv3x3). */
+    /* weight reuse along K (split-fp16 operands): with kwrap != 0 column k of the product reads w[n * ldw + k] for k < kwrap
+     * and w[n * ldw + k - kwrap] beyond (ONE step back).  K = 2 * kwrap: A = [hi | lo] is multiplied against [W | W] without storing W
+     * twice.  K = 3 * kwrap (ldw >= 2 * kwrap, weight rows [Whi | Wlo]): columns [0, kwrap) twice, then [kwrap, 2 * kwrap) -- with
+     * A = [xhi | xlo] and the second source a2 = xhi at ksplit = 2 * kwrap that is the three-pass product xhi.Whi + xlo.Whi + xhi.Wlo.
+     * kwrap % 64 == 0, kwrap < K <= 3 * kwrap.  ldw == 0: the row stride is K (kwrap == 0) or kwrap.  gl_gemm only (ignored by gl_conv3x3). */
     int32_t ldw, kwrap;
     int32_t rowbias_f32;                /* != 0: rowbias is fp32 [B, N] (ld_rowbias in floats) instead of fp16: the ResBlock's emb_layers output is
                                            added to the conv result unrounded (openaimodel.py:220-226) */
@@ -499,6 +500,9 @@ int gl_sizeof_gn_args(void);
  * key 43 = the relation chain of rela_fuse (attention.py:348-351) runs on max_b nvalid[b] rows per sample (rounded up to 8) instead of all
  * max_objs = 30 (1 default; read when gl_set_conditioning runs, which then copies the nvalid counts back to the host once); the used rows
  * are unchanged up to the tile / split-K choice of GEMMs with fewer rows.
+ * key 45 (with key 41) = the three kinds of 1x1 conv, whose weight rows are stored [Whi | Wlo] (Whi = fp16(W), Wlo = fp16(W - Whi)), add the
+ * third pass xhi.Wlo to xhi.Whi + xlo.Whi for launches of more than 1024 rows (1 default; 0 = the fp16 weight alone): the rounding of those
+ * weights is 57 % of the error of storing the UNet's weights in fp16.
  * key 46 = half-height (128-row) tiles of the 8-wave GEMM / conv kernel where the 256-row grid would cover at most half the chip (32x32
  * maps and below at 2B = 8): bit 0 = convs whose 256-row plan leaves <= 16 K-tiles per split-K slice, bit 1 = plain GEMMs, bit 2 = every
  * conv (A/B), bit 3 = multi-round plain GEMMs whose 256-row grid ends in a mostly empty round while the 128-row grid fills its rounds;

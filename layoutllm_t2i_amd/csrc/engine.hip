@@ -34,6 +34,7 @@ constexpr int64_t WS_BYTES = 96ll << 20; // split-K fp32 partial tiles
 #define g_precise gl_opt(41)      // default 1;                   // split-fp16 activations for the 1x1 convs + GroupNorm on the fp32 stream
 #define g_h1_f32 gl_opt(42)       // default 1;                   // with key 41: the ResBlock's first conv writes fp32 for out_layers' GroupNorm
 #define g_rela_compact gl_opt(43) // default 1;                   // the relation chain runs on max_b nvalid[b] (rounded up to 8) rows per sample instead of max_objs = 30
+#define g_w3 gl_opt(45)          // default 1;                   // with key 41: the 1x1 convs' third pass xhi.Wlo (weights stored [Whi | Wlo]) for launches of > 1024 rows
 #define g_share gl_opt(44)        // default 1;                   // 2B = [cond ; uncond] forwards: everything before the first conditioning-dependent op
                                                                   // (conv_in, the first ResBlock, proj_in .. attn1 of the first transformer) runs ONCE on
                                                                   // the B shared latents and is duplicated
@@ -201,6 +202,11 @@ void add_lin(gl_engine* e, const std::string& p, int64_t n, int64_t k, bool bias
     add_w(e, p + ".w", 0, {n, k});
     if (bias) add_w(e, p + ".b", 1, {n});
 }
+// the three kinds of 1x1 conv (skip_connection, proj_in, proj_out): weight rows [Whi | Wlo], Whi = fp16(W), Wlo = fp16(W - Whi)
+void add_lin_split(gl_engine* e, const std::string& p, int64_t n, int64_t k) {
+    add_w(e, p + ".w", 0, {n, 2 * k});
+    add_w(e, p + ".b", 1, {n});
+}
 void add_norm(gl_engine* e, const std::string& p, int64_t c) {
     add_w(e, p + ".g", 1, {c});
     add_w(e, p + ".b", 1, {c});
@@ -291,15 +297,15 @@ void build_table(gl_engine* e) {
             add_conv3(e, p + ".in_layers.2", l.cin, l.cout);
             add_norm(e, p + ".out_layers.0", l.cout);
             add_conv3(e, p + ".out_layers.3", l.cout, l.cout);
-            if (l.cin != l.cout) add_lin(e, p + ".skip_connection", l.cout, l.cin);
+            if (l.cin != l.cout) add_lin_split(e, p + ".skip_connection", l.cout, l.cin);
             e->emb_off[p] = off;
             off += l.cout;
         } else if (l.kind == ST) {
             const int C = l.cin;
             e->st_layers.push_back(l);
             add_norm(e, p + ".norm", C);
-            add_lin(e, p + ".proj_in", C, C);
-            add_lin(e, p + ".proj_out", C, C);
+            add_lin_split(e, p + ".proj_in", C, C);
+            add_lin_split(e, p + ".proj_out", C, C);
             const std::string t = p + ".transformer_blocks.0";
             add_w(e, t + ".attn1.qkv.w", 0, {3 * C, C});
             add_lin(e, t + ".attn1.o", C, C);
@@ -370,7 +376,7 @@ struct Run {
     int gemm(const void* a, int lda, const std::string& w, int M, void* out, int ldc, int out_mode = GL_OUT_F16_ROWMAJOR,
              const std::string& bias = "", int epi = GL_EPI_BIAS, const void* res = nullptr, int ldres = 0, int res_f32 = 0,
              const float* gate = nullptr, void* out2 = nullptr, int ldc2 = 0, const void* a2 = nullptr, int lda2 = 0, int ksplit = 0,
-             bool hilo_a = false) {
+             bool hilo_a = false, bool wsplit = false) {
         const WInfo* wi = e->wi(w);
         if (!wi) return GL_ERR_BAD_ARG;
         gl_gemm_args g{};
@@ -378,7 +384,16 @@ struct Run {
         g.w = e->W(w);
         g.bias = bias.empty() ? nullptr : e->Wf(bias);
         g.M = M; g.N = (int)wi->shape[0]; g.K = (int)wi->shape[1];
-        if (hilo_a) {           // A = [hi | lo] of the activation, both halves against the same weight (gl_gemm_args.kwrap)
+        if (wsplit) {           // weight rows [Whi | Wlo] (add_lin_split): the true K is half the stored row
+            const int Kc = g.K / 2;
+            g.ldw = g.K; g.K = Kc;
+            if (hilo_a) {       // x.W = xhi.Whi + xlo.Whi (+ xhi.Wlo: third K segment, A from the second source = the hi half again)
+                g.kwrap = Kc; g.K = 2 * Kc;
+                if (g_w3 && M > 1024 && a2 == nullptr) {
+                    g.K = 3 * Kc; g.a2 = a; g.lda2 = lda; g.ksplit = 2 * Kc;
+                }
+            }
+        } else if (hilo_a) {    // A = [hi | lo] of the activation, both halves against the same weight (gl_gemm_args.kwrap)
             g.kwrap = g.K; g.ldw = g.K; g.K = 2 * g.K;
         }
         g.epi = epi; g.out_mode = out_mode; g.out = out; g.ldc = ldc;
@@ -594,10 +609,10 @@ int res_block(Run& r, const LayerD& l, Stream2 h, const Stream2* skip, int skip_
         CKP(skb);
         if (precise) {
             CK(r.gemm(split, 2 * l.cin, p + ".skip_connection.w", M, skb, l.cout, GL_OUT_F32_ROWMAJOR, p + ".skip_connection.b", GL_EPI_BIAS, nullptr, 0, 0,
-                      nullptr, nullptr, 0, nullptr, 0, 0, true));
+                      nullptr, nullptr, 0, nullptr, 0, 0, true, true));
         } else {
             CK(r.gemm(h.h, c1, p + ".skip_connection.w", M, skb, l.cout, GL_OUT_F32_ROWMAJOR, p + ".skip_connection.b", GL_EPI_BIAS, nullptr, 0, 0, nullptr,
-                      nullptr, 0, skip ? skip->h : nullptr, skip_c, skip ? c1 : 0));
+                      nullptr, 0, skip ? skip->h : nullptr, skip_c, skip ? c1 : 0, false, true));
         }
         sk = skb;
     } else if (skip) {
@@ -639,11 +654,12 @@ int spatial_transformer(Run& r, const LayerD& l, int li, Stream2 xin, int side, 
             // Normalize on the fp32 stream, rows written as [hi | lo]; proj_in takes both halves against the same weight
             CK(r.gn(xin.f, C, nullptr, 0, 1, B1, N, p + ".norm", 1e-6f, 0, g0, 2 * C, g0 + C));
             CK(r.gemm(g0, 2 * C, p + ".proj_in.w", M1, x, C, GL_OUT_F32_ROWMAJOR, p + ".proj_in.b", GL_EPI_BIAS, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, 0,
-                      0, true));
+                      0, true, true));
         } else {
             CKP(xin.h);
             CK(r.gn(xin.h, C, nullptr, 0, 0, B1, N, p + ".norm", 1e-6f, 0, g0));
-            CK(r.gemm(g0, C, p + ".proj_in.w", M1, x, C, GL_OUT_F32_ROWMAJOR, p + ".proj_in.b"));
+            CK(r.gemm(g0, C, p + ".proj_in.w", M1, x, C, GL_OUT_F32_ROWMAJOR, p + ".proj_in.b", GL_EPI_BIAS, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, 0, 0,
+                      false, true));
         }
         // --- attn1 (attention.py:395)
         half_t* att1 = nullptr;
@@ -760,7 +776,7 @@ int spatial_transformer(Run& r, const LayerD& l, int li, Stream2 xin, int side, 
     CKP(out->f);
     if (need_h) CKP(out->h);
     return r.gemm(x16, precise ? 2 * C : C, p + ".proj_out.w", M, out->f, C, GL_OUT_F32_ROWMAJOR, p + ".proj_out.b", GL_EPI_RES, xin.f, C, 1, nullptr, out->h,
-                  C, nullptr, 0, 0, precise);
+                  C, nullptr, 0, 0, precise, true);
 }
 
 int launch_forward(gl_engine* e, int reps, bool fuser_on, bool sd_conv, bool uniform_t, hipStream_t st, int* n_launches) {

@@ -875,9 +875,12 @@ extern "C" int gl_gemm(const gl_gemm_args* a, void* stream) {
     if (!a || !a->a || !a->w || !a->out) return GL_ERR_BAD_ARG;
     ConvGeom cg{};
     gl_gemm_args g = *a;
-    if (g.kwrap != 0 && ((g.kwrap % 64) != 0 || g.kwrap >= g.K || g.K > 2 * g.kwrap)) return GL_ERR_BAD_ARG;
+    // kwrap: the weight column of K index k is k for k < kwrap and k - kwrap beyond (ONE step back): K = 2 * kwrap walks the same kwrap weight
+    // columns twice ([hi | lo] activations), K = 3 * kwrap walks columns [0, kwrap) twice and then [kwrap, 2 * kwrap) -- [Whi | Wlo] weight rows
+    // for the three-pass product xhi.Whi + xlo.Whi + xhi.Wlo, whose third A segment the caller supplies as the second source (a2 = xhi)
+    if (g.kwrap != 0 && ((g.kwrap % 64) != 0 || g.kwrap >= g.K || g.K > 3 * g.kwrap)) return GL_ERR_BAD_ARG;
     if (g.ldw == 0) g.ldw = g.kwrap != 0 ? g.kwrap : g.K;
-    if (g.ldw < (g.kwrap != 0 ? g.kwrap : g.K) || (g.ldw % 8) != 0) return GL_ERR_BAD_ARG;
+    if (g.ldw < (g.kwrap != 0 ? (g.K > 2 * g.kwrap ? 2 * g.kwrap : g.kwrap) : g.K) || (g.ldw % 8) != 0) return GL_ERR_BAD_ARG;
     return dispatch<false>(g, cg, (hipStream_t)stream);
 }
 

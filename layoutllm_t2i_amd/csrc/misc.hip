@@ -250,6 +250,7 @@ static gl_opts make_default_opts() {
     o.v[42] = 1;
     o.v[43] = 1;
     o.v[44] = 1;
+    o.v[45] = 1;
     o.v[46] = 11;
     o.v[47] = 100;
     return o;
@@ -261,7 +262,7 @@ int g_gl_option_epoch = 0;
 bool gl_opts_store(gl_opts& t, int key, int value) {
     switch (key) {
         case 2: case 3: case 4: case 6: case 7: case 8: case 10: case 13: case 17: case 20: case 21: case 23: case 24: case 25:
-        case 27: case 29: case 30: case 31: case 32: case 33: case 35: case 37: case 41: case 42: case 43: case 44: case 46: case 47:
+        case 27: case 29: case 30: case 31: case 32: case 33: case 35: case 37: case 41: case 42: case 43: case 44: case 45: case 46: case 47:
             t.v[key] = value;
             return true;
         case 5:                                  // < 0: the built-in thresholds (plain GEMM 300 tiles, conv 450)

@@ -114,10 +114,13 @@ def _fill_epilogue(g: GemmArgs, epi, out, N_out, bias, res, gate, rowbias, rows_
 
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias=None, epi: int = EPI_BIAS, res=None, gate=None,
          rowbias=None, rows_per_sample: int = 0, a2: Optional[torch.Tensor] = None, nchw_hw: int = 0, out16=None,
-         vt: Optional[torch.Tensor] = None, vt_col0: int = 0, vt_rows: int = 0, hilo_a: bool = False, hilo_out: bool = False) -> torch.Tensor:
+         vt: Optional[torch.Tensor] = None, vt_col0: int = 0, vt_rows: int = 0, hilo_a: bool = False, hilo_out: bool = False,
+         wsplit: int = 0) -> torch.Tensor:
     """out = [a | a2] @ w.T (+ epilogue).  a [M, K1], a2 [M, K2] (optional), w [N, K1+K2] fp16.
     ``hilo_a``: a is [M, 2K] = [hi | lo] of a split-fp16 activation and w [N, K] is used for both halves (gl_gemm_args.kwrap);
     ``hilo_out``: out is fp16 [M, 2N] = [hi | lo] of the result (GL_OUT_F16_HILO).
+    ``wsplit``: w is [N, 2K] = [Whi | Wlo] rows of a split-fp16 weight: 1 = use Whi only (K or, with hilo_a, 2K products), 2 = with hilo_a the
+    three-pass product xhi.Whi + xlo.Whi + xhi.Wlo (K index 3K; the third A segment is the hi half again, passed as the second source).
     ``vt`` [B, H, d, ldvt] fp16: columns [vt_col0, N) are written there as gl_attention's V^T operand (row m = sample
     m // vt_rows, key m % vt_rows) instead of to ``out`` (fused QKV projection)."""
     _req(a, F16, "a")
@@ -128,7 +131,18 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias=None, epi: in
         raise ValueError("w must be contiguous")
     g = GemmArgs()
     g.a, g.lda = a.data_ptr(), lda
-    if a2 is not None:
+    if wsplit:
+        if K % 2 or (wsplit == 2 and (not hilo_a or a2 is not None)):
+            raise ValueError("wsplit: w must be [N, 2K]; the three-pass form needs hilo_a and no second source")
+        K //= 2
+        g.ldw = 2 * K
+    if wsplit == 2:
+        if K1 != 2 * K:
+            raise ValueError(f"hilo_a: a has {K1} columns, expected 2 x K = {2 * K}")
+        g.kwrap = K
+        g.a2, g.lda2, g.ksplit = a.data_ptr(), lda, 2 * K
+        K = 3 * K
+    elif a2 is not None:
         _req(a2, F16, "a2")
         M2, K2, lda2 = _rows(a2, "a2")
         if M2 != M or K1 + K2 != K:
@@ -137,7 +151,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias=None, epi: in
     elif hilo_a:
         if K1 != 2 * K:
             raise ValueError(f"hilo_a: a has {K1} columns, expected 2 x K = {2 * K}")
-        g.kwrap, g.ldw = K, K
+        g.kwrap = K
+        if not wsplit:
+            g.ldw = K
         K = 2 * K
     elif K1 != K:
         raise ValueError(f"a has K={K1}, w has K={K}")

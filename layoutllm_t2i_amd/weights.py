@@ -167,6 +167,15 @@ def pack_state_dict(sd: Mapping[str, object], cfg: UNetConfig, device, sd_first_
         if bias:
             W[dst + ".b"] = g(p + ".bias").contiguous()
 
+    def lin_split(p):
+        """the three kinds of 1x1 conv: rows [Whi | Wlo], Whi = fp16(W), Wlo = fp16(W - Whi) (engine.hip add_lin_split; they carry 57 % of the
+        error of storing the weights in fp16, profiles/r4_weight_rounding_attribution.txt)"""
+        w32 = g(p + ".weight").reshape(g(p + ".weight").shape[0], -1).float()
+        hi = _h(w32)
+        lo = _h(w32 - hi.float())
+        W[p + ".w"] = torch.cat([hi, lo], 1).contiguous()
+        W[p + ".b"] = g(p + ".bias").contiguous()
+
     def norm(p):
         W[p + ".g"] = g(p + ".weight").contiguous()
         W[p + ".b"] = g(p + ".bias").contiguous()
@@ -208,15 +217,15 @@ def pack_state_dict(sd: Mapping[str, object], cfg: UNetConfig, device, sd_first_
             norm(p + ".out_layers.0")
             conv3(p + ".out_layers.3")
             if l.cin != l.cout:
-                lin(p + ".skip_connection")
+                lin_split(p + ".skip_connection")
             emb_w.append(g(p + ".emb_layers.1.weight"))
             emb_b.append(g(p + ".emb_layers.1.bias"))
             P.emb_offsets[p] = off
             off += l.cout
         elif l.kind == "st":
             norm(p + ".norm")
-            lin(p + ".proj_in")
-            lin(p + ".proj_out")
+            lin_split(p + ".proj_in")
+            lin_split(p + ".proj_out")
             t = p + ".transformer_blocks.0"
             self_attn(t + ".attn1", l.d_head)
             cross_attn(t + ".attn2", l.d_head)

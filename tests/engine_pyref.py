@@ -62,6 +62,7 @@ class PyRefEngine:
         self.precise, self.h1_f32 = True, True
         self.share_prefix = True              # gl_set_option 44
         self.rela_compact = True              # gl_set_option 43
+        self.w3 = True                        # gl_set_option 45
         # constant gates of rela_fuse, per-step gates of the fuser (scale * tanh(alpha))
         for l in self.st_layers:
             t = l.prefix + ".transformer_blocks.0"
@@ -87,6 +88,10 @@ class PyRefEngine:
 
     # ------------------------------------------------------------------ conditioning (once per image)
     @torch.no_grad()
+    def _w3(self, rows: int) -> int:
+        """engine.hip Run::gemm: the third pass xhi.Wlo for launches of more than 1024 rows (key 45)"""
+        return 2 if (self.w3 and rows > 1024) else 1
+
     def set_conditioning(self, context, relations, boxes, masks, positive_embeddings, hw: int) -> None:
         """context [Bn,77,ctx], relations [Bn,R,ctx], boxes [Bn,30,4], masks [Bn,30],
         positive_embeddings [Bn,30,in_dim]: fp32 tensors (any device).  Null grounding = zeros
@@ -209,9 +214,9 @@ class PyRefEngine:
         if l.cin != l.cout:
             skb = self.buf("rb.skip.f32", (Bn * HW, l.cout), F32)
             if self.precise:
-                sk = ops.gemm(split, W[p + ".skip_connection.w"], skb, W[p + ".skip_connection.b"], hilo_a=True)
+                sk = ops.gemm(split, W[p + ".skip_connection.w"], skb, W[p + ".skip_connection.b"], hilo_a=True, wsplit=self._w3(Bn * HW))
             else:
-                sk = ops.gemm(h16, W[p + ".skip_connection.w"], skb, W[p + ".skip_connection.b"], a2=s16)
+                sk = ops.gemm(h16, W[p + ".skip_connection.w"], skb, W[p + ".skip_connection.b"], a2=s16, wsplit=1)
         else:
             assert skip is None
             sk = h32
@@ -259,10 +264,10 @@ class PyRefEngine:
         xa1, xb1 = xa[:M1], xb[:M1]
         if self.precise:     # Normalize on the fp32 stream, [hi | lo] rows, both halves against proj_in's weight
             g0 = self._groupnorm(xin32[:M1], None, B1, N, p + ".norm", 1e-6, False, "st.gn", hilo=True)
-            x = ops.gemm(g0, W[p + ".proj_in.w"], xa1, W[p + ".proj_in.b"], hilo_a=True)
+            x = ops.gemm(g0, W[p + ".proj_in.w"], xa1, W[p + ".proj_in.b"], hilo_a=True, wsplit=self._w3(g0.shape[0]))
         else:
             g0 = self._groupnorm(xin16[:M1], None, B1, N, p + ".norm", 1e-6, False, "st.gn")
-            x = ops.gemm(g0, W[p + ".proj_in.w"], xa1, W[p + ".proj_in.b"])
+            x = ops.gemm(g0, W[p + ".proj_in.w"], xa1, W[p + ".proj_in.b"], wsplit=1)
         # --- attn1 (attention.py:395)
         n1 = ops.layernorm(x, self.buf("st.ln", (M1, C)), W[t + ".norm1.g"], W[t + ".norm1.b"], B1, N)
         att = self._self_attention(n1, N, N, N, C, d, t + ".attn1", "st.sa", Bn=B1)
@@ -324,7 +329,8 @@ class PyRefEngine:
         x16 = self._feed_forward(n3, x, t + ".ff", M, C, self.buf("st.x6", (M, 2 * C if self.precise else C)), hilo_out=self.precise)
         # --- proj_out + residual (attention.py:444-446)
         o32, o16 = self._stream(out_tag, M, C, need_h)
-        ops.gemm(x16, W[p + ".proj_out.w"], o32, W[p + ".proj_out.b"], EPI_RES, res=xin32, out16=o16, hilo_a=self.precise)
+        ops.gemm(x16, W[p + ".proj_out.w"], o32, W[p + ".proj_out.b"], EPI_RES, res=xin32, out16=o16, hilo_a=self.precise,
+                 wsplit=self._w3(x16.shape[0]) if self.precise else 1)
         return o32, o16
 
     # ------------------------------------------------------------------ one forward (eager launch sequence)
@@ -441,7 +447,7 @@ class PyRefEngine:
             self._launch_forward(x_static, t_buf, reps, fuser_on, sd_conv, eps_out, uniform_t)
             return eps_out
         key = (Bn, side, c["R"], c["Lc"], c["mo"], c["ms"], fuser_on, sd_conv, reps, eps_out.data_ptr(), tuple(x_lat.shape), self.precise, self.h1_f32,
-               self.share_prefix, uniform_t)
+               self.share_prefix, self.w3, uniform_t)
         g = self._graphs.get(key)
         if g is None:
             # warm-up run allocates every pooled buffer, then capture the same launch sequence

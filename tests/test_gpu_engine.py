@@ -271,6 +271,7 @@ def test_precision_modes_match_python_sequence_and_precise_is_closer_to_the_orac
                      context_dim=128, pos_in_dim=64, pos_out_dim=128)
     dev = torch.device(DEV)
     sd = recipe.state_dict(cfg, 3)
+    sd = {k: (np.asarray(v).astype(np.float16).astype(np.float32) if np.asarray(v).ndim >= 2 else np.asarray(v)) for k, v in sd.items()}     # fp16-representable matrices on both sides
     P = pack_state_dict(sd, cfg, dev, recipe.sd_first_conv(cfg, 3))
     eng, ref = UNetEngine(P), PyRefEngine(P)
     B, hw = 2, 16
@@ -363,3 +364,31 @@ def test_relation_chain_on_used_rows_matches_python_sequence_and_the_30_row_chai
     finally:
         ops.set_option(43, 1)
         ref.rela_compact = True
+
+
+def test_third_pass_of_the_1x1_convs_matches_python_sequence_and_moves_towards_fp32_weights():
+    """gl_set_option 45 (default on, with key 41): skip_connection / proj_in / proj_out store [Whi | Wlo] rows and launches of more than 1024
+    rows add the pass xhi.Wlo.  Bitwise equal to the Python launch sequence either way; with fp16-representable weights (Wlo = 0) the third
+    pass adds exact zeros, so the outputs with and without it are bitwise equal."""
+    eng, ref = engines(TINY)
+    B, hw = 2, 32                      # 2B * 32 * 32 = 4096 rows at the first level
+    inp = {k: T(v) for k, v in recipe.synth_inputs(TINY, B, hw, n_boxes=4, n_rel=3, seed=77).items()}
+    z = torch.zeros_like
+    cat = lambda p, q: torch.cat([p, q], 0)
+    for e in (eng, ref):
+        e.set_conditioning(cat(inp["context"], inp["uc"]), cat(inp["relations"], inp["relations"]), cat(inp["boxes"], z(inp["boxes"])),
+                           cat(inp["masks"], z(inp["masks"])), cat(inp["positive_embeddings"], z(inp["positive_embeddings"])), hw)
+    x = inp["x"].to(DEV)
+    outs = []
+    try:
+        for opt in (1, 0):
+            ops.set_option(45, opt)
+            ref.w3 = bool(opt)
+            a = eng.forward(x, 481.0, 1.0, False, 2).clone()
+            assert same(a, ref.forward(x, 481.0, 1.0, False, 2).clone()), opt
+            outs.append(a)
+    finally:
+        ops.set_option(45, 1)
+        ref.w3 = True
+    r = float((outs[0] - outs[1]).norm() / outs[1].norm())
+    assert 1e-6 < r < 3e-3, r              # the recipe weights are fp32: the third pass moves the result at the weight-rounding level

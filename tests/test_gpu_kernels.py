@@ -735,6 +735,41 @@ def test_gemm_split_fp16_activation(M, N, K, res):
     assert e_split < 2e-6 and e_plain > 20 * e_split, (e_split, e_plain)
 
 
+@pytest.mark.parametrize("M,N,K,res", [(300, 320, 320, False), (8192, 640, 640, True), (2048, 1280, 2560, True), (33000, 320, 320, True), (2048, 1280, 1920, False)])
+def test_gemm_split_fp16_activation_and_weight(M, N, K, res):
+    """wsplit: weight rows [Whi | Wlo] of an UNROUNDED fp32 weight.  wsplit = 1 uses Whi only and must equal the plain hilo_a product on a
+    [N, K] copy of Whi bit for bit; wsplit = 2 is the three-pass product xhi.Whi + xlo.Whi + xhi.Wlo (K index 3K: kwrap steps the weight
+    column back once, the third A segment comes in as the second source) -- against the fp64 product of the unrounded x and W the error drops
+    from the fp16-weight level (~2e-4) to fp32-accumulation level.  4-wave, 8-wave (both tile heights), split-K dispatch."""
+    x = rnd(f"wa{M}{K}", (M, K)) * 1.7 + 0.4
+    w = rnd(f"ww{N}{K}", (N, K), 1 / math.sqrt(K))
+    b = rnd(f"wb{N}", (N,), 0.1)
+    hi, whi = x.half(), w.half()
+    lo, wlo = (x - hi.float()).half(), (w - whi.float()).half()
+    a = torch.cat([hi, lo], 1).to(DEV)
+    w2 = torch.cat([whi, wlo], 1).contiguous().to(DEV)
+    r = rnd(f"wr{M}{N}", (M, N)) if res else None
+    kw = dict(res=r.to(DEV)) if res else {}
+    epi = EPI_RES if res else EPI_BIAS
+    two = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm(a, whi.to(DEV), two, b.to(DEV), epi, hilo_a=True, **kw)
+    two_w = torch.empty_like(two)
+    ops.gemm(a, w2, two_w, b.to(DEV), epi, hilo_a=True, wsplit=1, **kw)
+    assert torch.equal(two, two_w)
+    plain_w = torch.empty_like(two)
+    ops.gemm(hi.to(DEV), w2, plain_w, b.to(DEV), epi, wsplit=1, **kw)            # fp16 A against Whi through the wide rows
+    plain = torch.empty_like(two)
+    ops.gemm(hi.to(DEV), whi.to(DEV), plain, b.to(DEV), epi, **kw)
+    assert torch.equal(plain, plain_w)
+    three = torch.empty_like(two)
+    ops.gemm(a, w2, three, b.to(DEV), epi, hilo_a=True, wsplit=2, **kw)
+    ref = F.linear(x.double(), w.double(), b.double()).float() + (r if res else 0)
+    e3 = float((three.cpu() - ref).norm() / ref.norm())
+    e2 = float((two.cpu() - ref).norm() / ref.norm())
+    print(f"[gemm_hilo_w_{M}x{N}x{K}] rel_l2 three-pass={e3:.2e} two-pass (fp16 weight)={e2:.2e}")
+    assert e3 < 2e-6 and e2 > 20 * e3, (e3, e2)
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 320, 1280), (4096, 640, 2560), (512, 1280, 5120)])
 def test_gemm_hilo_output(M, N, K):
     """GL_OUT_F16_HILO: the epilogue writes hi = fp16(v) and lo = fp16(v - hi) N columns apart (bias + fp32 residual epilogue)."""

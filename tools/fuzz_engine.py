@@ -67,6 +67,8 @@ while time.time() - t0 < budget:
     lr = random.Random(layout_seed)
     try:
         sd = recipe.state_dict(cfg, seed)
+        # arithmetic parity: fp16-representable weight matrices on both sides (the engine's split 1x1-conv weights then have Wlo = 0)
+        sd = {k: (np.asarray(v).astype(np.float16).astype(np.float32) if np.asarray(v).ndim >= 2 else np.asarray(v)) for k, v in sd.items()}
         fc = recipe.sd_first_conv(cfg, seed)
         m = UNetModel(cfg, sd, device=DEV, sd_first_conv=fc)
         m.grounding_tokenizer_input = GroundingNetInput()
