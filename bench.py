@@ -480,7 +480,7 @@ def main():
         from layoutllm_t2i_amd import ops as _op2
         _op2.set_option(45, 0)
         e_on_hi = eng.forward(inp["x"], 481.0, 1.0, False, 2).clone()
-        _op2.set_option(45, 1)
+        _op2.set_option(45, 1024)
         for kv in args.opt:                          # (restore a --opt 45=... given on the command line)
             if kv.split("=")[0] == "45":
                 _op2.set_option(45, int(kv.split("=")[1]))

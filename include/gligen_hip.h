@@ -501,7 +501,7 @@ int gl_sizeof_gn_args(void);
  * max_objs = 30 (1 default; read when gl_set_conditioning runs, which then copies the nvalid counts back to the host once); the used rows
  * are unchanged up to the tile / split-K choice of GEMMs with fewer rows.
  * key 45 (with key 41) = the three kinds of 1x1 conv, whose weight rows are stored [Whi | Wlo] (Whi = fp16(W), Wlo = fp16(W - Whi)), add the
- * third pass xhi.Wlo to xhi.Whi + xlo.Whi for launches of more than 1024 rows (1 default; 0 = the fp16 weight alone): the rounding of those
+ * third pass xhi.Wlo to xhi.Whi + xlo.Whi for launches of more than this many rows (default 1024, the minimum; 0 = the fp16 weight alone): the rounding of those
  * weights is 57 % of the error of storing the UNet's weights in fp16.
  * key 46 = half-height (128-row) tiles of the 8-wave GEMM / conv kernel where the 256-row grid would cover at most half the chip (32x32
  * maps and below at 2B = 8): bit 0 = convs whose 256-row plan leaves <= 16 K-tiles per split-K slice, bit 1 = plain GEMMs, bit 2 = every

@@ -34,7 +34,7 @@ constexpr int64_t WS_BYTES = 96ll << 20; // split-K fp32 partial tiles
 #define g_precise gl_opt(41)      // default 1;                   // split-fp16 activations for the 1x1 convs + GroupNorm on the fp32 stream
 #define g_h1_f32 gl_opt(42)       // default 1;                   // with key 41: the ResBlock's first conv writes fp32 for out_layers' GroupNorm
 #define g_rela_compact gl_opt(43) // default 1;                   // the relation chain runs on max_b nvalid[b] (rounded up to 8) rows per sample instead of max_objs = 30
-#define g_w3 gl_opt(45)          // default 1;                   // with key 41: the 1x1 convs' third pass xhi.Wlo (weights stored [Whi | Wlo]) for launches of > 1024 rows
+#define g_w3 gl_opt(45)          // default 1024;                // with key 41: the 1x1 convs' third pass xhi.Wlo (weights stored [Whi | Wlo]) for launches of more than this many rows (>= 1024; 0 = off)
 #define g_share gl_opt(44)        // default 1;                   // 2B = [cond ; uncond] forwards: everything before the first conditioning-dependent op
                                                                   // (conv_in, the first ResBlock, proj_in .. attn1 of the first transformer) runs ONCE on
                                                                   // the B shared latents and is duplicated
@@ -389,7 +389,7 @@ struct Run {
             g.ldw = g.K; g.K = Kc;
             if (hilo_a) {       // x.W = xhi.Whi + xlo.Whi (+ xhi.Wlo: third K segment, A from the second source = the hi half again)
                 g.kwrap = Kc; g.K = 2 * Kc;
-                if (g_w3 && M > 1024 && a2 == nullptr) {
+                if (g_w3 > 0 && M > (g_w3 < 1024 ? 1024 : g_w3) && a2 == nullptr) {
                     g.K = 3 * Kc; g.a2 = a; g.lda2 = lda; g.ksplit = 2 * Kc;
                 }
             }

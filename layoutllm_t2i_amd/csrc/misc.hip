@@ -250,7 +250,7 @@ static gl_opts make_default_opts() {
     o.v[42] = 1;
     o.v[43] = 1;
     o.v[44] = 1;
-    o.v[45] = 1;
+    o.v[45] = 1024;
     o.v[46] = 11;
     o.v[47] = 100;
     return o;

@@ -62,7 +62,7 @@ class PyRefEngine:
         self.precise, self.h1_f32 = True, True
         self.share_prefix = True              # gl_set_option 44
         self.rela_compact = True              # gl_set_option 43
-        self.w3 = True                        # gl_set_option 45
+        self.w3 = 1024                        # gl_set_option 45: rows threshold of the third pass (0 = off)
         # constant gates of rela_fuse, per-step gates of the fuser (scale * tanh(alpha))
         for l in self.st_layers:
             t = l.prefix + ".transformer_blocks.0"
@@ -90,7 +90,7 @@ class PyRefEngine:
     @torch.no_grad()
     def _w3(self, rows: int) -> int:
         """engine.hip Run::gemm: the third pass xhi.Wlo for launches of more than 1024 rows (key 45)"""
-        return 2 if (self.w3 and rows > 1024) else 1
+        return 2 if (self.w3 and rows > max(1024, int(self.w3))) else 1
 
     def set_conditioning(self, context, relations, boxes, masks, positive_embeddings, hw: int) -> None:
         """context [Bn,77,ctx], relations [Bn,R,ctx], boxes [Bn,30,4], masks [Bn,30],

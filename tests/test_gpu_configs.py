@@ -156,7 +156,7 @@ def test_unrounded_reference_weights_at_bench_batch():
     try:
         r2 = report("2B=8 cond fuser on, fp32 reference weights, fp16 weights only  ", eng.forward(x, 481.0, 1.0, False, 2)[k:k + 1], ref)
     finally:
-        ops.set_option(45, 1)
+        ops.set_option(45, 1024)
     assert r3 < 1.3e-3 and r3 < 0.93 * r2, (r3, r2)
     del m, eng
     torch.cuda.empty_cache()

@@ -206,7 +206,7 @@ def test_full_unet_config2_vs_oracle():
     try:
         out_hi = eng.forward(inp["x"].to(DEV), 481.0, 1.0, False, 1).clone()
     finally:
-        ops.set_option(45, 1)
+        ops.set_option(45, 1024)
     t = torch.full((B,), 481, dtype=torch.long)
     torch.set_num_threads(min(32, max(1, os.cpu_count() or 1)))
     with torch.no_grad():
