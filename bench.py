@@ -479,8 +479,10 @@ def main():
         # weight matrices the second oracle run below uses (arithmetic-only comparison)
         from layoutllm_t2i_amd import ops as _op2
         _op2.set_option(45, 0)
+        _op2.set_option(38, 0)
         e_on_hi = eng.forward(inp["x"], 481.0, 1.0, False, 2).clone()
         _op2.set_option(45, 1024)
+        _op2.set_option(38, 1)
         for kv in args.opt:                          # (restore a --opt 45=... given on the command line)
             if kv.split("=")[0] == "45":
                 _op2.set_option(45, int(kv.split("=")[1]))

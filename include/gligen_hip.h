@@ -276,13 +276,16 @@ int gl_silu_f16(const void* x, void* y, int64_t n, void* stream);
  *                    x_prev = sqrt_aprev * pred_x0 + dir_coef * e'                       (plms.py:126-161)
  *                    evaluated in the reference's operation order with FP contraction off.
  *   gl_pack_latent : x fp32 NCHW [B, C, hw] -> fp16 NHWC [reps*B, hw, Cpad] (zero channel padding), the
- *                    first-conv input for both CFG halves.
+ *                    first-conv input for both CFG halves.  split != 0 (Cpad >= 3C): channels [0, C) = hi = fp16(x), [C, 2C) = fp16(x - hi),
+ *                    [2C, 3C) = hi again -- with first-conv weights packed [Whi | Whi | Wlo] over those channels the conv computes
+ *                    xhi.Whi + xlo.Whi + xhi.Wlo in the padding it carries anyway (the engine's weight table always holds that packing;
+ *                    gl_set_option 38 = 0 feeds hi alone).
  */
 int gl_cfg_combine(const float* eps2b, float guidance, int64_t n, float* e_out, void* stream);
 int gl_plms_update(const float* x, const float* e, const float* e1, const float* e2, const float* e3,
                    float c0, float c1, float c2, float c3, float div, float sqrt_at, float s1m,
                    float sqrt_aprev, float dir_coef, int64_t n, float* x_prev, void* stream);
-int gl_pack_latent(const float* x, int32_t B, int32_t C, int32_t hw, int32_t Cpad, int32_t reps, void* out,
+int gl_pack_latent(const float* x, int32_t B, int32_t C, int32_t hw, int32_t Cpad, int32_t reps, int32_t split, void* out,
                    void* stream);
 
 /*
@@ -497,6 +500,7 @@ int gl_sizeof_gn_args(void);
  * conditioning-dependent op -- conv_in, the first ResBlock, proj_in .. attn1 of the first transformer block -- ONCE on the shared
  * latents and duplicates it for the uncond half (1 default; 0 = both halves computed; results equal up to the tile / split-K choice
  * of the half-sized launches).
+ * key 38 = the first conv takes the latent as [hi | lo | hi] channels against [Whi | Whi | Wlo] weights (1 default; 0 = fp16(x) against Whi alone).
  * key 43 = the relation chain of rela_fuse (attention.py:348-351) runs on max_b nvalid[b] rows per sample (rounded up to 8) instead of all
  * max_objs = 30 (1 default; read when gl_set_conditioning runs, which then copies the nvalid counts back to the host once); the used rows
  * are unchanged up to the tile / split-K choice of GEMMs with fewer rows.

@@ -156,7 +156,7 @@ PROTOTYPES = {
     "gl_silu_f16": (i32, [vp, vp, i64, vp]),
     "gl_cfg_combine": (i32, [fp, f32, i64, fp, vp]),
     "gl_plms_update": (i32, [fp, fp, fp, fp, fp, f32, f32, f32, f32, f32, f32, f32, f32, f32, i64, fp, vp]),
-    "gl_pack_latent": (i32, [fp, i32, i32, i32, i32, i32, vp, vp]),
+    "gl_pack_latent": (i32, [fp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "gl_latent_affine_pack": (i32, [fp, fp, fp, f32, i32, i32, i32, i32, vp, vp]),
     "gl_softmax_rows": (i32, [vp, i32, i32, i32, f32, vp]),
     "gl_abi_version": (i32, []),

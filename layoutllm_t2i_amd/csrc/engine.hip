@@ -35,6 +35,7 @@ constexpr int64_t WS_BYTES = 96ll << 20; // split-K fp32 partial tiles
 #define g_h1_f32 gl_opt(42)       // default 1;                   // with key 41: the ResBlock's first conv writes fp32 for out_layers' GroupNorm
 #define g_rela_compact gl_opt(43) // default 1;                   // the relation chain runs on max_b nvalid[b] (rounded up to 8) rows per sample instead of max_objs = 30
 #define g_w3 gl_opt(45)          // default 1024;                // with key 41: the 1x1 convs' third pass xhi.Wlo (weights stored [Whi | Wlo]) for launches of more than this many rows (>= 1024; 0 = off)
+#define g_in_split gl_opt(38)     // default 1;                   // the first conv's input as [hi | lo | hi] channels against [Whi | Whi | Wlo] weights (free: 4 of 64 padded channels are used)
 #define g_share gl_opt(44)        // default 1;                   // 2B = [cond ; uncond] forwards: everything before the first conditioning-dependent op
                                                                   // (conv_in, the first ResBlock, proj_in .. attn1 of the first transformer) runs ONCE on
                                                                   // the B shared latents and is duplicated
@@ -810,7 +811,7 @@ int launch_forward(gl_engine* e, int reps, bool fuser_on, bool sd_conv, bool uni
     half_t* xin = e->h16("in.x", (size_t)Bn * side * side * CIN_PAD);
     CKP(xin);
     ++r.launches;
-    CK(gl_pack_latent(x_lat, Bn / reps, cfg.in_channels, side * side, CIN_PAD, share ? 1 : reps, xin, st));
+    CK(gl_pack_latent(x_lat, Bn / reps, cfg.in_channels, side * side, CIN_PAD, share ? 1 : reps, g_in_split && 3 * cfg.in_channels <= CIN_PAD, xin, st));
     const std::string fc = sd_conv ? "sd_first_conv" : "input_blocks.0.0";
     // fp16 copies of stream tensors: only where a down / up conv consumes the tensor (precise mode: every GroupNorm and 1x1 conv
     // reads the fp32 stream), or everywhere in the round-3 fp16-copy mode

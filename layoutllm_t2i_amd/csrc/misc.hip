@@ -85,8 +85,10 @@ __global__ void plms_update_kernel(const float* x, const float* e, const float* 
 }
 #pragma clang fp contract(fast)
 
-// x fp32 [B, C, hw] -> fp16 [reps*B, hw, Cpad]
-__global__ void pack_latent_kernel(const float* __restrict__ x, int B, int C, int hw, int Cpad, int reps,
+// x fp32 [B, C, hw] -> fp16 [reps*B, hw, Cpad].  split: channels [0, C) = hi = fp16(x), [C, 2C) = lo = fp16(x - hi), [2C, 3C) = hi again -- against
+// first-conv weights packed [Whi | Whi | Wlo] (weights.py pack_first_conv) the one conv launch computes xhi.Whi + xlo.Whi + xhi.Wlo in the channel
+// padding it carries anyway (4 of 64 channels used)
+__global__ void pack_latent_kernel(const float* __restrict__ x, int B, int C, int hw, int Cpad, int reps, int split,
                                    half_t* __restrict__ out) {
     const size_t total = (size_t)reps * B * hw * Cpad;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -95,9 +97,16 @@ __global__ void pack_latent_kernel(const float* __restrict__ x, int B, int C, in
         const int p = (int)(t % hw);
         const int rb = (int)(t / hw);
         const int b = rb % B;
-        float v = 0.0f;
-        if (c < C) v = x[((size_t)b * C + c) * hw + p];
-        out[i] = (half_t)v;
+        half_t o = (half_t)0.0f;
+        if (c < C) {
+            o = (half_t)x[((size_t)b * C + c) * hw + p];
+        } else if (split && c < 3 * C) {
+            const int cc = c < 2 * C ? c - C : c - 2 * C;
+            const float v = x[((size_t)b * C + cc) * hw + p];
+            const half_t hi = (half_t)v;
+            o = c < 2 * C ? (half_t)(v - (float)hi) : hi;
+        }
+        out[i] = o;
     }
 }
 
@@ -210,11 +219,11 @@ extern "C" int gl_plms_update(const float* x, const float* e, const float* e1, c
     return 0;
 }
 
-extern "C" int gl_pack_latent(const float* x, int32_t B, int32_t C, int32_t hw, int32_t Cpad, int32_t reps, void* out,
+extern "C" int gl_pack_latent(const float* x, int32_t B, int32_t C, int32_t hw, int32_t Cpad, int32_t reps, int32_t split, void* out,
                               void* stream) {
-    if (!x || !out || B <= 0 || C <= 0 || hw <= 0 || Cpad < C || reps <= 0) return GL_ERR_BAD_ARG;
+    if (!x || !out || B <= 0 || C <= 0 || hw <= 0 || Cpad < (split ? 3 * C : C) || reps <= 0) return GL_ERR_BAD_ARG;
     pack_latent_kernel<<<dim3(ew_blocks((size_t)reps * B * hw * Cpad)), dim3(256), 0, (hipStream_t)stream>>>(
-        x, B, C, hw, Cpad, reps, reinterpret_cast<half_t*>(out));
+        x, B, C, hw, Cpad, reps, split, reinterpret_cast<half_t*>(out));
     GL_CHECK_LAUNCH();
     return 0;
 }
@@ -249,6 +258,7 @@ static gl_opts make_default_opts() {
     o.v[41] = 1;
     o.v[42] = 1;
     o.v[43] = 1;
+    o.v[38] = 1;
     o.v[44] = 1;
     o.v[45] = 1024;
     o.v[46] = 11;
@@ -262,7 +272,7 @@ int g_gl_option_epoch = 0;
 bool gl_opts_store(gl_opts& t, int key, int value) {
     switch (key) {
         case 2: case 3: case 4: case 6: case 7: case 8: case 10: case 13: case 17: case 20: case 21: case 23: case 24: case 25:
-        case 27: case 29: case 30: case 31: case 32: case 33: case 35: case 37: case 41: case 42: case 43: case 44: case 45: case 46: case 47:
+        case 27: case 29: case 30: case 31: case 32: case 33: case 35: case 37: case 38: case 41: case 42: case 43: case 44: case 45: case 46: case 47:
             t.v[key] = value;
             return true;
         case 5:                                  // < 0: the built-in thresholds (plain GEMM 300 tiles, conv 450)

@@ -469,12 +469,12 @@ def plms_update(x, e, olds, coefs, div, sqrt_at, s1m, sqrt_aprev, dir_coef, x_pr
     return x_prev
 
 
-def pack_latent(x: torch.Tensor, Cpad: int, reps: int, out: torch.Tensor):
-    """x fp32 [B, C, h, w] -> out fp16 [reps*B, h*w, Cpad]."""
+def pack_latent(x: torch.Tensor, Cpad: int, reps: int, out: torch.Tensor, split: bool = False):
+    """x fp32 [B, C, h, w] -> out fp16 [reps*B, h*w, Cpad]; ``split``: channels [hi | lo | hi] of x (first-conv weights [Whi | Whi | Wlo])."""
     _req(x, F32, "x")
     _req(out, F16, "out")
     B, Cc, h, w = x.shape
-    check(_lib.lib().gl_pack_latent(x.data_ptr(), B, Cc, h * w, Cpad, reps, out.data_ptr(), _stream()), "gl_pack_latent")
+    check(_lib.lib().gl_pack_latent(x.data_ptr(), B, Cc, h * w, Cpad, reps, int(split), out.data_ptr(), _stream()), "gl_pack_latent")
     return out
 
 

@@ -63,6 +63,7 @@ class PyRefEngine:
         self.share_prefix = True              # gl_set_option 44
         self.rela_compact = True              # gl_set_option 43
         self.w3 = 1024                        # gl_set_option 45: rows threshold of the third pass (0 = off)
+        self.in_split = True                  # gl_set_option 38
         # constant gates of rela_fuse, per-step gates of the fuser (scale * tanh(alpha))
         for l in self.st_layers:
             t = l.prefix + ".transformer_blocks.0"
@@ -351,7 +352,8 @@ class PyRefEngine:
         emb_out = ops.gemm(e2, W["emb_all.w"], self.buf("te.out32" if self.precise else "te.out", (Bn, self.P.emb_total), F32 if self.precise else F16),
                            W["emb_all.b"])
         # first conv on the zero-padded NHWC latent (openaimodel.py:299, :393-405)
-        xin = ops.pack_latent(x_lat, CIN_PAD, 1 if share else reps, self.buf("in.x", (B0 * side * side, CIN_PAD)))
+        xin = ops.pack_latent(x_lat, CIN_PAD, 1 if share else reps, self.buf("in.x", (B0 * side * side, CIN_PAD)),
+                              split=self.in_split and 3 * self.cfg.in_channels <= CIN_PAD)
         fc = "sd_first_conv" if sd_conv else "input_blocks.0.0"
         M0 = Bn * side * side
         Mh = B0 * side * side
@@ -447,7 +449,7 @@ class PyRefEngine:
             self._launch_forward(x_static, t_buf, reps, fuser_on, sd_conv, eps_out, uniform_t)
             return eps_out
         key = (Bn, side, c["R"], c["Lc"], c["mo"], c["ms"], fuser_on, sd_conv, reps, eps_out.data_ptr(), tuple(x_lat.shape), self.precise, self.h1_f32,
-               self.share_prefix, self.w3, uniform_t)
+               self.share_prefix, self.w3, self.in_split, uniform_t)
         g = self._graphs.get(key)
         if g is None:
             # warm-up run allocates every pooled buffer, then capture the same launch sequence

@@ -383,12 +383,16 @@ def test_third_pass_of_the_1x1_convs_matches_python_sequence_and_moves_towards_f
     try:
         for opt in (1024, 0):
             ops.set_option(45, opt)
+            ops.set_option(38, 1 if opt else 0)          # ... and the split first conv (key 38) with it
             ref.w3 = opt
+            ref.in_split = bool(opt)
             a = eng.forward(x, 481.0, 1.0, False, 2).clone()
             assert same(a, ref.forward(x, 481.0, 1.0, False, 2).clone()), opt
             outs.append(a)
     finally:
         ops.set_option(45, 1024)
+        ops.set_option(38, 1)
         ref.w3 = 1024
+        ref.in_split = True
     r = float((outs[0] - outs[1]).norm() / outs[1].norm())
     assert 1e-6 < r < 3e-3, r              # the recipe weights are fp32: the third pass moves the result at the weight-rounding level

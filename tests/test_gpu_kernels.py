@@ -476,6 +476,41 @@ def test_conv3x3_first_and_last():
     check(eps, F.conv2d(h, w2, b2, padding=1), "conv_last_nchw_f32", rtol=1e-4, atol=1e-5)
 
 
+def test_first_conv_split_latent_and_weights():
+    """gl_pack_latent split + weights.pack_first_conv: the latent goes in as [hi | lo | hi] channels against [Whi | Whi | Wlo] weights in the 64
+    padded input channels the first conv carries anyway -- against the fp64 conv of the UNROUNDED latent and weights the error drops from the
+    fp16-operand level to fp32-accumulation level; with fp16-representable x and W the result equals the unsplit form bit for bit."""
+    from layoutllm_t2i_amd.weights import pack_first_conv
+    B, hw, mc = 2, 16, 64
+    x = rnd("slat", (B, 4, hw, hw)) * 1.3
+    w = rnd("sfcw", (mc, 4, 3, 3), 1 / 6)
+    b = rnd("sfcb", (mc,), 0.1)
+    xs = torch.empty(B * hw * hw, 64, dtype=torch.float16, device=DEV)
+    ops.pack_latent(x.to(DEV), 64, 1, xs, split=True)
+    hi = x.half()
+    lo = (x - hi.float()).half()
+    assert torch.equal(xs[:, 0:4].cpu(), _nhwc(hi)) and torch.equal(xs[:, 4:8].cpu(), _nhwc(lo)) and torch.equal(xs[:, 8:12].cpu(), _nhwc(hi))
+    assert float(xs[:, 12:].abs().max()) == 0.0
+    out = torch.empty(B * hw * hw, mc, dtype=torch.float32, device=DEV)
+    ops.conv3x3(xs, pack_first_conv(w, 64).to(DEV), out, B, hw, hw, b.to(DEV))
+    ref = _nhwc(F.conv2d(x.double(), w.double(), b.double(), padding=1).float())
+    plain_in = torch.empty_like(xs)
+    ops.pack_latent(x.to(DEV), 64, 1, plain_in)
+    plain = torch.empty_like(out)
+    ops.conv3x3(plain_in, pack_conv3x3(w.half(), 64).to(DEV), plain, B, hw, hw, b.to(DEV))
+    e_split = float((out.cpu() - ref).norm() / ref.norm())
+    e_plain = float((plain.cpu() - ref).norm() / ref.norm())
+    print(f"[first_conv_split] rel_l2 split={e_split:.2e} plain fp16={e_plain:.2e}")
+    assert e_split < 2e-6 and e_plain > 20 * e_split, (e_split, e_plain)
+    # fp16-representable operands: lo = 0 and Wlo = 0, the extra channels add exact zeros
+    xr, wr = x.half().float(), w.half().float()
+    ops.pack_latent(xr.to(DEV), 64, 1, xs, split=True)
+    ops.conv3x3(xs, pack_first_conv(wr, 64).to(DEV), out, B, hw, hw, b.to(DEV))
+    ops.pack_latent(xr.to(DEV), 64, 1, plain_in)
+    ops.conv3x3(plain_in, pack_conv3x3(wr.half(), 64).to(DEV), plain, B, hw, hw, b.to(DEV))
+    assert torch.equal(out, plain)
+
+
 def test_conv3x3_epilogues(hw=8):
     B, C = 2, 128
     x, _ = h16(rnd("cex", (B, C, hw, hw)))

@@ -55,6 +55,10 @@ def get_model(cfg, fp16_round=False):
     return _models[key]
 
 
+def _fp16_representable(sd):
+    return {k: (np.asarray(v).astype(np.float16).astype(np.float32) if np.asarray(v).ndim >= 2 else np.asarray(v)) for k, v in sd.items()}
+
+
 def oracle_sd(sd, half_round=True):
     """Oracle weights: the recipe tensors rounded to fp16 where the engine stores fp16 (matrices/convs),
     so the comparison isolates arithmetic error from weight quantisation."""
@@ -167,14 +171,15 @@ LEVELS = [
 @pytest.mark.parametrize("name,cfg,hw,B", LEVELS, ids=[l[0] for l in LEVELS])
 def test_full_width_level_vs_oracle(name, cfg, hw, B):
     """A one-level UNet with the real channel width / head dim / token count of config 2
-    (ResBlock + SpatialTransformer with fuser + rela_fuse, middle block, skip-concat ResBlocks)."""
-    sd = recipe.state_dict(cfg, 0)
+    (ResBlock + SpatialTransformer with fuser + rela_fuse, middle block, skip-concat ResBlocks).  Arithmetic parity: both sides take the
+    fp16-representable weight matrices (the engine's split weights then have Wlo = 0)."""
+    sd = _fp16_representable(recipe.state_dict(cfg, 0))
     model = UNetModel(cfg, sd, device=DEV)
     inp = cond_inputs(cfg, B, hw, n_boxes=8)
     eng = model.engine
     eng.set_conditioning(inp["context"], inp["relations"], inp["boxes"], inp["masks"], inp["positive_embeddings"], hw)
     t = torch.full((B,), 481, dtype=torch.long)
-    out = eng.forward(inp["x"].to(DEV), 481.0, 1.0, False, 1).clone()
+    out = eng.forward(inp["x"].half().float().to(DEV), 481.0, 1.0, False, 1).clone()      # the oracle below takes the fp16-rounded latent too
     with torch.no_grad():
         torch.set_num_threads(min(32, max(1, os.cpu_count() or 1)))     # eager torch gets slower beyond 32 threads on the 256-thread host (these three tests took 320 s of the suite)
         ref = unet_ref.unet_forward(oracle_sd(sd), cfg, inp["x"].half().float(), t, inp["context"].half().float(),
@@ -203,10 +208,12 @@ def test_full_unet_config2_vs_oracle():
     out = eng.forward(inp["x"].to(DEV), 481.0, 1.0, False, 1).clone()
     # the three kinds of 1x1 conv store [Whi | Wlo] (gl_set_option 45): on the Whi halves alone the engine's weights ARE the fp16-rounded matrices
     ops.set_option(45, 0)
+    ops.set_option(38, 0)
     try:
         out_hi = eng.forward(inp["x"].to(DEV), 481.0, 1.0, False, 1).clone()
     finally:
         ops.set_option(45, 1024)
+        ops.set_option(38, 1)
     t = torch.full((B,), 481, dtype=torch.long)
     torch.set_num_threads(min(32, max(1, os.cpu_count() or 1)))
     with torch.no_grad():
@@ -291,12 +298,12 @@ def test_config3_768px_level_vs_oracle():
     of two (72 query slabs of 128, 144 key tiles), one sample, 16 boxes."""
     cfg = UNetConfig(image_size=96, model_channels=320, channel_mult=(1,), attention_resolutions=(1,), num_res_blocks=1)
     hw, B = 96, 1
-    sd = recipe.state_dict(cfg, 0)
+    sd = _fp16_representable(recipe.state_dict(cfg, 0))
     model = UNetModel(cfg, sd, device=DEV)
     inp = cond_inputs(cfg, B, hw, n_boxes=16)
     eng = model.engine
     eng.set_conditioning(inp["context"], inp["relations"], inp["boxes"], inp["masks"], inp["positive_embeddings"], hw)
-    out = eng.forward(inp["x"].to(DEV), 481.0, 1.0, False, 1).clone()
+    out = eng.forward(inp["x"].half().float().to(DEV), 481.0, 1.0, False, 1).clone()
     t = torch.full((B,), 481, dtype=torch.long)
     with torch.no_grad():
         torch.set_num_threads(min(32, max(1, os.cpu_count() or 1)))
@@ -317,7 +324,7 @@ def test_tiny_unet_max_boxes_max_relations_vs_oracle():
     inp = {k: T(v) for k, v in recipe.synth_inputs(TINY, B, hw, n_boxes=30, n_rel=10, seed=77).items()}
     eng = model.engine
     eng.set_conditioning(inp["context"], inp["relations"], inp["boxes"], inp["masks"], inp["positive_embeddings"], hw)
-    out = eng.forward(inp["x"].to(DEV), 250.0, 1.0, False, 1).clone()
+    out = eng.forward(inp["x"].half().float().to(DEV), 250.0, 1.0, False, 1).clone()
     t = torch.full((B,), 250, dtype=torch.long)
     with torch.no_grad():
         ref = unet_ref.unet_forward(oracle_sd(sd), TINY, inp["x"].half().float(), t, inp["context"].half().float(),

@@ -49,7 +49,7 @@ def condition(e):
 
 for e in engines.values():
     condition(e)
-DEFAULTS = {17: 1, 21: 1, 13: 3, 7: 300, 8: 1, 5: -1, 6: 16, 3: 0, 10: -1, 2: 0, 4: 400, 16: 16, 23: 1, 24: 64, 25: 1, 27: 1, 29: 1, 30: 1, 31: 200, 33: 0, 34: 11, 35: 5, 37: 1, 41: 1, 42: 1, 43: 1, 44: 1, 45: 1024, 46: 11, 47: 100}
+DEFAULTS = {17: 1, 21: 1, 13: 3, 7: 300, 8: 1, 5: -1, 6: 16, 3: 0, 10: -1, 2: 0, 4: 400, 16: 16, 23: 1, 24: 64, 25: 1, 27: 1, 29: 1, 30: 1, 31: 200, 33: 0, 34: 11, 35: 5, 37: 1, 38: 1, 41: 1, 42: 1, 43: 1, 44: 1, 45: 1024, 46: 11, 47: 100}
 res = {n: {1.0: [], 0.0: []} for n, _ in variants}
 launches = {}
 for rnd in range(5):

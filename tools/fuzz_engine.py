@@ -88,7 +88,7 @@ while time.time() - t0 < budget:
         ofc = {k: (T(np.asarray(v)).float().half().float() if np.asarray(v).ndim >= 2 else T(np.asarray(v)).float()) for k, v in fc.items()}
         eng = m.engine
         z = torch.zeros_like
-        x = inp["x"].to(DEV)
+        x = inp["x"].half().float().to(DEV)          # the oracle takes the fp16-rounded latent (xh below)
         tval = float(lr.choice([1, 201, 481, 981]))
         tt = torch.full((B,), int(tval), dtype=torch.long)
         xh = inp["x"].half().float()

@@ -54,12 +54,16 @@ class Sim(TorchFunctionMode):
         return func(*args, **kwargs)
 
 
-CLASSES = ("conv3x3", "proj_in", "proj_out", "skip1x1", "qkv", "attn_out", "ff_in", "ff_out", "qk", "pv", "cond")
+CLASSES = ("conv3x3", "out_conv", "in_conv", "proj_in", "proj_out", "skip1x1", "qkv", "attn_out", "ff_in", "ff_out", "qk", "pv", "cond")
 
 
 def classify(name: str, w: torch.Tensor) -> str:
     if w.dim() == 4:
         if w.shape[-1] == 3:
+            if name.startswith("out."):
+                return "out_conv"          # the last conv writes eps itself
+            if name.startswith("input_blocks.0.0."):
+                return "in_conv"
             return "conv3x3"
         return "proj_in" if ".proj_in." in name else "proj_out" if ".proj_out." in name else "skip1x1"
     if ".to_q." in name or ".to_k." in name or ".to_v." in name:
