@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GL_ABI_VERSION 13
+#define GL_ABI_VERSION 14
 
 /* error codes (negative; positive values are hipError_t) */
 #define GL_ERR_BAD_ARG (-1)
@@ -135,6 +135,11 @@ typedef struct gl_conv_args {
     int32_t stride;        /* 1 or 2 */
     int32_t upsample2x;    /* 0 or 1 (stride must be 1) */
     gl_gemm_args g;        /* w, bias, N, epi, out_mode, out, ldc, res, ldres, rowbias..., hw */
+    /* split-fp16 operands (ABI 14; strict mode).  in_split = 2: the input pixels are [hi | lo] rows of 2 Cin channels
+     * (hi = fp16(x), lo = fp16(x - hi), e.g. gl_groupnorm_ex's out / out_lo with ldo = 2 Cin) and the K walk visits both halves against
+     * the same weight: x.W = hi.W + lo.W (~22 mantissa bits of the activation); in_split = 3 (needs w_split): a third pass hi.Wlo.
+     * w_split != 0: the weight rows are [Whi | Wlo], fp16 [Cout, 2, Cin/64, 3, 3, 64] (Wlo = fp16(W - Whi)); in_split 0 / 2 read Whi only. */
+    int32_t in_split, w_split;
 } gl_conv_args;
 
 /*
@@ -154,6 +159,11 @@ typedef struct gl_attn_args {
     float scale;
     int32_t q_prescaled;   /* != 0: scale * log2(e) is already folded into Q (the packer folds it into the q projection
                               weights); `scale` is then ignored and the running max is subtracted inside the MFMA */
+    /* split-fp16 attention (ABI 14; strict mode): with q_lo != NULL every operand is hi + lo -- q_lo / k_lo / vt_lo hold the fp16 residuals
+     * in the layouts (strides, batch strides) of q / k / vt, the logits are q.k = qhi.khi + qlo.khi + qhi.klo, the probabilities are split
+     * P = Phi + Plo in registers, O = Phi.Vhi + Plo.Vhi + Phi.Vlo, and out / out_lo (same ldo, out_lo may be NULL) receive fp16(O) and
+     * fp16(O - fp16(O)).  All three of q_lo, k_lo, vt_lo must be given. */
+    const void* q_lo; const void* k_lo; const void* vt_lo; void* out_lo;
 } gl_attn_args;
 
 /* gl_transpose_v: V [B, Nk, *] (row stride ldv, head h at column h*d) -> vt [B, H, d, ldvt], zero-fills keys
@@ -220,6 +230,11 @@ int gl_layernorm(const void* x, int32_t ldx, int32_t x_f32, void* y, int32_t ldy
  * gl_layernorm_stats: only the per-row (mean, rstd) of fp32 rows [rows, C] (the same two-pass arithmetic as gl_layernorm), for consumers that
  * re-evaluate the normalisation themselves in fp32 (gl_rela_pool_ln3, gl_rela_merge): rela_fuse's LayerNorm3 output is then never stored. */
 int gl_layernorm_stats(const float* x, int32_t ldx, int32_t rows, int32_t C, float eps, float* stats, void* stream);
+/* x_f32 bit 3 (value 8; ABI 14): the fp16 output rows are written as [hi | lo] -- y[r * ldy + c] = fp16(v), y[r * ldy + C + c] = fp16(v - fp16(v)),
+ * ldy >= 2 C -- the split-fp16 operand of the projection that follows (strict mode).  fp32 input rows only (bit 0; with a second source: bit 2). */
+/* gl_split_f32: fp32 rows [rows, C] (row stride ldx floats) -> fp16 [rows, 2 C] rows [hi | lo] (row stride ldy): the split-fp16 form of a
+ * residual-stream tensor for a matrix-core consumer that has no producer to write it (down / up convs, the conditioning tensors). C % 8 == 0. */
+int gl_split_f32(const float* x, int32_t ldx, int64_t rows, int32_t C, void* y, int32_t ldy, void* stream);
 
 /*
  * RelationCrossAttention (attention.py:315-359) in closed form:
@@ -265,6 +280,10 @@ int gl_posnet_input(const float* boxes, const float* masks, const float* emb, co
 
 /* gl_timestep_embedding: [cos(t w_k) | sin(t w_k)], w_k = exp(-ln(1e4) k / half) (util.py:161-181) -> fp16 [B, dim] */
 int gl_timestep_embedding(const float* t, int32_t B, int32_t dim, void* out, void* stream);
+/* fp32-output forms (ABI 14; strict mode: the rows then go through gl_split_f32 and enter the first Linear as [hi | lo]) */
+int gl_timestep_embedding_f32(const float* t, int32_t B, int32_t dim, float* out, void* stream);
+int gl_posnet_input_f32(const float* boxes, const float* masks, const float* emb, const float* null_pos, const float* null_xyxy,
+                        int32_t rows, int32_t in_dim, int32_t num_freqs, float* out, void* stream);
 
 /* gl_silu_f16: y = silu(x) elementwise fp16 (emb_layers SiLU, openaimodel.py:173). n % 8 == 0. */
 int gl_silu_f16(const void* x, void* y, int64_t n, void* stream);
@@ -312,6 +331,11 @@ typedef struct gl_unet_config {          /* UNetModel.__init__ arguments (openai
     int32_t num_heads, context_dim;
     int32_t pos_in_dim, pos_out_dim, fourier_freqs;                    /* PositionNet (text_grounding_net.py:7-24) */
     int32_t max_objs;                                                  /* 30 (interface.py:158,425) */
+    int32_t split_weights;       /* ABI 14.  != 0: EVERY matrix of the weight table is stored [Whi | Wlo] (Whi = fp16(W), Wlo = fp16(W - Whi); Linear
+                                    rows [N, 2K], 3x3 convs [Cout, 2, Cin/64, 3, 3, 64]): the layout the strict mode (gl_set_handle_option 50) needs for
+                                    its third pass x.Wlo -- with it the engine reproduces the reference's fp32 weights to ~22 bits.  The default
+                                    mode of such a handle reads the Whi halves and computes what a handle without the flag computes; the table is
+                                    twice the size (5 GB for the GLIGEN UNet).  0 = the compact table (only the 1x1 convs keep [Whi | Wlo]). */
 } gl_unet_config;
 
 typedef struct gl_engine gl_engine;      /* opaque */

@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgligen_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 # enum gl_epilogue / gl_out_mode
 EPI_BIAS, EPI_SILU, EPI_GEGLU, EPI_RES, EPI_GATE_RES, EPI_ROWBIAS = range(6)
@@ -70,6 +70,7 @@ class ConvArgs(C.Structure):
         ("stride", i32),
         ("upsample2x", i32),
         ("g", GemmArgs),
+        ("in_split", i32), ("w_split", i32),
     ]
 
 
@@ -82,6 +83,7 @@ class AttnArgs(C.Structure):
         ("B", i32), ("H", i32), ("d", i32), ("Nq", i32), ("Nk", i32),
         ("scale", f32),
         ("q_prescaled", i32),
+        ("q_lo", vp), ("k_lo", vp), ("vt_lo", vp), ("out_lo", vp),
     ]
 
 
@@ -94,6 +96,7 @@ class UNetConfigC(C.Structure):
         ("num_heads", i32), ("context_dim", i32),
         ("pos_in_dim", i32), ("pos_out_dim", i32), ("fourier_freqs", i32),
         ("max_objs", i32),
+        ("split_weights", i32),
     ]
 
 
@@ -148,6 +151,9 @@ PROTOTYPES = {
     "gl_sizeof_gn_args": (i32, []),
     "gl_layernorm": (i32, [vp, i32, i32, vp, i32, fp, fp, i32, i32, i32, i32, i32, f32, fp, vp, i32, i32, vp]),
     "gl_layernorm_stats": (i32, [fp, i32, i32, i32, f32, fp, vp]),
+    "gl_split_f32": (i32, [fp, i32, i64, i32, vp, i32, vp]),
+    "gl_timestep_embedding_f32": (i32, [fp, i32, i32, fp, vp]),
+    "gl_posnet_input_f32": (i32, [fp, fp, fp, fp, fp, i32, i32, i32, fp, vp]),
     "gl_rela_pool_ln3": (i32, [fp, fp, fp, fp, i32, i32, i32, i32, vp, vp, vp, i32, i32, vp, fp, fp, vp, vp]),
     "gl_rela_pool": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, i32, i32, vp, fp, fp, vp, vp]),
     "gl_rela_merge": (i32, [vp, i32, vp, fp, fp, fp, vp, i32, i32, i32, i32, vp, vp, vp, i32, i32, vp, fp, fp, vp, vp]),
@@ -275,6 +281,7 @@ def unet_config_c(cfg) -> UNetConfigC:
         c.attention_resolutions[i] = int(m)
     c.num_heads, c.context_dim = cfg.num_heads, cfg.context_dim
     c.pos_in_dim, c.pos_out_dim, c.fourier_freqs, c.max_objs = cfg.pos_in_dim, cfg.pos_out_dim, cfg.fourier_freqs, cfg.max_objs
+    c.split_weights = int(bool(getattr(cfg, "split_weights", False)))
     return c
 
 

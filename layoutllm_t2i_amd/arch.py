@@ -30,6 +30,10 @@ class UNetConfig:
     pos_out_dim: int = 768       # PositionNet out_dim
     fourier_freqs: int = 8
     max_objs: int = 30           # interface.py:158,425
+    # not a hyper-parameter of the network: the packed-weight LAYOUT (gl_unet_config.split_weights).  True stores every matrix as
+    # [Whi | Wlo] halves, which the engine's strict mode (option 50: split-fp16 operands, within north_star's tolerance of the fp32
+    # reference) needs for its third pass; the default mode of such an engine reads the Whi halves.  Twice the weight bytes.
+    split_weights: bool = False
 
     @property
     def time_embed_dim(self) -> int:

@@ -138,8 +138,10 @@ class ClipTowers:
         buffer) and captures it on a side stream; later calls copy the input into the static buffer and replay."""
         g = self._graphs.get(key)
         if g is None:
-            if len(self._graphs) >= 16:                         # a host that keeps changing batch sizes: do not hoard graphs
-                self._graphs.clear()
+            if len(self._graphs) >= 16:                         # a host that keeps changing batch sizes: do not hoard graphs --
+                torch.cuda.synchronize(self.device)             # nor the pooled buffers they were captured on (keyed by shape, never reused
+                self._graphs.clear()                            # by another shape: without this the pool grows monotonically over a rollout)
+                self._pool.clear()
             buf = static_in.clone()
             fn(buf)                                             # warm-up: pool allocations, LDS attributes
             torch.cuda.synchronize(self.device)
@@ -199,6 +201,26 @@ class ClipTowers:
         ops.clip_gather_rows(out[:B * T], rows, out[B * T:])
         return out
 
+    def _bucket_ids(self, ids: torch.Tensor):
+        """Token rows [B, T] -> [B8, Tb] int32 on the device, B rounded up to a multiple of 8 and T up to 16 / 32 / the position
+        table; a row is padded with ITS OWN largest id (the eos id for tokenizer output), pad rows repeat row 0: the conditioning path calls
+        with B = the number of relation / grounding phrases and T = the longest phrase, both different on every call, and every
+        new (B, T) would cost an eager warm-up, a synchronize, a capture and its own set of pooled buffers (~1.5 MB per row).
+        Under the causal mask the pad columns cannot change a real row, argmax(-1) still finds each row's FIRST eos, and the pad
+        rows are dropped by the caller."""
+        B, T = ids.shape
+        tmax = min(int(self.tpos.shape[0]), 128)
+        Tb = next((t for t in (16, 32) if T <= t <= tmax), tmax)
+        B8 = (B + 7) // 8 * 8
+        if B8 == B and Tb == T:
+            return ids.to(torch.int32).contiguous()
+        ids32 = ids.to(torch.int32)
+        out = ids32.max(dim=-1, keepdim=True).values.expand(B, Tb).contiguous()
+        out[:, :T] = ids32
+        if B8 != B:
+            out = torch.cat([out, out[:1].expand(B8 - B, Tb)], 0).contiguous()
+        return out
+
     @torch.no_grad()
     def text_hidden_states(self, input_ids: torch.Tensor):
         """(last_hidden_state fp32 [B, T, C], pooler_output fp32 [B, C]) of ``transformers.CLIPTextModel`` for token rows
@@ -209,9 +231,10 @@ class ClipTowers:
         if T > self.tpos.shape[0] or T > 128:
             raise ValueError(f"sequence length {T} exceeds the position table ({self.tpos.shape[0]}) / the short-attention kernel (128)")
         with torch.cuda.device(self.device):
-            ids32 = ids.to(torch.int32).contiguous()
-            out = self._replay(("h", B, T), ids32, self._text_hidden) if self.use_graphs else self._text_hidden(ids32).clone()
-        return out[:B * T].view(B, T, -1), out[B * T:]
+            ids32 = self._bucket_ids(ids)
+            Bb, Tb = ids32.shape
+            out = self._replay(("h", Bb, Tb), ids32, self._text_hidden) if self.use_graphs else self._text_hidden(ids32).clone()
+        return out[:Bb * Tb].view(Bb, Tb, -1)[:B, :T], out[Bb * Tb:Bb * Tb + B]
 
     @torch.no_grad()
     def get_text_features(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -222,7 +245,7 @@ class ClipTowers:
         if T > self.tpos.shape[0] or T > 128:
             raise ValueError(f"sequence length {T} exceeds the position table ({self.tpos.shape[0]}) / the short-attention kernel (128)")
         with torch.cuda.device(self.device):
-            ids32 = ids.to(torch.int32).contiguous()
+            ids32 = self._bucket_ids(ids)
             if self.use_graphs:
-                return self._replay(("t", B, T), ids32, self._text_features)
-            return self._text_features(ids32)
+                return self._replay(("t",) + tuple(ids32.shape), ids32, self._text_features)[:B]
+            return self._text_features(ids32)[:B]

@@ -373,6 +373,220 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(gl_attn_args p, int flags
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Split-fp16 attention (strict mode, gl_attn_args.q_lo != NULL): every matrix-core operand is hi + lo
+// (hi = fp16(x), lo = fp16(x - hi): ~22 mantissa bits), every product takes three MFMA passes
+//   S = Khi.Qhi + Khi.Qlo + Klo.Qhi,   P = Phi + Plo (split in registers),   O += Vhi.Phi + Vhi.Plo + Vlo.Phi,
+// softmax statistics and the row sum in fp32 from the unsplit probabilities; out / out_lo receive fp16(O), fp16(O - fp16(O)).
+// Same work decomposition and register layouts as attn_kernel (S^T = K.Q^T so a lane owns its query's scores, P fed from
+// the score registers); 4 waves x 32 queries, ONE LDS buffer set (K hi / lo, V^T hi / lo: 89 KB at d = 160, dynamic LDS)
+// with two barriers per 64-key tile, the FMA form of the online softmax.  Three times the matrix work of attn_kernel by
+// construction: this is the parity mode, not the fast one.
+template <int DQK>
+__global__ __launch_bounds__(256) void attn_split_kernel(gl_attn_args p) {
+    constexpr int NW = 4, NTHR = 64 * NW;
+    constexpr int NKS = DQK / 16, NDT = (DQK + 31) / 32, KSTR = DQK + 8, KCH = DQK / 8;
+    constexpr int K_ITEMS = KT * KCH, K_PER_T = (K_ITEMS + NTHR - 1) / NTHR;
+    constexpr int V_ITEMS = NDT * 32 * (KT / 8), V_PER_T = (V_ITEMS + NTHR - 1) / NTHR;
+    constexpr int QBLK = NW * 32;
+    constexpr int KBUF = KT * KSTR, VBUF = NDT * 32 * VSTR2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_attn[];
+    half_t* Ksm = reinterpret_cast<half_t*>(smem_attn);         // [2 (hi, lo)][KBUF]
+    half_t* Vsm = Ksm + 2 * KBUF;                               // [2 (hi, lo)][VBUF]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ql = lane & 31, hi = lane >> 5;
+    const int nqb = (p.Nq + QBLK - 1) / QBLK;
+    int logical;
+    {
+        const int total = gridDim.x, L = blockIdx.x;
+        const int xcd = L & 7, qd = total >> 3, rm = total & 7;
+        logical = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (L >> 3);
+    }
+    const int qb = logical % nqb, bh = logical / nqb, h = bh % p.H, b = bh / p.H;
+    const int q0 = qb * QBLK + wave * 32;
+    const int d = p.d, Nq = p.Nq, Nk = p.Nk;
+    const size_t qoff = (size_t)b * p.q_bstride + (size_t)h * d, koff = (size_t)b * p.k_bstride + (size_t)h * d;
+    const size_t voff = (size_t)(b * p.H + h) * d * p.ldvt;
+    const half_t* Kg[2] = {reinterpret_cast<const half_t*>(p.k) + koff, reinterpret_cast<const half_t*>(p.k_lo) + koff};
+    const half_t* Vg[2] = {reinterpret_cast<const half_t*>(p.vt) + voff, reinterpret_cast<const half_t*>(p.vt_lo) + voff};
+
+    half8_t qf[2][NKS];                     // [hi, lo] Q fragments
+    {
+        int q = q0 + ql;
+        if (q >= Nq) q = Nq - 1;
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            const half_t* qrow = reinterpret_cast<const half_t*>(part ? p.q_lo : p.q) + qoff + (size_t)q * p.ldq;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const int c0 = (2 * ks + hi) * 8;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (c0 < d) v = ld16(qrow + c0);
+                qf[part][ks] = *reinterpret_cast<half8_t*>(&v);
+            }
+        }
+    }
+    f32x16 o[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;
+    const float c_scale = p.q_prescaled ? 1.0f : p.scale * 1.4426950408889634f;
+
+    const int ntiles = (Nk + KT - 1) / KT;
+    for (int t = 0; t < ntiles; ++t) {
+        const int key0 = t * KT;
+        // ---- stage K hi / lo [64][d] and V^T hi / lo [d][64] (zero padding, keys >= Nk masked: see attn_kernel)
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+#pragma unroll
+            for (int i = 0; i < K_PER_T; ++i) {
+                const int idx = tid + NTHR * i;
+                if (idx < K_ITEMS) {
+                    const int row = idx / KCH, c = idx - row * KCH;
+                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                    if (c * 8 < d && key0 + row < Nk) v = ld16(Kg[part] + (size_t)(key0 + row) * p.ldk + c * 8);
+                    st16(Ksm + part * KBUF + row * KSTR + c * 8, v);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < V_PER_T; ++i) {
+                const int idx = tid + NTHR * i;
+                if (idx < V_ITEMS) {
+                    const int row = idx >> 3, c = idx & 7;
+                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                    if (row < d) {
+                        v = ld16(Vg[part] + (size_t)row * p.ldvt + key0 + c * 8);
+                        const int kfirst = key0 + c * 8;
+                        if (kfirst + 8 > Nk) {
+                            const int keep = Nk - kfirst;
+                            unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                if (2 * q >= keep) w[q] = 0u;
+                                else if (2 * q + 1 >= keep) w[q] &= 0xFFFFu;
+                            }
+                            v = make_uint4(w[0], w[1], w[2], w[3]);
+                        }
+                    }
+                    uint2* dst = reinterpret_cast<uint2*>(Vsm + part * VBUF + row * VSTR2 + 16 * (c >> 1) + 4 * (c & 1));
+                    dst[0] = make_uint2(v.x, v.y);
+                    dst[2] = make_uint2(v.z, v.w);
+                }
+            }
+        }
+        __syncthreads();
+        const bool tail = (key0 + KT > Nk);
+        // ---- S^T = K . Q^T in three passes (small terms first)
+        f32x16 s[2];
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kh][r] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const half8_t kfh = *reinterpret_cast<const half8_t*>(Ksm + (kh * 32 + ql) * KSTR + (2 * ks + hi) * 8);
+                const half8_t kfl = *reinterpret_cast<const half8_t*>(Ksm + KBUF + (kh * 32 + ql) * KSTR + (2 * ks + hi) * 8);
+                s[kh] = mfma32(kfl, qf[0][ks], s[kh]);
+                s[kh] = mfma32(kfh, qf[1][ks], s[kh]);
+                s[kh] = mfma32(kfh, qf[0][ks], s[kh]);
+            }
+        }
+        if (tail) {
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key0 + kh * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (key >= Nk) s[kh][r] = -INFINITY;
+                }
+        }
+        // ---- online softmax, fp32, exact running max (no deferral: P <= 1)
+        float tmax = s[0][0];
+#pragma unroll
+        for (int i = 1; i < 32; ++i) tmax = fmaxf(tmax, s[i >> 4][i & 15]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * c_scale;
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);       // first tile: exp2(-inf) = 0 on zero accumulators
+        m_run = m_new;
+        l_run *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        uint4 pfh[4], pfl[4];
+        float psum = 0.0f;
+        const float nm = -m_run;
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float p0 = pin_value(__builtin_amdgcn_exp2f(fmaf(s[kh][r], c_scale, nm)));       // hi and lo from ONE value (common.h)
+                const float p1 = pin_value(__builtin_amdgcn_exp2f(fmaf(s[kh][r + 1], c_scale, nm)));
+                psum += p0 + p1;
+                f32x2 pv = {p0, p1};
+                const half2_t ph = __builtin_convertvector(pv, half2_t);
+                f32x2 pr = {p0 - (float)ph[0], p1 - (float)ph[1]};
+                const half2_t pl = __builtin_convertvector(pr, half2_t);
+                const unsigned pw = *reinterpret_cast<const unsigned*>(&ph), lw = *reinterpret_cast<const unsigned*>(&pl);
+                const int j = kh * 2 + (r >> 3);
+                const int e = (r & 7) >> 1;
+                if (e == 0) { pfh[j].x = pw; pfl[j].x = lw; } else if (e == 1) { pfh[j].y = pw; pfl[j].y = lw; }
+                else if (e == 2) { pfh[j].z = pw; pfl[j].z = lw; } else { pfh[j].w = pw; pfl[j].w = lw; }
+            }
+        l_run += psum;
+        // ---- O^T += V^T . P^T in three passes
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                const half8_t vfh = *reinterpret_cast<const half8_t*>(Vsm + (dt * 32 + ql) * VSTR2 + 16 * j + 8 * hi);
+                const half8_t vfl = *reinterpret_cast<const half8_t*>(Vsm + VBUF + (dt * 32 + ql) * VSTR2 + 16 * j + 8 * hi);
+                o[dt] = mfma32(vfl, *reinterpret_cast<const half8_t*>(&pfh[j]), o[dt]);
+                o[dt] = mfma32(vfh, *reinterpret_cast<const half8_t*>(&pfl[j]), o[dt]);
+                o[dt] = mfma32(vfh, *reinterpret_cast<const half8_t*>(&pfh[j]), o[dt]);
+            }
+        __syncthreads();       // every wave is done with the tile before the next one is staged
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + ql;
+    if (q < Nq) {
+        const size_t orow = (size_t)b * p.o_bstride + (size_t)q * p.ldo + (size_t)h * d;
+        half_t* oh = reinterpret_cast<half_t*>(p.out) + orow;
+        half_t* ol = p.out_lo ? reinterpret_cast<half_t*>(p.out_lo) + orow : nullptr;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int c = dt * 32 + 8 * rg + 4 * hi;
+                if (c < d) {
+                    half4_t ov, lv;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const float v = pin_value(o[dt][rg * 4 + jj] * inv);
+                        ov[jj] = (half_t)v;
+                        lv[jj] = (half_t)(v - (float)ov[jj]);
+                    }
+                    *reinterpret_cast<half4_t*>(oh + c) = ov;
+                    if (ol) *reinterpret_cast<half4_t*>(ol + c) = lv;
+                }
+            }
+    }
+}
+
+template <int DQK>
+constexpr int attn_split_lds() { return 2 * (KT * (DQK + 8) + ((DQK + 31) / 32) * 32 * VSTR2) * (int)sizeof(half_t); }
+
+template <int DQK>
+int launch_attn_split(const gl_attn_args& a, hipStream_t st) {
+    dim3 grid(gl_cdiv(a.Nq, 128) * a.H * a.B);
+    attn_split_kernel<DQK><<<grid, dim3(256), attn_split_lds<DQK>(), st>>>(a);
+    GL_CHECK_LAUNCH();
+    return 0;
+}
+
 // V [B, Nk, *] -> V^T [B, H, d, ldvt] with zero fill of keys >= Nk.  One block per (64 keys, head, sample): 16-byte
 // global loads (8 channels of one key), a [64][d + 2] LDS tile (row stride chosen so that the 8 key groups of one
 // channel column fall on 8 different banks), 16-byte global stores (8 consecutive keys of one channel; 8 lanes
@@ -445,6 +659,16 @@ extern "C" int gl_attention(const gl_attn_args* a, void* stream) {
     if (a->ldvt < ((a->Nk + 63) / 64) * 64) return GL_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int d = a->d;
+    if (a->q_lo != nullptr || a->k_lo != nullptr || a->vt_lo != nullptr) {
+        if (!a->q_lo || !a->k_lo || !a->vt_lo || (a->ldo % 4)) return GL_ERR_BAD_ARG;
+        if (d <= 16) return launch_attn_split<16>(*a, st);
+        if (d <= 32) return launch_attn_split<32>(*a, st);
+        if (d <= 48) return launch_attn_split<48>(*a, st);
+        if (d <= 64) return launch_attn_split<64>(*a, st);
+        if (d <= 80) return launch_attn_split<80>(*a, st);
+        if (d <= 128) return launch_attn_split<128>(*a, st);
+        return launch_attn_split<160>(*a, st);
+    }
     if (d <= 16) return launch_attn_auto<16>(*a, st);
     if (d <= 32) return launch_attn_auto<32>(*a, st);
     if (d <= 48) return launch_attn_auto<48>(*a, st);
@@ -452,6 +676,13 @@ extern "C" int gl_attention(const gl_attn_args* a, void* stream) {
     if (d <= 80) return launch_attn_auto<80>(*a, st);
     if (d <= 128) return launch_attn_auto<128>(*a, st);
     return launch_attn_auto<160>(*a, st);
+}
+
+extern "C" int gl_init_attn(void) {
+    // the split-fp16 kernel's LDS exceeds the 64 KB static limit at the largest head dims
+    hipError_t e = hipFuncSetAttribute((const void*)attn_split_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_split_lds<128>());
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_split_kernel<160>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_split_lds<160>());
+    return e == hipSuccess ? 0 : (int)e;
 }
 
 extern "C" int gl_transpose_v(const void* v, int64_t v_bstride, int32_t ldv, void* vt, int32_t ldvt, int32_t B,

@@ -58,6 +58,14 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
     return r;
 }
 
+// The value a [hi | lo] split is taken of must be ONE value: hipcc may otherwise clone the expression that produces it (e.g. into the
+// branch that stores the lo half) and contract the clones differently; fp16(v1) and v2 - fp16(v2) then disagree about the rounding of the
+// hi half whenever v sits on a rounding tie (measured: 30 of 655 360 GEGLU outputs off by one fp16 ulp).  An empty asm pins the value.
+__device__ __forceinline__ float pin_value(float v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 __device__ __forceinline__ uint4 ld16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
 __device__ __forceinline__ void st16(void* p, uint4 v) { *reinterpret_cast<uint4*>(p) = v; }
 

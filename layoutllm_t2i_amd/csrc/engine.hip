@@ -36,6 +36,10 @@ constexpr int64_t WS_BYTES = 96ll << 20; // split-K fp32 partial tiles
 #define g_rela_compact gl_opt(43) // default 1;                   // the relation chain runs on max_b nvalid[b] (rounded up to 8) rows per sample instead of max_objs = 30
 #define g_w3 gl_opt(45)          // default 1024;                // with key 41: the 1x1 convs' third pass xhi.Wlo (weights stored [Whi | Wlo]) for launches of more than this many rows (>= 1024; 0 = off)
 #define g_in_split gl_opt(38)     // default 1;                   // the first conv's input as [hi | lo | hi] channels against [Whi | Whi | Wlo] weights (free: 4 of 64 padded channels are used)
+#define g_strict gl_opt(50)       // default 0;                   // STRICT mode (handles created with split_weights): every matrix product takes split-fp16
+                                                                  // operands -- activations [hi | lo] against the weight, + a third pass hi.Wlo with key 51 --
+                                                                  // so that the forward reproduces the fp32 reference within north_star's rtol 1e-3 / atol 1e-4
+#define g_strict_w3 gl_opt(51)    // default 1;                   // strict: the third pass x.Wlo (weights stored [Whi | Wlo])
 #define g_share gl_opt(44)        // default 1;                   // 2B = [cond ; uncond] forwards: everything before the first conditioning-dependent op
                                                                   // (conv_in, the first ResBlock, proj_in .. attn1 of the first transformer) runs ONCE on
                                                                   // the B shared latents and is duplicated
@@ -134,7 +138,7 @@ struct gl_engine {
     bool cond_set = false;
     int Bn = 0, R = 0, Lc = 0, hw = 0;
     // graphs
-    std::map<std::tuple<int, int, int, int, int, int, int>, hipGraphExec_t> graphs;
+    std::map<std::tuple<int, int, int, int, int, int, int, int>, hipGraphExec_t> graphs;
     float fuser_scale_cur = -1e30f;
     std::vector<float> gate_host;      // the [n_st][4] array last computed
     float* gate_pin[2] = {nullptr, nullptr};           // pinned double buffer the async upload reads from
@@ -199,8 +203,12 @@ void add_w(gl_engine* e, const std::string& name, int dtype, std::initializer_li
     e->tab[name] = w;
     e->names.push_back(name);
 }
+// a matrix [n, k]: with cfg.split_weights stored as rows [Whi | Wlo] (k columns each)
+void add_mat(gl_engine* e, const std::string& name, int64_t n, int64_t k) {
+    add_w(e, name, 0, {n, e->cfg.split_weights ? 2 * k : k});
+}
 void add_lin(gl_engine* e, const std::string& p, int64_t n, int64_t k, bool bias = true) {
-    add_w(e, p + ".w", 0, {n, k});
+    add_mat(e, p + ".w", n, k);
     if (bias) add_w(e, p + ".b", 1, {n});
 }
 // the three kinds of 1x1 conv (skip_connection, proj_in, proj_out): weight rows [Whi | Wlo], Whi = fp16(W), Wlo = fp16(W - Whi)
@@ -212,12 +220,13 @@ void add_norm(gl_engine* e, const std::string& p, int64_t c) {
     add_w(e, p + ".g", 1, {c});
     add_w(e, p + ".b", 1, {c});
 }
-void add_conv3(gl_engine* e, const std::string& p, int64_t cin, int64_t cout) {
-    add_w(e, p + ".w", 0, {cout, 9 * cin});
+// (the first conv keeps its own split form inside its padded input channels: split = false)
+void add_conv3(gl_engine* e, const std::string& p, int64_t cin, int64_t cout, bool split = true) {
+    add_w(e, p + ".w", 0, {cout, (split && e->cfg.split_weights ? 18 : 9) * cin});
     add_w(e, p + ".b", 1, {cout});
 }
 void add_ff(gl_engine* e, const std::string& p, int64_t C) {
-    add_w(e, p + ".ff1.w", 0, {8 * C, C});
+    add_mat(e, p + ".ff1.w", 8 * C, C);
     add_w(e, p + ".ff1.b", 1, {8 * C});
     add_lin(e, p + ".ff2", C, 4 * C);
 }
@@ -286,8 +295,8 @@ void build_table(gl_engine* e) {
     const int mc = c.model_channels, te = 4 * mc, ctx = c.context_dim;
     add_lin(e, "time_embed.0", te, mc);
     add_lin(e, "time_embed.2", te, te);
-    add_conv3(e, "input_blocks.0.0", CIN_PAD, mc);
-    add_conv3(e, "sd_first_conv", CIN_PAD, mc);
+    add_conv3(e, "input_blocks.0.0", CIN_PAD, mc, false);
+    add_conv3(e, "sd_first_conv", CIN_PAD, mc, false);
     int off = 0;
     for_all_layers(e, [&](LayerD& l) {
         const std::string& p = l.prefix;
@@ -308,16 +317,16 @@ void build_table(gl_engine* e) {
             add_lin_split(e, p + ".proj_in", C, C);
             add_lin_split(e, p + ".proj_out", C, C);
             const std::string t = p + ".transformer_blocks.0";
-            add_w(e, t + ".attn1.qkv.w", 0, {3 * C, C});
+            add_mat(e, t + ".attn1.qkv.w", 3 * C, C);
             add_lin(e, t + ".attn1.o", C, C);
-            add_w(e, t + ".attn2.q.w", 0, {C, C});
-            add_w(e, t + ".attn2.kv.w", 0, {2 * C, ctx});
+            add_mat(e, t + ".attn2.q.w", C, C);
+            add_mat(e, t + ".attn2.kv.w", 2 * C, ctx);
             add_lin(e, t + ".attn2.o", C, C);
             add_ff(e, t + ".ff", C);
             for (const char* n : {".norm1", ".norm2", ".norm3"}) add_norm(e, t + n, C);
             const std::string f = t + ".fuser";
             add_lin(e, f + ".linear", C, ctx);
-            add_w(e, f + ".attn.qkv.w", 0, {3 * C, C});
+            add_mat(e, f + ".attn.qkv.w", 3 * C, C);
             add_lin(e, f + ".attn.o", C, C);
             add_ff(e, f + ".ff", C);
             add_norm(e, f + ".norm1", C);
@@ -325,8 +334,8 @@ void build_table(gl_engine* e) {
             add_w(e, f + ".tanh_attn", 1, {1});
             add_w(e, f + ".tanh_dense", 1, {1});
             const std::string r = t + ".rela_fuse";
-            add_w(e, r + ".attn.q.w", 0, {C, C});
-            add_w(e, r + ".attn.kv.w", 0, {2 * C, ctx});
+            add_mat(e, r + ".attn.q.w", C, C);
+            add_mat(e, r + ".attn.kv.w", 2 * C, ctx);
             add_lin(e, r + ".attn.o", C, C);
             add_ff(e, r + ".ff", C);
             for (const char* n : {".norm1", ".norm2", ".norm3"}) add_norm(e, r + n, C);
@@ -385,12 +394,14 @@ struct Run {
         g.w = e->W(w);
         g.bias = bias.empty() ? nullptr : e->Wf(bias);
         g.M = M; g.N = (int)wi->shape[0]; g.K = (int)wi->shape[1];
-        if (wsplit) {           // weight rows [Whi | Wlo] (add_lin_split): the true K is half the stored row
+        const bool strict = g_strict != 0 && e->cfg.split_weights;
+        if (wsplit || e->cfg.split_weights) {           // weight rows [Whi | Wlo] (add_lin_split; every matrix of a split_weights table): the true K is half the stored row
             const int Kc = g.K / 2;
             g.ldw = g.K; g.K = Kc;
             if (hilo_a) {       // x.W = xhi.Whi + xlo.Whi (+ xhi.Wlo: third K segment, A from the second source = the hi half again)
                 g.kwrap = Kc; g.K = 2 * Kc;
-                if (g_w3 > 0 && M > (g_w3 < 1024 ? 1024 : g_w3) && a2 == nullptr) {
+                const bool third = strict ? (g_strict_w3 != 0) : (g_w3 > 0 && M > (g_w3 < 1024 ? 1024 : g_w3));
+                if (third && a2 == nullptr) {
                     g.K = 3 * Kc; g.a2 = a; g.lda2 = lda; g.ksplit = 2 * Kc;
                 }
             }
@@ -411,6 +422,7 @@ struct Run {
         gl_gemm_args g{};
         g.a = a; g.lda = lda; g.w = e->W(w);
         g.M = M; g.N = (int)wi->shape[0]; g.K = (int)wi->shape[1];
+        if (e->cfg.split_weights) { g.ldw = g.K; g.K /= 2; }      // rows [Whi | Wlo]: the default mode reads Whi
         g.epi = GL_EPI_BIAS; g.out_mode = GL_OUT_F16_ROWMAJOR; g.out = out; g.ldc = ldc;
         g.vt = vt; g.vt_col0 = vt_col0; g.vt_rows = vt_rows; g.vt_d = vt_d; g.vt_ld = vt_ld; g.vt_H = vt_H;
         g.workspace = ws; g.workspace_bytes = WS_BYTES;
@@ -419,10 +431,15 @@ struct Run {
     }
     int conv(const void* in, const std::string& w, const std::string& bias, int B, int Hin, int Win, int Cin, int stride, int ups,
              void* out, int out_mode, int epi = GL_EPI_BIAS, const void* res = nullptr, int ldres = 0, int res_f32 = 0,
-             const void* rowbias = nullptr, int ld_rowbias = 0, int rows_per_sample = 0, void* out2 = nullptr, int nchw_hw = 0) {
+             const void* rowbias = nullptr, int ld_rowbias = 0, int rows_per_sample = 0, void* out2 = nullptr, int nchw_hw = 0,
+             bool hilo_in = false) {
         const WInfo* wi = e->wi(w);
         if (!wi) return GL_ERR_BAD_ARG;
         gl_conv_args a{};
+        // weight rows [Whi | Wlo] in a split_weights table (not the first conv, which is split inside its padded channels)
+        a.w_split = wi->shape[1] == 18 * (int64_t)Cin;
+        // strict: the input pixels are [hi | lo] rows (2 Cin channels); third pass hi.Wlo with key 51
+        a.in_split = hilo_in ? ((a.w_split && g_strict_w3 != 0) ? 3 : 2) : 0;
         a.in = in; a.B = B; a.Hin = Hin; a.Win = Win; a.Cin = Cin;
         a.Hout = ups ? 2 * Hin : (Hin + 2 - 3) / stride + 1;
         a.Wout = ups ? 2 * Win : (Win + 2 - 3) / stride + 1;
@@ -431,17 +448,23 @@ struct Run {
         a.g.epi = epi; a.g.out_mode = out_mode; a.g.out = out; a.g.ldc = a.g.N; a.g.hw = nchw_hw;
         a.g.res = res; a.g.ldres = ldres; a.g.res_f32 = res_f32;
         a.g.rowbias = rowbias; a.g.ld_rowbias = ld_rowbias; a.g.rows_per_sample = rows_per_sample;
-        a.g.rowbias_f32 = rowbias != nullptr && g_precise != 0;      // precise mode: the emb_layers output stays fp32
+        a.g.rowbias_f32 = rowbias != nullptr && (g_precise != 0 || g_strict != 0);      // precise mode: the emb_layers output stays fp32
         a.g.out2 = out2; a.g.ldc2 = a.g.N;
         a.g.workspace = ws; a.g.workspace_bytes = WS_BYTES;
         ++launches;
         return gl_conv3x3(&a, st);
     }
+    // y_lo: rows written as [hi | lo] (ldy >= 2 C): the split-fp16 operand of the projection that follows (strict mode)
     int ln(const void* x, int ldx, int x_f32, half_t* y, int ldy, const std::string& p, int B, int rows_in, int rows_out, int row_off,
-           int C, float* stats = nullptr, const void* x2 = nullptr, int rows2 = 0, int x2_f32 = 0) {
+           int C, float* stats = nullptr, const void* x2 = nullptr, int rows2 = 0, int x2_f32 = 0, bool y_lo = false) {
         ++launches;
-        return gl_layernorm(x, ldx, x_f32 | (x2_f32 ? 4 : 0), y, ldy, e->Wf(p + ".g"), e->Wf(p + ".b"), B, rows_in, rows_out, row_off, C, 1e-5f, stats,
-                            x2, C, rows2, st);
+        return gl_layernorm(x, ldx, x_f32 | (x2_f32 ? 4 : 0) | (y_lo ? 8 : 0), y, ldy, e->Wf(p + ".g"), e->Wf(p + ".b"), B, rows_in, rows_out, row_off, C,
+                            1e-5f, stats, x2, C, rows2, st);
+    }
+    // fp32 rows -> fp16 [hi | lo] rows (strict mode: stream tensors entering a down / up conv, conditioning tensors)
+    int split(const float* x, int64_t rows, int C, half_t* y) {
+        ++launches;
+        return gl_split_f32(x, C, rows, C, y, 2 * C, st);
     }
     // x_f32: the sources are fp32 stream tensors; out_lo / raw: the split-fp16 side outputs of gl_groupnorm_ex
     int gn(const void* x1, int C1, const void* x2, int C2, int x_f32, int B, int HW, const std::string& p, float eps, int silu, half_t* out,
@@ -458,8 +481,10 @@ struct Run {
         return gl_groupnorm_ex(&a, st);
     }
     int attn(const half_t* q, int64_t qb, int ldq, const half_t* k, int64_t kb, int ldk, const half_t* vt, int ldvt, half_t* out,
-             int64_t ob, int ldo, int B, int H, int d, int Nq, int Nk) {
+             int64_t ob, int ldo, int B, int H, int d, int Nq, int Nk, const half_t* q_lo = nullptr, const half_t* k_lo = nullptr,
+             const half_t* vt_lo = nullptr, half_t* out_lo = nullptr) {
         gl_attn_args a{};
+        a.q_lo = q_lo; a.k_lo = k_lo; a.vt_lo = vt_lo; a.out_lo = out_lo;
         a.q = q; a.q_bstride = qb; a.ldq = ldq; a.k = k; a.k_bstride = kb; a.ldk = ldk; a.vt = vt; a.ldvt = ldvt;
         a.out = out; a.o_bstride = ob; a.ldo = ldo; a.B = B; a.H = H; a.d = d; a.Nq = Nq; a.Nk = Nk;
         a.scale = 1.0f / sqrtf((float)d);
@@ -532,6 +557,24 @@ int self_attention(Run& r, const half_t* src, int rows_per_b, int Nq, int Nk, in
                    half_t** out) {
     gl_engine* e = r.e;
     const int Bn = e->Bn, H = e->cfg.num_heads;
+    if (g_strict != 0) {
+        // strict: src rows are [hi | lo] (2 C); q | k | v leave the projection as [hi (3 C) | lo (3 C)] rows, V^T hi / lo through the
+        // transpose kernel, split-fp16 attention, output rows [hi | lo] (2 C) for the to_out projection
+        half_t* qkv = e->h16(tag + ".qkv", (size_t)Bn * rows_per_b * 6 * C);
+        const int ldvt = vt_ld(Nk > rows_per_b ? Nk : rows_per_b);
+        half_t* vt = e->h16(tag + ".vt", (size_t)2 * Bn * H * d * ldvt);
+        half_t* vtl = vt + (size_t)Bn * H * d * ldvt;
+        half_t* att = e->h16(tag + ".att", (size_t)Bn * Nq * 2 * C);
+        CKP(qkv); CKP(vt); CKP(att);
+        CK(r.gemm(src, 2 * C, wp + ".qkv.w", Bn * rows_per_b, qkv, 6 * C, GL_OUT_F16_HILO, "", GL_EPI_BIAS, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, 0, 0,
+                  true));
+        const int64_t bs = (int64_t)rows_per_b * 6 * C;
+        CK(r.transpose_v(qkv + 2 * C, bs, 6 * C, vt, ldvt, Bn, H, d, Nk));
+        CK(r.transpose_v(qkv + 5 * C, bs, 6 * C, vtl, ldvt, Bn, H, d, Nk));
+        CK(r.attn(qkv, bs, 6 * C, qkv + C, bs, 6 * C, vt, ldvt, att, (int64_t)Nq * 2 * C, 2 * C, Bn, H, d, Nq, Nk, qkv + 3 * C, qkv + 4 * C, vtl, att + C));
+        *out = att;
+        return 0;
+    }
     half_t* qkv = e->h16(tag + ".qkv", (size_t)Bn * rows_per_b * 3 * C);
     const int ldvt = vt_ld(Nk > rows_per_b ? Nk : rows_per_b);      // the fused V^T tail writes one column per ROW (pad rows included)
     half_t* vt = e->h16(tag + ".vt", (size_t)Bn * H * d * ldvt);
@@ -554,7 +597,15 @@ int self_attention(Run& r, const half_t* src, int rows_per_b, int Nq, int Nk, in
 
 int feed_forward(Run& r, const half_t* xn, const float* res, const std::string& p, int M, int C, void* out, int out_mode, const float* gate) {
     const int ldc = out_mode == GL_OUT_F16_HILO ? 2 * C : C;       // [hi | lo] rows for a split-fp16 consumer
-    if (gl_ff_fused_applicable(C, M)) {
+    if (g_strict != 0) {
+        // strict: xn rows are [hi | lo]; the GEGLU rows leave the first projection as [hi (4 C) | lo (4 C)]
+        half_t* hg = r.e->h16("ff.h", (size_t)M * 8 * C);
+        CKP(hg);
+        CK(r.gemm(xn, 2 * C, p + ".ff1.w", M, hg, 8 * C, GL_OUT_F16_HILO, p + ".ff1.b", GL_EPI_GEGLU, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, 0, 0, true));
+        return r.gemm(hg, 8 * C, p + ".ff2.w", M, out, ldc, out_mode, p + ".ff2.b", gate ? GL_EPI_GATE_RES : GL_EPI_RES, res, C, 1, gate, nullptr, 0, nullptr, 0,
+                      0, true);
+    }
+    if (gl_ff_fused_applicable(C, M) && !r.e->cfg.split_weights) {
         // narrow / long level: the whole FeedForward in one launch, the [M, 4C] GEGLU intermediate never leaves the CU
         gl_ff_args a{};
         a.x = xn; a.ldx = C;
@@ -582,16 +633,19 @@ int res_block(Run& r, const LayerD& l, Stream2 h, const Stream2* skip, int skip_
     const int Bn = e->Bn, HW = side * side, M = Bn * HW;
     const std::string& p = l.prefix;
     const int c1 = l.cin - skip_c;
-    const bool precise = g_precise != 0, h1f = precise && g_h1_f32 != 0, has_skip_conv = l.cin != l.cout;
-    half_t* t = e->h16("rb.gn1", (size_t)M * l.cin);
-    half_t* t2 = e->h16("rb.gn2", (size_t)M * l.cout);
+    const bool strict = g_strict != 0;
+    const bool precise = g_precise != 0 || strict, h1f = precise && (g_h1_f32 != 0 || strict), has_skip_conv = l.cin != l.cout;
+    // strict: both GroupNorm outputs are [hi | lo] pixel rows, the 3x3 convs take split-fp16 inputs
+    half_t* t = e->h16("rb.gn1", (size_t)M * l.cin * (strict ? 2 : 1));
+    half_t* t2 = e->h16("rb.gn2", (size_t)M * l.cout * (strict ? 2 : 1));
     CKP(t); CKP(t2);
     // in_layers GroupNorm + SiLU.  precise: reads the fp32 stream itself and, for a block with a 1x1 skip_connection, also writes
     // the raw input concat as [hi | lo] fp16 -- the split-fp16 operand of that 1x1 conv (its input IS the block input, :231)
     half_t* split = nullptr;
     if (precise) {
         if (has_skip_conv) { split = e->h16("rb.split", (size_t)M * 2 * l.cin); CKP(split); }
-        CK(r.gn(h.f, c1, skip ? skip->f : nullptr, skip_c, 1, Bn, HW, p + ".in_layers.0", 1e-5f, 1, t, 0, nullptr, split, 2 * l.cin));
+        CK(r.gn(h.f, c1, skip ? skip->f : nullptr, skip_c, 1, Bn, HW, p + ".in_layers.0", 1e-5f, 1, t, strict ? 2 * l.cin : 0, strict ? t + l.cin : nullptr,
+                split, 2 * l.cin));
     } else {
         CKP(h.h);
         CK(r.gn(h.h, c1, skip ? skip->h : nullptr, skip_c, 0, Bn, HW, p + ".in_layers.0", 1e-5f, 1, t));
@@ -602,8 +656,8 @@ int res_block(Run& r, const LayerD& l, Stream2 h, const Stream2* skip, int skip_
     CK(r.conv(t, p + ".in_layers.2.w", p + ".in_layers.2.b", Bn, side, side, l.cin, 1, 0, h1, h1f ? GL_OUT_F32_ROWMAJOR : GL_OUT_F16_ROWMAJOR,
               GL_EPI_ROWBIAS, nullptr, 0, 0,
               precise ? (const void*)(reinterpret_cast<const float*>(emb_out) + off) : (const void*)(reinterpret_cast<const half_t*>(emb_out) + off),
-              e->emb_total, HW));
-    CK(r.gn(h1, l.cout, nullptr, 0, h1f ? 1 : 0, Bn, HW, p + ".out_layers.0", 1e-5f, 1, t2));
+              e->emb_total, HW, nullptr, 0, strict));
+    CK(r.gn(h1, l.cout, nullptr, 0, h1f ? 1 : 0, Bn, HW, p + ".out_layers.0", 1e-5f, 1, t2, strict ? 2 * l.cout : 0, strict ? t2 + l.cout : nullptr));
     const float* sk = h.f;
     if (has_skip_conv) {
         float* skb = e->f32("rb.skip.f32", (size_t)M * l.cout);
@@ -624,7 +678,7 @@ int res_block(Run& r, const LayerD& l, Stream2 h, const Stream2* skip, int skip_
     CKP(out->f);
     if (need_h) CKP(out->h);
     return r.conv(t2, p + ".out_layers.3.w", p + ".out_layers.3.b", Bn, side, side, l.cout, 1, 0, out->f, GL_OUT_F32_ROWMAJOR, GL_EPI_RES, sk, l.cout, 1,
-                  nullptr, 0, 0, out->h);
+                  nullptr, 0, 0, out->h, 0, strict);
 }
 
 // SpatialTransformer.forward + BasicTransformerBlock._forward (attention.py:436-446, :394-402)
@@ -641,9 +695,11 @@ int spatial_transformer(Run& r, const LayerD& l, int li, Stream2 xin, int side, 
     const std::string sl = std::to_string(li);
     float* xa = e->f32("st.xa", (size_t)M * C);
     float* xb = e->f32("st.xb", (size_t)M * C);
-    const bool precise = g_precise != 0;
+    const bool strict = g_strict != 0;
+    const bool precise = g_precise != 0 || strict;
+    const int lnw = strict ? 2 * C : C;          // strict: every LayerNorm writes [hi | lo] rows for the projection behind it
     half_t* g0 = e->h16("st.gn", (size_t)M * C * (precise ? 2 : 1));
-    half_t* lnb = e->h16("st.ln", (size_t)M * C);
+    half_t* lnb = e->h16("st.ln", (size_t)M * lnw);
     CKP(xa); CKP(xb); CKP(g0); CKP(lnb);
     const float* gates = e->f32("gates", e->st_layers.size() * 4) + (size_t)li * 4;
     float* x = xa;
@@ -664,10 +720,10 @@ int spatial_transformer(Run& r, const LayerD& l, int li, Stream2 xin, int side, 
         }
         // --- attn1 (attention.py:395)
         half_t* att1 = nullptr;
-        CK(r.ln(x, C, 1, lnb, C, t + ".norm1", B1, N, N, 0, C));
+        CK(r.ln(x, C, 1, lnb, lnw, t + ".norm1", B1, N, N, 0, C, nullptr, nullptr, 0, 0, strict));
         CK(self_attention(r, lnb, N, N, N, C, d, t + ".attn1", "st.sa", &att1));
         float* y = nxt(x);
-        CK(r.gemm(att1, C, t + ".attn1.o.w", M1, y, C, GL_OUT_F32_ROWMAJOR, t + ".attn1.o.b", GL_EPI_RES, x, C, 1));
+        CK(r.gemm(att1, lnw, t + ".attn1.o.w", M1, y, C, GL_OUT_F32_ROWMAJOR, t + ".attn1.o.b", GL_EPI_RES, x, C, 1, nullptr, nullptr, 0, nullptr, 0, 0, strict));
         x = y;
         if (share_half) {
             // the uncond half: identical up to here (same latent, t, weights; attention.py:395 is the last op before the conditioning enters)
@@ -684,18 +740,20 @@ int spatial_transformer(Run& r, const LayerD& l, int li, Stream2 xin, int side, 
         // pad rows are never normalised into (arbitrary finite-or-not contents): as keys they are masked by the attention
         // kernel (Nk = N + mo), as queries they are not used (Nq = N)
         const int rows = N + ((mo + 7) & ~7);
-        half_t* cat = e->h16("st.cat", (size_t)Bn * rows * C);
+        half_t* cat = e->h16("st.cat", (size_t)Bn * rows * lnw);
         CKP(cat);
-        if (precise) {
+        if (strict) {
+            CK(r.ln(x, C, 1, cat, lnw, f + ".norm1", Bn, N, rows, 0, C, nullptr, e->f32("hoist.objs32s." + sl, (size_t)Bn * mo * C), mo, 1, true));
+        } else if (precise) {
             CK(r.ln(x, C, 1, cat, C, f + ".norm1", Bn, N, rows, 0, C, nullptr, e->f32("hoist.objs32." + sl, (size_t)Bn * mo * C), mo, 1));
         } else {
             CK(r.ln(x, C, 1, cat, C, f + ".norm1", Bn, N, rows, 0, C, nullptr, e->h16("hoist.objs." + sl, (size_t)Bn * mo * C), mo));
         }
         CK(self_attention(r, cat, rows, N, N + mo, C, d, f + ".attn", "st.fa", &att));
         float* y = nxt(x);
-        CK(r.gemm(att, C, f + ".attn.o.w", M, y, C, GL_OUT_F32_ROWMAJOR, f + ".attn.o.b", GL_EPI_GATE_RES, x, C, 1, gates + 0));
+        CK(r.gemm(att, lnw, f + ".attn.o.w", M, y, C, GL_OUT_F32_ROWMAJOR, f + ".attn.o.b", GL_EPI_GATE_RES, x, C, 1, gates + 0, nullptr, 0, nullptr, 0, 0, strict));
         x = y;
-        CK(r.ln(x, C, 1, lnb, C, f + ".norm2", Bn, N, N, 0, C));
+        CK(r.ln(x, C, 1, lnb, lnw, f + ".norm2", Bn, N, N, 0, C, nullptr, nullptr, 0, 0, strict));
         y = nxt(x);
         CK(feed_forward(r, lnb, x, f + ".ff", M, C, y, GL_OUT_F32_ROWMAJOR, gates + 1));
         x = y;
@@ -744,7 +802,7 @@ int spatial_transformer(Run& r, const LayerD& l, int li, Stream2 xin, int side, 
         float* y = nxt(x);
         ++r.launches;
         // ... and LayerNorm(norm2) of the merged rows in the same launch (the rows attn2's q projection reads)
-        const bool fuse_ln2 = g_fuse_merge_ln && ms <= 32;
+        const bool fuse_ln2 = g_fuse_merge_ln && ms <= 32 && !strict;      // (strict: norm2 is a launch of its own that also writes the lo half)
         CK(gl_rela_merge(x, 1, nullptr, stats, e->Wf(rf + ".norm3.g"), e->Wf(rf + ".norm3.b"), f2, Bn, side, side, C, rects, nvalid, poison, mo, ms, y,
                          fuse_ln2 ? e->Wf(t + ".norm2.g") : nullptr, fuse_ln2 ? e->Wf(t + ".norm2.b") : nullptr, fuse_ln2 ? lnb : nullptr, r.st));
         x = y;
@@ -752,24 +810,37 @@ int spatial_transformer(Run& r, const LayerD& l, int li, Stream2 xin, int side, 
     }
     // --- attn2: text cross-attention with hoisted K/V (attention.py:400)
     {
-        half_t* q2 = e->h16("st.q2", (size_t)M * C);
-        half_t* a2 = e->h16("st.att2", (size_t)M * C);
-        const half_t* kv = e->h16("hoist.kvctx." + sl, (size_t)Bn * Lc * 2 * C);
+        half_t* q2 = e->h16("st.q2", (size_t)M * lnw);
+        half_t* a2 = e->h16("st.att2", (size_t)M * lnw);
         const int ldvt = vt_ld(Lc);
-        const half_t* vtc = e->h16("hoist.vtctx." + sl, (size_t)Bn * H * d * ldvt);
-        CKP(q2); CKP(a2); CKP(kv); CKP(vtc);
-        if (!ln2_done) CK(r.ln(x, C, 1, lnb, C, t + ".norm2", Bn, N, N, 0, C));
-        CK(r.gemm(lnb, C, t + ".attn2.q.w", M, q2, C));
-        CK(r.attn(q2, (int64_t)N * C, C, kv, (int64_t)Lc * 2 * C, 2 * C, vtc, ldvt, a2, (int64_t)N * C, C, Bn, H, d, N, Lc));
+        CKP(q2); CKP(a2);
         float* y = nxt(x);
-        CK(r.gemm(a2, C, t + ".attn2.o.w", M, y, C, GL_OUT_F32_ROWMAJOR, t + ".attn2.o.b", GL_EPI_RES, x, C, 1));
+        if (strict) {
+            // hoisted K / V of the text context as [k v | k_lo v_lo] rows and V^T hi / lo (gl_set_conditioning, split_weights handles)
+            const half_t* kv = e->h16("hoist.kvctxs." + sl, (size_t)Bn * Lc * 4 * C);
+            const half_t* vtc = e->h16("hoist.vtctxs." + sl, (size_t)2 * Bn * H * d * ldvt);
+            CKP(kv); CKP(vtc);
+            CK(r.ln(x, C, 1, lnb, lnw, t + ".norm2", Bn, N, N, 0, C, nullptr, nullptr, 0, 0, true));
+            CK(r.gemm(lnb, lnw, t + ".attn2.q.w", M, q2, lnw, GL_OUT_F16_HILO, "", GL_EPI_BIAS, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, 0, 0, true));
+            CK(r.attn(q2, (int64_t)N * lnw, lnw, kv, (int64_t)Lc * 4 * C, 4 * C, vtc, ldvt, a2, (int64_t)N * lnw, lnw, Bn, H, d, N, Lc, q2 + C, kv + 2 * C,
+                      vtc + (size_t)Bn * H * d * ldvt, a2 + C));
+            CK(r.gemm(a2, lnw, t + ".attn2.o.w", M, y, C, GL_OUT_F32_ROWMAJOR, t + ".attn2.o.b", GL_EPI_RES, x, C, 1, nullptr, nullptr, 0, nullptr, 0, 0, true));
+        } else {
+            const half_t* kv = e->h16("hoist.kvctx." + sl, (size_t)Bn * Lc * 2 * C);
+            const half_t* vtc = e->h16("hoist.vtctx." + sl, (size_t)Bn * H * d * ldvt);
+            CKP(kv); CKP(vtc);
+            if (!ln2_done) CK(r.ln(x, C, 1, lnb, C, t + ".norm2", Bn, N, N, 0, C));
+            CK(r.gemm(lnb, C, t + ".attn2.q.w", M, q2, C));
+            CK(r.attn(q2, (int64_t)N * C, C, kv, (int64_t)Lc * 2 * C, 2 * C, vtc, ldvt, a2, (int64_t)N * C, C, Bn, H, d, N, Lc));
+            CK(r.gemm(a2, C, t + ".attn2.o.w", M, y, C, GL_OUT_F32_ROWMAJOR, t + ".attn2.o.b", GL_EPI_RES, x, C, 1));
+        }
         x = y;
     }
     // --- GEGLU feed-forward (attention.py:401): the sum is only consumed by proj_out's matrix product -> fp16
     // (precise: as [hi | lo] rows, proj_out takes both halves against the same weight)
     half_t* x16 = e->h16("st.x6", (size_t)M * C * (precise ? 2 : 1));
     CKP(x16);
-    CK(r.ln(x, C, 1, lnb, C, t + ".norm3", Bn, N, N, 0, C));
+    CK(r.ln(x, C, 1, lnb, lnw, t + ".norm3", Bn, N, N, 0, C, nullptr, nullptr, 0, 0, strict));
     CK(feed_forward(r, lnb, x, t + ".ff", M, C, x16, precise ? GL_OUT_F16_HILO : GL_OUT_F16_ROWMAJOR, nullptr));
     // --- proj_out + residual (attention.py:444-446)
     out->f = e->f32(tag + ".f32", (size_t)M * C);
@@ -796,17 +867,30 @@ int launch_forward(gl_engine* e, int reps, bool fuser_on, bool sd_conv, bool uni
     float* eps = e->f32("out.eps", (size_t)Bn * cfg.out_channels * side * side);
     CKP(x_lat); CKP(t_buf); CKP(eps);
     // time embedding (openaimodel.py:428-429) and all emb_layers in one GEMM (:172-178, :220)
-    half_t* te = e->h16("te.sin", (size_t)Bn * mc);
-    half_t* e1 = e->h16("te.e1", (size_t)Bn * 4 * mc);
-    half_t* e2 = e->h16("te.e2", (size_t)Bn * 4 * mc);
+    const bool strict = g_strict != 0;
+    if (strict && !e->cfg.split_weights) { e->err = "strict mode (option 50) needs a handle created with split_weights"; return GL_ERR_BAD_ARG; }
+    const bool precise = g_precise != 0 || strict;
+    const int tw = strict ? 2 : 1;                 // strict: the time-embedding rows are [hi | lo] all the way
+    half_t* te = e->h16("te.sin", (size_t)Bn * mc * tw);
+    half_t* e1 = e->h16("te.e1", (size_t)Bn * 4 * mc * tw);
+    half_t* e2 = e->h16("te.e2", (size_t)Bn * 4 * mc * tw);
     // (precise mode: the 22 emb_layers outputs stay fp32 -- they are added to every element of a ResBlock's first conv result)
-    void* emb_out = g_precise ? (void*)e->f32("te.out32", (size_t)Bn * e->emb_total) : (void*)e->h16("te.out", (size_t)Bn * e->emb_total);
+    void* emb_out = precise ? (void*)e->f32("te.out32", (size_t)Bn * e->emb_total) : (void*)e->h16("te.out", (size_t)Bn * e->emb_total);
     CKP(te); CKP(e1); CKP(e2); CKP(emb_out);
     ++r.launches;
-    CK(gl_timestep_embedding(t_buf, Bn, mc, te, st));
-    CK(r.gemm(te, mc, "time_embed.0.w", Bn, e1, 4 * mc, GL_OUT_F16_ROWMAJOR, "time_embed.0.b", GL_EPI_SILU));
-    CK(r.gemm(e1, 4 * mc, "time_embed.2.w", Bn, e2, 4 * mc, GL_OUT_F16_ROWMAJOR, "time_embed.2.b", GL_EPI_SILU));
-    CK(r.gemm(e2, 4 * mc, "emb_all.w", Bn, emb_out, e->emb_total, g_precise ? GL_OUT_F32_ROWMAJOR : GL_OUT_F16_ROWMAJOR, "emb_all.b"));
+    if (strict) {
+        float* te32 = e->f32("te.sin32", (size_t)Bn * mc);
+        CKP(te32);
+        CK(gl_timestep_embedding_f32(t_buf, Bn, mc, te32, st));
+        CK(r.split(te32, Bn, mc, te));
+    } else {
+        CK(gl_timestep_embedding(t_buf, Bn, mc, te, st));
+    }
+    const int tom = strict ? GL_OUT_F16_HILO : GL_OUT_F16_ROWMAJOR;
+    CK(r.gemm(te, mc * tw, "time_embed.0.w", Bn, e1, 4 * mc * tw, tom, "time_embed.0.b", GL_EPI_SILU, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, 0, 0, strict));
+    CK(r.gemm(e1, 4 * mc * tw, "time_embed.2.w", Bn, e2, 4 * mc * tw, tom, "time_embed.2.b", GL_EPI_SILU, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, 0, 0, strict));
+    CK(r.gemm(e2, 4 * mc * tw, "emb_all.w", Bn, emb_out, e->emb_total, precise ? GL_OUT_F32_ROWMAJOR : GL_OUT_F16_ROWMAJOR, "emb_all.b", GL_EPI_BIAS, nullptr, 0, 0,
+              nullptr, nullptr, 0, nullptr, 0, 0, strict));
     // first conv on the zero-padded NHWC latent (openaimodel.py:299, :393-405)
     half_t* xin = e->h16("in.x", (size_t)Bn * side * side * CIN_PAD);
     CKP(xin);
@@ -815,7 +899,6 @@ int launch_forward(gl_engine* e, int reps, bool fuser_on, bool sd_conv, bool uni
     const std::string fc = sd_conv ? "sd_first_conv" : "input_blocks.0.0";
     // fp16 copies of stream tensors: only where a down / up conv consumes the tensor (precise mode: every GroupNorm and 1x1 conv
     // reads the fp32 stream), or everywhere in the round-3 fp16-copy mode
-    const bool precise = g_precise != 0;
     auto first_kind = [&](const BlockD* b) { return b && !b->layers.empty() ? b->layers[0].kind : -1; };
     auto wants_h = [&](int next_kind) { return !precise || next_kind == DOWN || next_kind == UP; };
     Stream2 h;
@@ -862,8 +945,15 @@ int launch_forward(gl_engine* e, int reps, bool fuser_on, bool sd_conv, bool uni
                 o.h = need_h ? e->h16(tag, (size_t)Bn * so * so * l.cout) : nullptr;
                 CKP(o.f); CKP(h.h);
                 if (need_h) CKP(o.h);
-                CK(r.conv(h.h, l.prefix + ".w", l.prefix + ".b", Bn, side, side, l.cin, 2, 0, o.f, GL_OUT_F32_ROWMAJOR, GL_EPI_BIAS, nullptr, 0, 0, nullptr,
-                          0, 0, o.h));
+                const half_t* cin_ = h.h;
+                if (strict) {          // the stream tensor itself as [hi | lo] pixel rows
+                    half_t* hs = e->h16("conv.split", (size_t)Bn * side * side * 2 * l.cin);
+                    CKP(hs);
+                    CK(r.split(h.f, (int64_t)Bn * side * side, l.cin, hs));
+                    cin_ = hs;
+                }
+                CK(r.conv(cin_, l.prefix + ".w", l.prefix + ".b", Bn, side, side, l.cin, 2, 0, o.f, GL_OUT_F32_ROWMAJOR, GL_EPI_BIAS, nullptr, 0, 0, nullptr,
+                          0, 0, o.h, 0, strict));
                 side = so;
             } else if (l.kind == UP) {
                 const int so = side * 2;
@@ -871,8 +961,15 @@ int launch_forward(gl_engine* e, int reps, bool fuser_on, bool sd_conv, bool uni
                 o.h = need_h ? e->h16(tag, (size_t)Bn * so * so * l.cout) : nullptr;
                 CKP(o.f); CKP(h.h);
                 if (need_h) CKP(o.h);
-                CK(r.conv(h.h, l.prefix + ".w", l.prefix + ".b", Bn, side, side, l.cin, 1, 1, o.f, GL_OUT_F32_ROWMAJOR, GL_EPI_BIAS, nullptr, 0, 0, nullptr,
-                          0, 0, o.h));
+                const half_t* cin_ = h.h;
+                if (strict) {
+                    half_t* hs = e->h16("conv.split", (size_t)Bn * side * side * 2 * l.cin);
+                    CKP(hs);
+                    CK(r.split(h.f, (int64_t)Bn * side * side, l.cin, hs));
+                    cin_ = hs;
+                }
+                CK(r.conv(cin_, l.prefix + ".w", l.prefix + ".b", Bn, side, side, l.cin, 1, 1, o.f, GL_OUT_F32_ROWMAJOR, GL_EPI_BIAS, nullptr, 0, 0, nullptr,
+                          0, 0, o.h, 0, strict));
                 side = so;
             } else {
                 return GL_ERR_BAD_ARG;
@@ -900,16 +997,19 @@ int launch_forward(gl_engine* e, int reps, bool fuser_on, bool sd_conv, bool uni
         if (sk.side != side) return GL_ERR_BAD_ARG;
         CK(run_block(e->output_blocks[i], "out." + std::to_string(i), &sk, i + 1 < e->output_blocks.size() ? &e->output_blocks[i + 1] : nullptr));
     }
-    half_t* g = e->h16("fin.gn", (size_t)Bn * side * side * e->out_channels_last);
+    const int ocl = e->out_channels_last;
+    half_t* g = e->h16("fin.gn", (size_t)Bn * side * side * ocl * (strict ? 2 : 1));
     CKP(g);
-    if (precise) {
+    if (strict) {
+        CK(r.gn(h.f, ocl, nullptr, 0, 1, Bn, side * side, "out.0", 1e-5f, 1, g, 2 * ocl, g + ocl));
+    } else if (precise) {
         CK(r.gn(h.f, e->out_channels_last, nullptr, 0, 1, Bn, side * side, "out.0", 1e-5f, 1, g));
     } else {
         CKP(h.h);
         CK(r.gn(h.h, e->out_channels_last, nullptr, 0, 0, Bn, side * side, "out.0", 1e-5f, 1, g));
     }
     CK(r.conv(g, "out.2.w", "out.2.b", Bn, side, side, e->out_channels_last, 1, 0, eps, GL_OUT_F32_NCHW, GL_EPI_BIAS, nullptr, 0, 0, nullptr, 0, 0, nullptr,
-              side * side));
+              side * side, strict));
     if (n_launches) *n_launches = r.launches;
     return 0;
 }
@@ -1039,6 +1139,51 @@ extern "C" int gl_set_conditioning(gl_engine* e, const float* context, const flo
         CK(r.gemm(rel16, ctx, t + ".rela_fuse.attn.kv.w", Bn * R, kvr, 2 * C));
         CK(r.transpose_v(kvr + C, (int64_t)R * 2 * C, 2 * C, vtr, ldr_, Bn, H, d, R));
     }
+    // --- strict mode's hoists (handles created with split_weights; computed with every conditioning so that option 50 can be switched per
+    //     step without a new gl_set_conditioning): the same tensors from split-fp16 operands all the way -- PositionNet on fp32 inputs
+    //     split into [hi | lo], every Linear with [hi | lo] activations (+ the third pass x.Wlo), K / V of the text context as
+    //     [k v | k_lo v_lo] rows with V^T hi / lo, fuser.linear(objs) in fp32
+    if (cfg.split_weights) {
+        gl_opts strict_opts = *(tl_gl_opts ? tl_gl_opts : &g_gl_opts);
+        strict_opts.v[50] = 1;
+        const gl_opts* prev_opts = tl_gl_opts;
+        tl_gl_opts = &strict_opts;                       // Run::gemm decides the third pass from the strict keys
+        struct Restore { const gl_opts* p; ~Restore() { tl_gl_opts = p; } } restore{prev_opts};
+        const size_t rows = (size_t)Bn * mo;
+        float* pin32 = e->f32("pn.in32", rows * pin_dim);
+        half_t* pins = e->h16("pn.ins", rows * 2 * pin_dim);
+        half_t* h1s = e->h16("pn.h1s", rows * 2 * 512);
+        half_t* h2s = e->h16("pn.h2s", rows * 2 * 512);
+        half_t* objss = e->h16("pn.objss", rows * 2 * cfg.pos_out_dim);
+        half_t* ctxs = e->h16("cond.ctxs", (size_t)Bn * Lc * 2 * ctx);
+        CKP(pin32); CKP(pins); CKP(h1s); CKP(h2s); CKP(objss); CKP(ctxs);
+        CK(gl_posnet_input_f32(boxes, masks, pos_emb, e->Wf("position_net.null_pos"), e->Wf("position_net.null_xyxy"), Bn * mo, cfg.pos_in_dim,
+                               cfg.fourier_freqs, pin32, st));
+        CK(r.split(pin32, (int64_t)rows, pin_dim, pins));
+        auto lin = [&](const half_t* a, int k, const std::string& w, void* out, int ldc, int out_mode, int epi) {
+            return r.gemm(a, 2 * k, w + ".w", (int)rows, out, ldc, out_mode, w + ".b", epi, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, 0, 0, true);
+        };
+        CK(lin(pins, pin_dim, "position_net.linears.0", h1s, 2 * 512, GL_OUT_F16_HILO, GL_EPI_SILU));
+        CK(lin(h1s, 512, "position_net.linears.2", h2s, 2 * 512, GL_OUT_F16_HILO, GL_EPI_SILU));
+        CK(lin(h2s, 512, "position_net.linears.4", objss, 2 * cfg.pos_out_dim, GL_OUT_F16_HILO, GL_EPI_BIAS));
+        CK(r.split(context, (int64_t)Bn * Lc, ctx, ctxs));
+        for (size_t li = 0; li < e->st_layers.size(); ++li) {
+            const LayerD& l = e->st_layers[li];
+            const std::string t = l.prefix + ".transformer_blocks.0";
+            const std::string sl = std::to_string(li);
+            const int C = l.cin, d = l.d_head;
+            float* o32 = e->f32("hoist.objs32s." + sl, rows * C);
+            CKP(o32);
+            CK(lin(objss, cfg.pos_out_dim, t + ".fuser.linear", o32, C, GL_OUT_F32_ROWMAJOR, GL_EPI_BIAS));
+            half_t* kv = e->h16("hoist.kvctxs." + sl, (size_t)Bn * Lc * 4 * C);
+            const int ldc_ = vt_ld(Lc);
+            half_t* vt = e->h16("hoist.vtctxs." + sl, (size_t)2 * Bn * H * d * ldc_);
+            CKP(kv); CKP(vt);
+            CK(r.gemm(ctxs, 2 * ctx, t + ".attn2.kv.w", Bn * Lc, kv, 4 * C, GL_OUT_F16_HILO, "", GL_EPI_BIAS, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, 0, 0, true));
+            CK(r.transpose_v(kv + C, (int64_t)Lc * 4 * C, 4 * C, vt, ldc_, Bn, H, d, Lc));
+            CK(r.transpose_v(kv + 3 * C, (int64_t)Lc * 4 * C, 4 * C, vt + (size_t)Bn * H * d * ldc_, ldc_, Bn, H, d, Lc));
+        }
+    }
     // --- integer rectangles per transformer resolution (attention.py:321-346)
     {
         std::vector<int> sides;
@@ -1064,21 +1209,21 @@ extern "C" int gl_set_conditioning(gl_engine* e, const float* context, const flo
         // resolutions, rounded up to 8.  One small device-to-host copy per conditioning (once per image batch, outside any capture).
         int slots = mo;
         if (g_rela_compact) {
-            std::vector<int> nv((size_t)Bn);
+            // every resolution's counts in flight, then ONE synchronisation
+            std::vector<int> nv((size_t)Bn * sides.size());
             int mx = 0;
-            for (int s_ : sides) {
-                const int* nvalid = reinterpret_cast<const int*>(e->buf("cond.nvalid." + std::to_string(s_), (size_t)Bn * 4));
+            for (size_t k = 0; k < sides.size(); ++k) {
+                const int* nvalid = reinterpret_cast<const int*>(e->buf("cond.nvalid." + std::to_string(sides[k]), (size_t)Bn * 4));
                 CKP(nvalid);
-                if (hipMemcpyAsync(nv.data(), nvalid, (size_t)Bn * 4, hipMemcpyDeviceToHost, st) != hipSuccess) return GL_ERR_BAD_ARG;
-                if (hipStreamSynchronize(st) != hipSuccess) return GL_ERR_BAD_ARG;
-                for (int v : nv) mx = v > mx ? v : mx;
+                if (hipMemcpyAsync(nv.data() + k * Bn, nvalid, (size_t)Bn * 4, hipMemcpyDeviceToHost, st) != hipSuccess) return GL_ERR_BAD_ARG;
             }
+            if (hipStreamSynchronize(st) != hipSuccess) return GL_ERR_BAD_ARG;
+            for (int v : nv) mx = v > mx ? v : mx;
             slots = (mx + 7) & ~7;
             if (slots < 8) slots = 8;
             if (slots > mo) slots = mo;
         }
-        if (slots != e->rel_slots) e->drop_graphs();
-        e->rel_slots = slots;
+        e->rel_slots = slots;          // part of the graph key: a rollout alternating between <= 8 and 9..16 boxes keeps both sets of graphs
     }
     if (e->pool_changed) e->drop_graphs();
     e->cond_set = true;
@@ -1115,7 +1260,7 @@ extern "C" int gl_unet_forward(gl_engine* e, const float* x, const float* t_dev,
         e->ovr_epoch = e->ovr.epoch;
     }
     const bool uniform_t = t_dev == nullptr;
-    const auto key = std::make_tuple(Bn, side, e->R, e->Lc, (int)fuser_on, (int)(sd_conv != 0), (int)reps + (uniform_t ? 16 : 0));
+    const auto key = std::make_tuple(Bn, side, e->R, e->Lc, (int)fuser_on, (int)(sd_conv != 0), (int)reps + (uniform_t ? 16 : 0), e->rel_slots);
     auto it = e->graphs.find(key);
     if (use_graph && it == e->graphs.end()) {
         // warm-up run allocates every pooled buffer, then the same launch sequence is captured

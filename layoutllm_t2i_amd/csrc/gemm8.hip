@@ -189,12 +189,12 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
         const int gc = (sslot ^ ((r >> 1) & 7)) << 3;
         const int n = n0 + r;
         const bool ok = (j < nb) && (r < BN) && (n < N);
-        bptr[j] = ok ? (Wg + (size_t)n * (CONV ? K : p.ldw) + gc) : zsrc;       // + the K-tile's offset at issue time
+        bptr[j] = ok ? (Wg + (size_t)n * p.ldw + gc) : zsrc;       // + the K-tile's offset at issue time (gl_conv3x3 sets ldw too)
         if (ok) bmask |= 1u << j;
     }
 
     // conv: (channel block, tap) of the K-tile the next issue refers to
-    const int ncblk = CONV ? cg.Cin >> 6 : 1;
+    const int ncblk = CONV ? K / 576 : 1;          // channel blocks the K walk visits (a split-fp16 input walks [hi | lo (| hi)])
     // K-tile visiting order as (outer, inner) counters: inner = tap (9) with channel blocks outside, or inner = channel block
     // with taps outside (tap-major: consecutive K-tiles then touch DIFFERENT 128-byte lines of the input pixels)
     const int in_lim = tap_major ? ncblk : 9;
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
 
     // per-K-tile issue state: refreshed by issue_begin() before the first unit of a K-tile
     int is_off = 0;                        // conv: wave-uniform element offset of (tap, channel block) from the centre pixel
-    int is_ky = 0, is_kx = 0;
+    int is_ky = 0, is_kx = 0, is_acb = 0;
     int is_boff = 0;                       // element offset of the K-tile inside a weight row
     auto issue_begin = [&]() __attribute__((always_inline)) {
         if constexpr (CONV) {
@@ -216,8 +216,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
             is_cblk = tap_major ? is_in : is_out;
             is_ky = (is_tap * 11) >> 5;                 // tap / 3 for tap in [0, 9)
             is_kx = is_tap - is_ky * 3;
-            is_off = ((is_ky - 1) * cg.Win + (is_kx - 1)) * cg.Cin + (is_cblk << 6);
+            is_acb = (cg.cwrap != 0 && is_cblk >= cg.cwrap) ? is_cblk - cg.cwrap : is_cblk;     // third pass of a split input: hi again
+            is_off = ((is_ky - 1) * cg.Win + (is_kx - 1)) * cg.Cin + (is_acb << 6);
             is_boff = (is_cblk * 9 + is_tap) << 6;
+            if (p.kwrap != 0 && is_boff >= p.kwrap) is_boff -= p.kwrap;      // [hi | lo] input against the same W (then Wlo: ONE step back)
         } else {
             is_boff = is_kt << 6;
             if (p.kwrap != 0 && is_boff >= p.kwrap) is_boff -= p.kwrap;      // weight reuse along K ([hi | lo] activations, same W)
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
                 int off = is_off;
                 if (cg.ups) {        // wave-uniform; this runs in the read section, outside the MFMA stream
                     const int ry = (is_ky - 1 + (int)((cmask[u] >> 9) & 1u)) >> 1, rx = (is_kx - 1 + (int)((cmask[u] >> 10) & 1u)) >> 1;
-                    off = (ry * cg.Win + rx) * cg.Cin + (is_cblk << 6);
+                    off = (ry * cg.Win + rx) * cg.Cin + (is_acb << 6);
                 }
                 const uint64_t a = reinterpret_cast<uint64_t>(aptr[u] + off), z = reinterpret_cast<uint64_t>(zsrc);
                 const uint64_t keep = (uint64_t)0 - (uint64_t)((cmask[u] >> is_tap) & 1u);
@@ -517,13 +519,16 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
                         const float4 g1 = *reinterpret_cast<const float4*>(stage + r * EPS + pc + 36);
                         float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
                         float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-                        half8_t o;
+                        half8_t o, lo8;
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             const float a = xv[j] + gg_bias[j], b = gv[j] + gg_bias[8 + j];
-                            o[j] = (half_t)(a * gelu_erf_f(b));
+                            const float y = pin_value(a * gelu_erf_f(b));
+                            o[j] = (half_t)y;
+                            lo8[j] = (half_t)(y - (float)o[j]);
                         }
                         st16(outp + (size_t)m * p.ldc + (nbase >> 1) + pc, *reinterpret_cast<uint4*>(&o));
+                        if (p.out_mode == GL_OUT_F16_HILO) st16(outp + (size_t)m * p.ldc + (N >> 1) + (nbase >> 1) + pc, *reinterpret_cast<uint4*>(&lo8));
                     }
                 }
             }

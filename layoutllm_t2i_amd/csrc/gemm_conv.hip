@@ -188,8 +188,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
         const int gc = (skc ^ swz(r)) << 3;
         const int n = n0 + r;
         const bool ok = (r < BN) && (n < N);
-        if constexpr (CONV) bptr[i] = ok ? (Wg + (size_t)n * K + k_first + gc) : zsrc;
-        else bptr[i] = ok ? (Wg + (size_t)n * p.ldw + (p.kwrap != 0 && k_first >= p.kwrap ? k_first - p.kwrap : k_first) + gc) : zsrc;
+        // (gl_conv3x3 sets ldw / kwrap as well: a split-fp16 input walks the same weight rows twice)
+        bptr[i] = ok ? (Wg + (size_t)n * p.ldw + (p.kwrap != 0 && k_first >= p.kwrap ? k_first - p.kwrap : k_first) + gc) : zsrc;
         if (ok) bmask |= 1u << i;
     }
 
@@ -201,7 +201,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
             const int t64 = k0 >> 6;
             const int cblk = t64 / 9;
             const int tap = t64 - cblk * 9;
-            const int ci0 = (cblk << 6) + (k0 & 63);
+            const int acb = (cg.cwrap != 0 && cblk >= cg.cwrap) ? cblk - cg.cwrap : cblk;      // third pass of a split input: hi again
+            const int ci0 = (acb << 6) + (k0 & 63);
             const int ky = tap / 3;
             const int kx = tap - ky * 3;
             if (!cg.ups) {
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
                 aptr[i] += ((amask >> i) & 1u) ? BKT : 0;
             }
         }
-        if constexpr (!CONV) {
+        {
             if (p.kwrap != 0 && k0 == p.kwrap && k0 != k_first) {
                 // weight reuse along K ([hi | lo] activations against the same W): back to column 0 of the weight rows, once per block
 #pragma unroll
@@ -507,14 +508,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
                         const float4 g1 = *reinterpret_cast<const float4*>(stage + r * EPS + pc + 36);
                         float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
                         float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-                        half8_t o;
+                        half8_t o, lo8;
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             float a = xv[j], b = gv[j];
                             if (bias) { a += bias[nx + j]; b += bias[nx + 32 + j]; }
-                            o[j] = (half_t)(a * gelu_erf_f(b));
+                            const float y = pin_value(a * gelu_erf_f(b));
+                            o[j] = (half_t)y;
+                            lo8[j] = (half_t)(y - (float)o[j]);
                         }
                         st16(outp + (size_t)m * p.ldc + (nbase >> 1) + pc, *reinterpret_cast<uint4*>(&o));
+                        // [hi | lo] rows for a split-fp16 FeedForward output projection: lo goes N / 2 (the output width) columns to the right
+                        if (p.out_mode == GL_OUT_F16_HILO) st16(outp + (size_t)m * p.ldc + (N >> 1) + (nbase >> 1) + pc, *reinterpret_cast<uint4*>(&lo8));
                     }
                 }
             } else {
@@ -760,7 +765,7 @@ template <bool CONV>
 int dispatch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K % 64) != 0) return GL_ERR_BAD_ARG;
     if (g.out_mode < 0 || g.out_mode > GL_OUT_F16_HILO) return GL_ERR_BAD_ARG;
-    if (g.out_mode == GL_OUT_F16_HILO && (g.epi == GL_EPI_GEGLU || g.vt != nullptr || g.ldc < 2 * g.N)) return GL_ERR_BAD_ARG;
+    if (g.out_mode == GL_OUT_F16_HILO && (g.vt != nullptr || g.ldc < (g.epi == GL_EPI_GEGLU ? g.N : 2 * g.N))) return GL_ERR_BAD_ARG;
     if (g.out_mode != GL_OUT_F32_NCHW && ((g.N % 8) != 0 || (g.ldc % 8) != 0)) return GL_ERR_BAD_ARG;
     if (g.out_mode == GL_OUT_F32_ROWMAJOR && g.out2 != nullptr && (g.ldc2 % 8) != 0) return GL_ERR_BAD_ARG;
     if (g.out_mode == GL_OUT_F32_ROWMAJOR && g.epi == GL_EPI_GEGLU) return GL_ERR_UNSUPPORTED;
@@ -890,15 +895,18 @@ extern "C" int gl_conv3x3(const gl_conv_args* a, void* stream) {
     if (a->stride != 1 && a->stride != 2) return GL_ERR_BAD_ARG;
     if (a->upsample2x && (a->stride != 1 || a->Hout != 2 * a->Hin || a->Wout != 2 * a->Win)) return GL_ERR_BAD_ARG;
     if (a->B >= 2048 || a->Hout >= 1024 || a->Wout >= 1024) return GL_ERR_BAD_ARG;     // packed (b, oy, ox) row coordinates
+    if (a->in_split != 0 && a->in_split != 2 && a->in_split != 3) return GL_ERR_BAD_ARG;
+    if (a->in_split == 3 && !a->w_split) return GL_ERR_BAD_ARG;      // the third pass multiplies by Wlo
     gl_gemm_args g = a->g;
     g.a = a->in;
     g.a2 = nullptr;
     g.M = a->B * a->Hout * a->Wout;
-    g.K = 9 * a->Cin;
-    g.ldw = g.K;
-    g.kwrap = 0;
-    ConvGeom cg{reinterpret_cast<const half_t*>(a->in), a->B, a->Hin, a->Win, a->Cin, a->Hout, a->Wout, a->stride,
-                a->upsample2x, nullptr};
+    // split-fp16 input (strict mode): pixel rows [hi | lo] of 2 Cin channels; the K walk visits hi, lo (, hi) against W, W (, Wlo)
+    g.K = 9 * a->Cin * (a->in_split ? a->in_split : 1);
+    g.ldw = 9 * a->Cin * (a->w_split ? 2 : 1);
+    g.kwrap = a->in_split ? 9 * a->Cin : 0;
+    ConvGeom cg{reinterpret_cast<const half_t*>(a->in), a->B, a->Hin, a->Win, a->Cin * (a->in_split ? 2 : 1), a->Hout, a->Wout, a->stride,
+                a->upsample2x, nullptr, a->in_split == 3 ? 2 * (a->Cin >> 6) : 0};
     return dispatch<true>(g, cg, (hipStream_t)stream);
 }
 

@@ -12,6 +12,9 @@ struct ConvGeom {
     const half_t* in;
     int B, Hin, Win, Cin, Hout, Wout, stride, ups;
     const half_t* zero;        // gemm8.hip: device address of 16 zero bytes (filled by its launcher)
+    int cwrap;                 // split-fp16 input with a third pass (gl_conv_args.in_split == 3): channel blocks >= cwrap read the input's block
+                               // (cblk - cwrap), i.e. the K walk [hi | lo | hi] over pixel rows that hold [hi | lo]; 0 = no wrap.  Cin above is the
+                               // pixel ROW STRIDE in channels (2 x the conv's channels for a split input); the channel blocks walked are K / 576
 };
 
 namespace {
@@ -95,6 +98,10 @@ __device__ __forceinline__ void fin8_store(const gl_gemm_args& p, float gate, in
         o16 = reinterpret_cast<half_t*>(p.out2);
         ld16o = p.ldc2;
         if (o16 == nullptr) return;
+    }
+    if (p.out_mode == GL_OUT_F16_HILO) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = pin_value(v[j]);      // hi and lo from the same value (common.h)
     }
     half8_t o;
 #pragma unroll

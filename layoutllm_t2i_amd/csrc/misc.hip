@@ -8,17 +8,19 @@ namespace {
 
 // text_grounding_net.py:30-41 + util.py:12-26.  One block per (b, i) row; out row = [in_dim | 8*num_freqs].
 // Fourier order: for each frequency f_j = 100^(j/num_freqs): sin(f_j * xyxy) (4) then cos(f_j * xyxy) (4).
+// OT = half_t (default) or float (strict mode: the row is split into [hi | lo] by gl_split_f32 afterwards)
+template <typename OT>
 __global__ __launch_bounds__(256) void posnet_input_kernel(const float* __restrict__ boxes, const float* __restrict__ masks,
                                                            const float* __restrict__ emb, const float* __restrict__ null_pos,
                                                            const float* __restrict__ null_xyxy, int in_dim, int num_freqs,
-                                                           half_t* __restrict__ out) {
+                                                           OT* __restrict__ out) {
     const int row = blockIdx.x;
     const float m = masks[row];
     const int pos_dim = num_freqs * 8;
-    half_t* o = out + (size_t)row * (in_dim + pos_dim);
+    OT* o = out + (size_t)row * (in_dim + pos_dim);
     for (int c = threadIdx.x; c < in_dim; c += 256) {
         const float v = emb[(size_t)row * in_dim + c] * m + (1.0f - m) * null_pos[c];
-        o[c] = (half_t)v;
+        o[c] = (OT)v;
     }
     for (int c = threadIdx.x; c < pos_dim; c += 256) {
         const int j = c / 8;
@@ -27,21 +29,39 @@ __global__ __launch_bounds__(256) void posnet_input_kernel(const float* __restri
         const float freq = powf(100.0f, (float)j / (float)num_freqs);
         const float arg = freq * boxes[(size_t)row * 4 + coord];
         const float e = (r < 4) ? sinf(arg) : cosf(arg);
-        o[in_dim + c] = (half_t)(e * m + (1.0f - m) * null_xyxy[c]);
+        o[in_dim + c] = (OT)(e * m + (1.0f - m) * null_xyxy[c]);
     }
 }
 
 // util.py:161-181: [cos(t*w) | sin(t*w)], w_k = exp(-ln(10000) * k / half)
-__global__ void timestep_embedding_kernel(const float* __restrict__ t, int dim, half_t* __restrict__ out) {
+template <typename OT>
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, int dim, OT* __restrict__ out) {
     const int b = blockIdx.x;
     const int half_dim = dim / 2;
     for (int k = threadIdx.x; k < half_dim; k += blockDim.x) {
         const float w = expf(-9.210340371976184f * (float)k / (float)half_dim);
         const float a = t[b] * w;
-        out[(size_t)b * dim + k] = (half_t)cosf(a);
-        out[(size_t)b * dim + half_dim + k] = (half_t)sinf(a);
+        out[(size_t)b * dim + k] = (OT)cosf(a);
+        out[(size_t)b * dim + half_dim + k] = (OT)sinf(a);
     }
-    if ((dim & 1) && threadIdx.x == 0) out[(size_t)b * dim + dim - 1] = (half_t)0.0f;
+    if ((dim & 1) && threadIdx.x == 0) out[(size_t)b * dim + dim - 1] = (OT)0.0f;
+}
+
+// fp32 rows -> fp16 [hi | lo] rows (8 channels per thread)
+__global__ void split_f32_kernel(const float* __restrict__ x, int ldx, size_t rows, int nvec, half_t* __restrict__ y, int ldy) {
+    const size_t total = rows * (size_t)nvec;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / (size_t)nvec;
+        const int c = (int)(i - r * (size_t)nvec) * 8;
+        const float4 a = *reinterpret_cast<const float4*>(x + r * ldx + c);
+        const float4 b = *reinterpret_cast<const float4*>(x + r * ldx + c + 4);
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        half8_t hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { hi[j] = (half_t)v[j]; lo[j] = (half_t)(v[j] - (float)hi[j]); }
+        st16(y + r * ldy + c, *reinterpret_cast<uint4*>(&hi));
+        st16(y + r * ldy + (size_t)nvec * 8 + c, *reinterpret_cast<uint4*>(&lo));
+    }
 }
 
 __global__ void silu_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, size_t nvec) {
@@ -181,15 +201,38 @@ extern "C" int gl_posnet_input(const float* boxes, const float* masks, const flo
                                const float* null_xyxy, int32_t rows, int32_t in_dim, int32_t num_freqs, void* out,
                                void* stream) {
     if (!boxes || !masks || !emb || !null_pos || !null_xyxy || !out || rows <= 0) return GL_ERR_BAD_ARG;
-    posnet_input_kernel<<<dim3(rows), dim3(256), 0, (hipStream_t)stream>>>(boxes, masks, emb, null_pos, null_xyxy, in_dim,
-                                                                           num_freqs, reinterpret_cast<half_t*>(out));
+    posnet_input_kernel<half_t><<<dim3(rows), dim3(256), 0, (hipStream_t)stream>>>(boxes, masks, emb, null_pos, null_xyxy, in_dim,
+                                                                                   num_freqs, reinterpret_cast<half_t*>(out));
+    GL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gl_posnet_input_f32(const float* boxes, const float* masks, const float* emb, const float* null_pos,
+                                   const float* null_xyxy, int32_t rows, int32_t in_dim, int32_t num_freqs, float* out, void* stream) {
+    if (!boxes || !masks || !emb || !null_pos || !null_xyxy || !out || rows <= 0) return GL_ERR_BAD_ARG;
+    posnet_input_kernel<float><<<dim3(rows), dim3(256), 0, (hipStream_t)stream>>>(boxes, masks, emb, null_pos, null_xyxy, in_dim, num_freqs, out);
+    GL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gl_timestep_embedding_f32(const float* t, int32_t B, int32_t dim, float* out, void* stream) {
+    if (!t || !out || B <= 0 || dim <= 0) return GL_ERR_BAD_ARG;
+    timestep_embedding_kernel<float><<<dim3(B), dim3(256), 0, (hipStream_t)stream>>>(t, dim, out);
+    GL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gl_split_f32(const float* x, int32_t ldx, int64_t rows, int32_t C, void* y, int32_t ldy, void* stream) {
+    if (!x || !y || rows <= 0 || C <= 0 || (C % 8) || (ldx % 4) || (ldy % 8) || ldy < 2 * C || ldx < C) return GL_ERR_BAD_ARG;
+    const size_t total = (size_t)rows * (C / 8);
+    split_f32_kernel<<<dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream>>>(x, ldx, (size_t)rows, C / 8, reinterpret_cast<half_t*>(y), ldy);
     GL_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int gl_timestep_embedding(const float* t, int32_t B, int32_t dim, void* out, void* stream) {
     if (!t || !out || B <= 0 || dim <= 0) return GL_ERR_BAD_ARG;
-    timestep_embedding_kernel<<<dim3(B), dim3(256), 0, (hipStream_t)stream>>>(t, dim, reinterpret_cast<half_t*>(out));
+    timestep_embedding_kernel<half_t><<<dim3(B), dim3(256), 0, (hipStream_t)stream>>>(t, dim, reinterpret_cast<half_t*>(out));
     GL_CHECK_LAUNCH();
     return 0;
 }
@@ -246,6 +289,7 @@ extern "C" int gl_latent_affine_pack(const float* z, const float* w, const float
 
 extern "C" int gl_init_gemm(void);
 extern "C" int gl_init_ff(void);
+extern "C" int gl_init_attn(void);
 // ---- option table (opts.h): process defaults, per-thread effective table of the running handle
 static gl_opts make_default_opts() {
     gl_opts o{};
@@ -263,6 +307,8 @@ static gl_opts make_default_opts() {
     o.v[45] = 1024;
     o.v[46] = 11;
     o.v[47] = 100;
+    o.v[50] = 0;       // strict mode (handles created with split_weights)
+    o.v[51] = 1;       // ... with the third pass x.Wlo
     return o;
 }
 gl_opts g_gl_opts = make_default_opts();
@@ -272,7 +318,7 @@ int g_gl_option_epoch = 0;
 bool gl_opts_store(gl_opts& t, int key, int value) {
     switch (key) {
         case 2: case 3: case 4: case 6: case 7: case 8: case 10: case 13: case 17: case 20: case 21: case 23: case 24: case 25:
-        case 27: case 29: case 30: case 31: case 32: case 33: case 35: case 37: case 38: case 41: case 42: case 43: case 44: case 45: case 46: case 47:
+        case 27: case 29: case 30: case 31: case 32: case 33: case 35: case 37: case 38: case 41: case 42: case 43: case 44: case 45: case 46: case 47: case 50: case 51:
             t.v[key] = value;
             return true;
         case 5:                                  // < 0: the built-in thresholds (plain GEMM 300 tiles, conv 450)
@@ -297,6 +343,7 @@ extern "C" int gl_sizeof_conv_args(void) { return (int)sizeof(gl_conv_args); }
 extern "C" int gl_sizeof_attn_args(void) { return (int)sizeof(gl_attn_args); }
 extern "C" int gl_sizeof_gn_args(void) { return (int)sizeof(gl_gn_args); }
 extern "C" int gl_init(void) {
-    const int e = gl_init_gemm();
-    return e ? e : gl_init_ff();
+    int e = gl_init_gemm();
+    if (!e) e = gl_init_ff();
+    return e ? e : gl_init_attn();
 }

@@ -46,16 +46,23 @@ template <> struct GnVec<true> {
 // fp16 store of 8 values; with `lo` also the fp16 residual v - float(fp16(v)) (split-fp16 operand, DESIGN.md 4: the
 // consumer multiplies [hi | lo] against [W | W], which restores ~22 mantissa bits of the activation operand)
 __device__ __forceinline__ void store_hl(half_t* hi, half_t* lo, const float (&v)[8]) {
+    if (lo != nullptr) {
+        // hi and lo from ONE pinned value each (common.h pin_value)
+        half8_t h, l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x = pin_value(v[j]);
+            h[j] = (half_t)x;
+            l[j] = (half_t)(x - (float)h[j]);
+        }
+        st16(hi, *reinterpret_cast<uint4*>(&h));
+        st16(lo, *reinterpret_cast<uint4*>(&l));
+        return;
+    }
     half8_t h;
 #pragma unroll
     for (int j = 0; j < 8; ++j) h[j] = (half_t)v[j];
     st16(hi, *reinterpret_cast<uint4*>(&h));
-    if (lo != nullptr) {
-        half8_t l;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) l[j] = (half_t)(v[j] - (float)h[j]);
-        st16(lo, *reinterpret_cast<uint4*>(&l));
-    }
 }
 
 // outputs of one GroupNorm launch (all row-major over the B * HW pixels):
@@ -492,7 +499,9 @@ __global__ __launch_bounds__(NT) void gn_bundle_kernel(const void* __restrict__ 
 // input row so that a consumer can re-evaluate the normalisation in fp32 (rela_merge).
 // Optional second source (fp16 rows x2, rows2 per sample): sample b's output rows are [rows_in rows of x | rows2 rows of x2],
 // i.e. the [x ; objs] concatenation of GatedSelfAttentionDense (attention.py:230) is normalised in ONE launch.
-template <bool XF32, int NV, bool YF32 = false, bool X2F32 = false>
+// YLO: the fp16 rows are followed, C columns to the right, by their fp16 residuals lo = fp16(y - fp16(y)) -- the [hi | lo] operand of a
+// split-fp16 projection (strict mode); its own instantiation, the plain form compiles unchanged.
+template <bool XF32, int NV, bool YF32 = false, bool X2F32 = false, bool YLO = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__ xv, int ldx, half_t* __restrict__ y,
                                                         int ldy, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int nrows, int rows_in,
@@ -583,10 +592,22 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
                 *reinterpret_cast<float4*>(yf) = make_float4(o[0], o[1], o[2], o[3]);
                 *reinterpret_cast<float4*>(yf + 4) = make_float4(o[4], o[5], o[6], o[7]);
             } else {
-                half8_t ov;
+                if constexpr (YLO) {
+                    half8_t ov, lv;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) ov[j] = (half_t)fmaf((v[i][j] - mean) * rstd, g[j], bt[j]);   // explicit: rela_merge_ln_kernel rounds identically
-                st16(yr + vec * 8, *reinterpret_cast<uint4*>(&ov));
+                    for (int j = 0; j < 8; ++j) {
+                        const float yv = pin_value(fmaf((v[i][j] - mean) * rstd, g[j], bt[j]));      // hi and lo from the same value
+                        ov[j] = (half_t)yv;
+                        lv[j] = (half_t)(yv - (float)ov[j]);
+                    }
+                    st16(yr + vec * 8, *reinterpret_cast<uint4*>(&ov));
+                    st16(yr + C + vec * 8, *reinterpret_cast<uint4*>(&lv));
+                } else {
+                    half8_t ov;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ov[j] = (half_t)fmaf((v[i][j] - mean) * rstd, g[j], bt[j]);   // explicit: rela_merge_ln_kernel rounds identically
+                    st16(yr + vec * 8, *reinterpret_cast<uint4*>(&ov));
+                }
             }
         }
     }
@@ -805,8 +826,20 @@ extern "C" int gl_layernorm(const void* x, int32_t ldx, int32_t x_f32, void* y, 
     hipStream_t st = (hipStream_t)stream;
     const int nv = gl_cdiv(C / 8, 64);
     const dim3 grid(gl_cdiv(nrows, 4)), blk(256);
-    const int y_f32 = (x_f32 >> 1) & 1, x2_f32 = (x_f32 >> 2) & 1;
+    const int y_f32 = (x_f32 >> 1) & 1, x2_f32 = (x_f32 >> 2) & 1, y_lo = (x_f32 >> 3) & 1;
     x_f32 &= 1;
+    if (y_lo) {
+        // [hi | lo] fp16 rows out of the fp32 stream (optionally with the fp32 second source): ldy covers both halves
+        if (!x_f32 || y_f32 || ldy < 2 * C || (x2 != nullptr && !x2_f32)) return GL_ERR_UNSUPPORTED;
+#define GL_LNL(V) layernorm_kernel<true, V, false, false, true><<<grid, blk, 0, st>>>(x, ldx, yp, ldy, gamma, beta, nrows, rows_in, rows_out, row_off, C, eps, stats, x2p, ldx2, rows2)
+#define GL_LNL2(V) layernorm_kernel<true, V, false, true, true><<<grid, blk, 0, st>>>(x, ldx, yp, ldy, gamma, beta, nrows, rows_in, rows_out, row_off, C, eps, stats, x2p, ldx2, rows2)
+        if (x2 != nullptr) { if (nv == 1) GL_LNL2(1); else if (nv == 2) GL_LNL2(2); else if (nv == 3) GL_LNL2(3); else GL_LNL2(4); }
+        else { if (nv == 1) GL_LNL(1); else if (nv == 2) GL_LNL(2); else if (nv == 3) GL_LNL(3); else GL_LNL(4); }
+#undef GL_LNL
+#undef GL_LNL2
+        GL_CHECK_LAUNCH();
+        return 0;
+    }
 #define GL_LN(F, V) layernorm_kernel<F, V><<<grid, blk, 0, st>>>(x, ldx, yp, ldy, gamma, beta, nrows, rows_in, rows_out, row_off, C, eps, stats, x2p, ldx2, rows2)
 #define GL_LNF(V) layernorm_kernel<true, V, true><<<grid, blk, 0, st>>>(x, ldx, yp, ldy, gamma, beta, nrows, rows_in, rows_out, row_off, C, eps, stats, x2p, ldx2, rows2)
 #define GL_LN2(V) layernorm_kernel<true, V, false, true><<<grid, blk, 0, st>>>(x, ldx, yp, ldy, gamma, beta, nrows, rows_in, rows_out, row_off, C, eps, stats, x2p, ldx2, rows2)

@@ -7,7 +7,7 @@
 #pragma once
 #include <cstdint>
 
-constexpr int GL_OPT_MAX = 48;
+constexpr int GL_OPT_MAX = 56;
 // internal slots (not settable keys): the conv variant of key 5
 constexpr int GL_OPT_SPLITK_TILES_CONV = 40;
 

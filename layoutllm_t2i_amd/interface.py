@@ -156,7 +156,8 @@ def load_ckpt(ckpt_path, device="cuda"):
         autoencoder = VAEDecoder(saved_ckpt["autoencoder"], vcfg, device)
     text_encoder = _load_text_encoder(config["text_encoder"], saved_ckpt["text_encoder"], device)
     for m in (autoencoder, text_encoder):
-        if not isinstance(m, VAEDecoder) and "device" in vars(m):
+        # (reference modules keep the device string they .to()'d; the HIP stages own a resolved torch.device and keep it)
+        if not isinstance(m, VAEDecoder) and not _is_hip_encoder(m) and "device" in vars(m):
             m.device = device
     return model, autoencoder, text_encoder, diffusion, config
 
@@ -598,39 +599,72 @@ def generate_batch_images_sharded(all_models, captions=None, labels=None, bboxes
     # With the HIP text tower in all_models on every rank (load_all_models_sharded ships its weights in the bundle) only the
     # host-side STRING work happens on src: the token rows travel (a few KB per prompt) and every rank encodes its own shard --
     # no rank-0 serial encoder stage.  Reference torch encoders (only present on src) keep the older flow: src encodes all rows.
+    # Nothing between two collectives may raise on one rank only (the others would block forever in the next collective): every
+    # failure travels as the payload of the collective that follows it and is raised on every rank after it.
     hip_flow = _is_hip_encoder(all_models[2])
     if rank == src or not multi:
-        n = len(captions)
-        seeds = list(range(n)) if seeds is None else [int(s_) for s_ in seeds]
-        assert len(seeds) == n
-        if hip_flow:
-            box = [dict(tok=tokenize_conditioning(all_models, captions, labels, bboxes, clip_processor), seeds=seeds,
-                        own_phrase_encoder=_is_hip_encoder(clip_model))]
-        else:
-            # prepare_conditioning returns HOST tensors: object collectives pickle tensors with their device, and rank r must not
-            # receive rank 0's "cuda:0" tensors
-            box = [dict(cond=prepare_conditioning(all_models, captions, labels, bboxes, clip_model, clip_processor, device), seeds=seeds)]
+        try:
+            n = len(captions)
+            seeds = list(range(n)) if seeds is None else [int(s_) for s_ in seeds]
+            assert len(seeds) == n
+            if hip_flow:
+                if clip_model is not None and not _is_hip_encoder(clip_model):
+                    # a reference torch CLIPModel for the grounding phrases (interface.py:114-141): never substituted silently by the
+                    # checkpoint's text tower.  One process: moved onto the HIP tower once (cached on the object); several ranks: the
+                    # other ranks do not hold its weights, so the caller has to pass an encoder every rank can build
+                    if multi:
+                        raise ValueError("clip_model is a torch CLIPModel that only rank %d holds: pass hip_phrase_encoder(clip_model, device) "
+                                         "built from the same weights on EVERY rank, or None on every rank to encode the grounding phrases "
+                                         "with the checkpoint's text tower" % src)
+                    cached = getattr(clip_model, "_gligen_hip_phrase_encoder", None)
+                    if cached is None:
+                        cached = hip_phrase_encoder(clip_model, device)
+                        try:
+                            clip_model._gligen_hip_phrase_encoder = cached
+                        except Exception:      # noqa: BLE001  (objects without attribute storage: rebuilt per call)
+                            pass
+                    clip_model = cached
+                box = [dict(tok=tokenize_conditioning(all_models, captions, labels, bboxes, clip_processor), seeds=seeds,
+                            own_phrase_encoder=_is_hip_encoder(clip_model))]
+            else:
+                # prepare_conditioning returns HOST tensors: object collectives pickle tensors with their device, and rank r must not
+                # receive rank 0's "cuda:0" tensors
+                box = [dict(cond=prepare_conditioning(all_models, captions, labels, bboxes, clip_model, clip_processor, device), seeds=seeds)]
+        except Exception as ex:          # noqa: BLE001
+            if not multi:
+                raise
+            box = [dict(error=f"rank {rank}: {type(ex).__name__}: {ex}")]
     if multi:
         with _collective_device(device):
             dist.broadcast_object_list(box, src=src)
+        if "error" in box[0]:
+            raise RuntimeError("generate_batch_images_sharded failed on " + box[0]["error"])      # on every rank alike
+        if "tok" in box[0] and box[0]["own_phrase_encoder"]:
+            # src encodes the grounding phrases with its own HIP phrase encoder (clip_model): every rank must hold one -- agreed on
+            # by ALL ranks before any of them diverges
+            flags = [None] * world
+            with _collective_device(device):
+                dist.all_gather_object(flags, bool(_is_hip_encoder(clip_model)))
+            missing = [r_ for r_, f_ in enumerate(flags) if not f_]
+            if missing:
+                raise ValueError("ranks %s passed no HIP phrase encoder: src encodes the grounding phrases with its own (clip_model); every "
+                                 "rank must pass one built from the same CLIP weights, or all ranks pass None to use the checkpoint's text "
+                                 "tower" % missing)
     seeds = box[0]["seeds"]
     n = len(seeds)
     mine = shard_indices(n, rank, world)
-    if "tok" in box[0]:
-        # grounding phrases: this rank's own phrase encoder when it has one (a HipCLIPTextEncoder, e.g. hip_phrase_encoder(CLIPModel)),
-        # else the conditioning tower itself -- the GLIGEN checkpoint's text encoder and the reference's default CLIPModel are both
-        # openai/clip-vit-large-patch14 (encoders/modules.py:146, train_rl.py:282)
-        if box[0]["own_phrase_encoder"] and not _is_hip_encoder(clip_model):
-            raise ValueError("rank %d: src encodes the grounding phrases with its own HIP phrase encoder (clip_model); every rank must pass "
-                             "one built from the same CLIP weights, or all ranks pass None to use the checkpoint's text tower" % rank)
-        pe = clip_model if box[0]["own_phrase_encoder"] else all_models[2]
-        sub = encode_conditioning(all_models, box[0]["tok"], mine, pe, device)
-    else:
-        sub = {k: v[mine] for k, v in box[0]["cond"].items()}
-    # a rank whose shard fails still takes part in the gather (with the error as its payload): the others must not block
-    # forever in gather_object, and src re-raises
-    err = None
+    # a rank whose shard fails (encoding included: sequence too long, out of memory, graph capture) still takes part in the gather,
+    # with the error as its payload: the others must not block forever in gather_object, and src re-raises
+    err, imgs = None, None
     try:
+        if "tok" in box[0]:
+            # grounding phrases: this rank's own phrase encoder when src has one (a HipCLIPTextEncoder, e.g.
+            # hip_phrase_encoder(CLIPModel)), else the conditioning tower itself -- the GLIGEN checkpoint's text encoder and the
+            # reference's default CLIPModel are both openai/clip-vit-large-patch14 (encoders/modules.py:146, train_rl.py:282)
+            pe = clip_model if box[0]["own_phrase_encoder"] else all_models[2]
+            sub = encode_conditioning(all_models, box[0]["tok"], mine, pe, device)
+        else:
+            sub = {k: v[mine] for k, v in box[0]["cond"].items()}
         imgs = run_shard(all_models, sub, prompt_noise([seeds[i] for i in mine], latent), device, steps=steps)
     except Exception as ex:          # noqa: BLE001
         if not multi:

@@ -172,16 +172,21 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias=None, epi: in
 
 def conv3x3(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, B: int, Hin: int, Win: int, bias=None,
             stride: int = 1, upsample2x: bool = False, epi: int = EPI_BIAS, res=None, rowbias=None,
-            rows_per_sample: int = 0, nchw_hw: int = 0, n_valid: Optional[int] = None, out16=None) -> torch.Tensor:
-    """x [B*Hin*Win, Cin] fp16 NHWC; w [Cout, 9*Cin] fp16 (tap-major, channel-minor)."""
+            rows_per_sample: int = 0, nchw_hw: int = 0, n_valid: Optional[int] = None, out16=None, in_split: int = 0,
+            w_split: bool = False) -> torch.Tensor:
+    """x [B*Hin*Win, Cin] fp16 NHWC; w [Cout, 9*Cin] fp16 (tap-major, channel-minor).
+    ``in_split`` = 2: x is [B*Hin*Win, 2 Cin] = [hi | lo] pixel rows of a split-fp16 activation, both halves against the same weight;
+    3 (with ``w_split``): plus the third pass hi.Wlo.  ``w_split``: w is [Cout, 18 Cin] = rows [Whi | Wlo] (gl_conv_args)."""
     _req(x, F16, "x")
     _req(w, F16, "w")
     rows, Cin, ldx = _rows(x, "x")
     if ldx != Cin or rows != B * Hin * Win:
         raise ValueError("x must be a contiguous [B*Hin*Win, Cin] matrix")
+    if in_split:
+        Cin //= 2
     N, K, _ = _rows(w, "w")
-    if K != 9 * Cin:
-        raise ValueError("w must be [Cout, 9*Cin]")
+    if K != (18 if w_split else 9) * Cin:
+        raise ValueError("w must be [Cout, 9*Cin] ([Cout, 18*Cin] with w_split)")
     if upsample2x:
         Hout, Wout = 2 * Hin, 2 * Win
     else:
@@ -190,6 +195,7 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, B: int, Hin: in
     a.inp = x.data_ptr()
     a.B, a.Hin, a.Win, a.Cin, a.Hout, a.Wout = B, Hin, Win, Cin, Hout, Wout
     a.stride, a.upsample2x = stride, int(upsample2x)
+    a.in_split, a.w_split = int(in_split), int(bool(w_split))
     a.g.w = w.data_ptr()
     a.g.N = N if n_valid is None else n_valid
     _fill_epilogue(a.g, epi, out, a.g.N, bias, res, None, rowbias, rows_per_sample, nchw_hw, out16)
@@ -218,8 +224,10 @@ def transpose_v(v: torch.Tensor, v_bstride: int, ldv: int, vt: torch.Tensor, B: 
 
 def attention(q: torch.Tensor, q_bstride: int, ldq: int, k: torch.Tensor, k_bstride: int, ldk: int, vt: torch.Tensor,
               out: torch.Tensor, o_bstride: int, ldo: int, B: int, H: int, d: int, Nq: int, Nk: int, scale: float,
-              q_prescaled: bool = False):
-    """``q_prescaled``: scale * log2(e) is already folded into q (weights.Q_FOLD does that to the packed q projections)."""
+              q_prescaled: bool = False, q_lo=None, k_lo=None, vt_lo=None, out_lo=None):
+    """``q_prescaled``: scale * log2(e) is already folded into q (weights.Q_FOLD does that to the packed q projections).
+    ``q_lo`` / ``k_lo`` / ``vt_lo`` (all three, same layouts as q / k / vt): the fp16 residuals of split-fp16 operands -> the three-pass
+    split attention kernel; ``out_lo`` then receives fp16(O - fp16(O))."""
     _req(q, F16, "q")
     _req(k, F16, "k")
     _req(vt, F16, "vt")
@@ -232,6 +240,10 @@ def attention(q: torch.Tensor, q_bstride: int, ldq: int, k: torch.Tensor, k_bstr
     a.B, a.H, a.d, a.Nq, a.Nk = B, H, d, Nq, Nk
     a.scale = scale
     a.q_prescaled = int(q_prescaled)
+    for t_, n_ in ((q_lo, "q_lo"), (k_lo, "k_lo"), (vt_lo, "vt_lo"), (out_lo, "out_lo")):
+        if t_ is not None:
+            _req(t_, F16, n_, 8)
+    a.q_lo, a.k_lo, a.vt_lo, a.out_lo = _ptr(q_lo), _ptr(k_lo), _ptr(vt_lo), _ptr(out_lo)
     check(_lib.lib().gl_attention(C.byref(a), _stream()), "gl_attention")
     return out
 
@@ -283,8 +295,9 @@ def groupnorm(x1: torch.Tensor, x2: Optional[torch.Tensor], B: int, HW: int, gam
 
 def layernorm(x: torch.Tensor, y: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, B: int, rows_in: int,
               rows_out: Optional[int] = None, row_off: int = 0, eps: float = 1e-5, stats: Optional[torch.Tensor] = None,
-              x2: Optional[torch.Tensor] = None, rows2: int = 0) -> torch.Tensor:
-    """x [B*rows_in, C] fp16 or fp32 (residual stream) -> y fp16 (or fp32: the dtype of ``y`` decides) rows b*rows_out + row_off + i (y is [B*rows_out, C]);
+              x2: Optional[torch.Tensor] = None, rows2: int = 0, y_lo: bool = False) -> torch.Tensor:
+    """``y_lo``: y is fp16 [B*rows_out, >= 2C] and receives [hi | lo] rows (gl_layernorm x_f32 bit 3; fp32 inputs only).
+    x [B*rows_in, C] fp16 or fp32 (residual stream) -> y fp16 (or fp32: the dtype of ``y`` decides) rows b*rows_out + row_off + i (y is [B*rows_out, C]);
     ``stats`` (optional fp32 [B*rows_in, 2]) receives (mean, rstd) per row.  ``x2`` (fp16 [B*rows2, C]): a second source
     whose rows follow x's rows inside every sample's block of y ([x ; objs] in one launch)."""
     xf32 = x.dtype == F32
@@ -306,7 +319,7 @@ def layernorm(x: torch.Tensor, y: torch.Tensor, gamma: torch.Tensor, beta: torch
         x2f32 = x2.dtype == F32
         _req(x2, F32 if x2f32 else F16, "x2")
         ldx2 = _rows(x2, "x2")[2]
-    check(_lib.lib().gl_layernorm(x.data_ptr(), ldx, int(xf32) | (2 if yf32 else 0) | (4 if x2f32 else 0), y.data_ptr(), ldy, gamma.data_ptr(), beta.data_ptr(), B, rows_in,
+    check(_lib.lib().gl_layernorm(x.data_ptr(), ldx, int(xf32) | (2 if yf32 else 0) | (4 if x2f32 else 0) | (8 if y_lo else 0), y.data_ptr(), ldy, gamma.data_ptr(), beta.data_ptr(), B, rows_in,
                                   rows_out, row_off, Cc, eps, _ptr(stats), _ptr(x2), ldx2, rows2, _stream()), "gl_layernorm")
     return y
 
@@ -325,6 +338,18 @@ def rela_pool(hid, B, H, W, Cc, rects, nvalid, poison, max_objs, feat, ln_gamma=
     check(_lib.lib().gl_rela_pool(hid.data_ptr(), B, H, W, Cc, rects.data_ptr(), nvalid.data_ptr(), poison.data_ptr(),
                                   max_objs, int(slots), feat.data_ptr(), _ptr(ln_gamma), _ptr(ln_beta), _ptr(ln_out), _stream()), "gl_rela_pool")
     return feat
+
+
+def split_f32(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """fp32 rows [rows, C] -> fp16 [rows, 2C] = [hi | lo] (gl_split_f32)."""
+    _req(x, F32, "x")
+    _req(y, F16, "y")
+    rows, Cc, ldx = _rows(x, "x")
+    _, c2, ldy = _rows(y, "y")
+    if c2 != 2 * Cc:
+        raise ValueError("y must be [rows, 2C]")
+    check(_lib.lib().gl_split_f32(x.data_ptr(), ldx, rows, Cc, y.data_ptr(), ldy, _stream()), "gl_split_f32")
+    return y
 
 
 def layernorm_stats(x: torch.Tensor, stats: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:

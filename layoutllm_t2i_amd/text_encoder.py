@@ -62,7 +62,10 @@ class HipCLIPTextEncoder:
 
     # FrozenCLIPEmbedder is an nn.Module: callers do .to(device).eval() on it (interface.py:86)
     def to(self, device):
-        if torch.device(device) != self.device:
+        # "cuda", "cuda:0", torch.device("cuda", 0) and 0 all name the same device: compare resolved (type, index) pairs
+        want, have = torch.device(device), torch.device(self.device)
+        idx = lambda dv: dv.index if dv.index is not None else (torch.cuda.current_device() if dv.type == "cuda" and torch.cuda.is_available() else 0)
+        if want.type != have.type or idx(want) != idx(have):
             raise RuntimeError(f"HipCLIPTextEncoder lives on {self.device}; build it on the target device")
         return self
 
@@ -89,6 +92,15 @@ class HipCLIPTextEncoder:
 
     __call__ = encode
     forward = encode
+
+    @torch.no_grad()
+    def encode_one_token(self, text, return_pooler_output: bool = True):
+        """encoders/modules.py:176-184: ONE string tokenised without padding or truncation; ``pooler_output`` [1, hidden] (what
+        GroundingNetInput.prepare's ``labels`` branch stores per box, text_layout_tokinzer_input.py:36) or ``last_hidden_state``
+        [1, T, hidden]."""
+        ids = self.tokenizer(text=text, padding=False, return_tensors="pt")["input_ids"]      # padding=False is CLIPTokenizer's default
+        z, pooled = self.towers.text_hidden_states(ids)
+        return pooled if return_pooler_output else z
 
     @torch.no_grad()
     def pooler_output(self, input_ids: torch.Tensor) -> torch.Tensor:

@@ -172,10 +172,20 @@ def pack_state_dict(sd: Mapping[str, object], cfg: UNetConfig, device, sd_first_
     P = PackedWeights(cfg, plan, device)
     W, S = P.w, P.s
     g = lambda k: _t(sd[k], device)
+    split_all = bool(getattr(cfg, "split_weights", False))
+
+    def mat(w32: torch.Tensor) -> torch.Tensor:
+        """fp32 [N, K] -> the stored matrix: fp16 [N, K], or rows [Whi | Wlo] (fp16 [N, 2K]) in a split_weights table
+        (gl_unet_config.split_weights: strict mode's third pass x.Wlo restores the fp32 weight to ~22 bits)"""
+        w32 = w32.reshape(w32.shape[0], -1).float()
+        hi = _h(w32)
+        if not split_all:
+            return hi
+        return torch.cat([hi, _h(w32 - hi.float())], 1).contiguous()
 
     def lin(p, dst=None, bias=True):
         dst = dst or p
-        W[dst + ".w"] = _h(g(p + ".weight").reshape(g(p + ".weight").shape[0], -1))
+        W[dst + ".w"] = mat(g(p + ".weight"))
         if bias:
             W[dst + ".b"] = g(p + ".bias").contiguous()
 
@@ -193,21 +203,26 @@ def pack_state_dict(sd: Mapping[str, object], cfg: UNetConfig, device, sd_first_
         W[p + ".b"] = g(p + ".bias").contiguous()
 
     def conv3(p, cin_pad=None):
-        W[p + ".w"] = pack_conv3x3(g(p + ".weight"), cin_pad)
+        w32 = g(p + ".weight").float()
+        hi = pack_conv3x3(w32, cin_pad)
+        if split_all:        # rows [Whi | Wlo], each half in the (64-channel block, tap, channel) order (gl_conv_args.w_split)
+            lo = pack_conv3x3(w32 - w32.half().float(), cin_pad)
+            hi = torch.cat([hi, lo], 1).contiguous()
+        W[p + ".w"] = hi
         W[p + ".b"] = g(p + ".bias").contiguous()
 
     def ff(p):
-        W[p + ".ff1.w"] = _h(geglu_interleave(g(p + ".net.0.proj.weight")))
+        W[p + ".ff1.w"] = mat(geglu_interleave(g(p + ".net.0.proj.weight")))
         W[p + ".ff1.b"] = geglu_interleave(g(p + ".net.0.proj.bias")).contiguous()
         lin(p + ".net.2", p + ".ff2")
 
     def self_attn(p, d):
-        W[p + ".qkv.w"] = _h(torch.cat([g(p + ".to_q.weight") * q_fold(d), g(p + ".to_k.weight"), g(p + ".to_v.weight")], 0))
+        W[p + ".qkv.w"] = mat(torch.cat([g(p + ".to_q.weight") * q_fold(d), g(p + ".to_k.weight"), g(p + ".to_v.weight")], 0))
         lin(p + ".to_out.0", p + ".o")
 
     def cross_attn(p, d):
-        W[p + ".q.w"] = _h(g(p + ".to_q.weight") * q_fold(d))
-        W[p + ".kv.w"] = _h(torch.cat([g(p + ".to_k.weight"), g(p + ".to_v.weight")], 0))
+        W[p + ".q.w"] = mat(g(p + ".to_q.weight") * q_fold(d))
+        W[p + ".kv.w"] = mat(torch.cat([g(p + ".to_k.weight"), g(p + ".to_v.weight")], 0))
         lin(p + ".to_out.0", p + ".o")
 
     lin("time_embed.0")
@@ -260,7 +275,7 @@ def pack_state_dict(sd: Mapping[str, object], cfg: UNetConfig, device, sd_first_
                 norm(f"{r}.{n}")
             S[r + ".tanh_attn"] = math.tanh(float(g(r + ".alpha_attn")))
             S[r + ".tanh_dense"] = math.tanh(float(g(r + ".alpha_dense")))
-    W["emb_all.w"] = _h(torch.cat(emb_w, 0))
+    W["emb_all.w"] = mat(torch.cat(emb_w, 0))
     W["emb_all.b"] = torch.cat(emb_b, 0).contiguous()
     P.emb_total = off
     norm("out.0")

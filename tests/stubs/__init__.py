@@ -70,6 +70,9 @@ class ToyTokenizer:
         if isinstance(text, str):
             text = [text]
         rows = [([self.BOS] + [1 + (sum(map(ord, w)) % 90) for w in t.split()])[:max_length - 1] + [self.EOS] for t in text]
+        if padding is False:          # CLIPTokenizer's default, as FrozenCLIPEmbedder.encode_one_token calls it (encoders/modules.py:177)
+            n = max(map(len, rows))
+            return {"input_ids": torch.tensor([r + [self.EOS] * (n - len(r)) for r in rows], dtype=torch.long)}
         return {"input_ids": torch.tensor([r + [self.EOS] * (max_length - len(r)) for r in rows], dtype=torch.long)}
 
 

@@ -273,3 +273,53 @@ def test_hip_text_encoder_encode_contract_and_oracle_at_vit_l_sizes():
     assert rl < 2e-3 and rp < 2e-3, (rl, rp)
     one = enc.encode("a quiet empty street")                                  # a single string is a batch of one
     assert one.shape == (1, 77, 768) and rel(one[0], z[2]) < 1e-3             # (other GEMM row counts: fp32 summation order only)
+
+
+@pytest.mark.gpu
+def test_encode_one_token_and_grounding_input_labels_branch():
+    """FrozenCLIPEmbedder.encode_one_token (encoders/modules.py:176-184) on the HIP tower, and the branch of
+    GroundingNetInput.prepare that calls it when a batch carries ``labels`` instead of ``text_embeddings``
+    (text_layout_tokinzer_input.py:29-39): (i) on the CLIPTextModel golden's weights, one unpadded row per call -> that row's
+    golden ``pooler_output``; (ii) at ViT-L/14's text sizes through prepare(), against the oracle tower."""
+    import stubs
+    from layoutllm_t2i_amd.model import GroundingNetInput
+    from layoutllm_t2i_amd.text_encoder import HipCLIPTextEncoder
+    z, sd = golden()
+    zt = np.load(GOLD_TEXT)
+    ids = T(zt["input_ids"])
+    first_eos = (ids == ids.max()).int().argmax(-1)
+
+    class RowTokenizer:                   # "3" -> golden row 3 cut after its first eos (no padding), CLIPTokenizer's call contract
+        def __call__(self, text=None, padding=False, return_tensors="pt", **kw):
+            r = int(text)
+            return {"input_ids": ids[r:r + 1, :int(first_eos[r]) + 1]}
+    enc = HipCLIPTextEncoder({k: v for k, v in sd.items() if k.startswith("text_model.")}, RowTokenizer(), "cuda", heads=int(z["heads"]),
+                             max_length=ids.shape[1])
+    assert enc.to("cuda") is enc and enc.to(torch.device("cuda", torch.cuda.current_device())) is enc and enc.to("cuda:0") is enc
+    for r in range(ids.shape[0]):
+        pooled = enc.encode_one_token(str(r))
+        assert pooled.shape == (1, zt["pooler_output"].shape[1])
+        assert rel(pooled[0], T(zt["pooler_output"][r])) < 3e-3, r
+        lhs = enc.encode_one_token(str(r), return_pooler_output=False)
+        assert lhs.shape == (1, int(first_eos[r]) + 1, zt["pooler_output"].shape[1])
+        assert rel(lhs[0], T(zt["last_hidden_state"][r, :int(first_eos[r]) + 1])) < 3e-3, r
+    # (ii) prepare() with labels: 768-wide tower (in_dim is hard-coded 768 there), two samples with 2 and 1 boxes
+    tsd = stubs.toy_text_tower_state_dict(2)
+    tok = stubs.ToyTokenizer()
+    enc768 = HipCLIPTextEncoder(tsd, tok, "cuda:0")
+    boxes = torch.zeros(2, 30, 4, device="cuda:0")
+    masks = torch.zeros(2, 30, device="cuda:0")
+    masks[0, :2] = 1
+    masks[1, :1] = 1
+    labels = ["red apple|a dog", "tall tree|unused"]
+    g = GroundingNetInput()
+    out = g.prepare(dict(boxes=boxes, masks=masks, labels=labels), text_encoder=enc768)
+    pe = out["positive_embeddings"]
+    assert pe.shape == (2, 30, 768) and out["boxes"] is boxes and out["masks"] is masks
+    for (b, i), text in {(0, 0): "red apple", (0, 1): "a dog", (1, 0): "tall tree"}.items():
+        with torch.no_grad():
+            want = clip_ref.text_hidden_states(tsd, tok(text, padding=False)["input_ids"], 12)[1][0]
+        assert rel(pe[b, i], want) < 2e-3, (b, i)
+    assert float(pe[1, 1:].abs().max()) == 0.0 and float(pe[0, 2:].abs().max()) == 0.0
+    null = g.get_null_input()
+    assert null["positive_embeddings"].shape == (2, 30, 768) and float(null["positive_embeddings"].abs().max()) == 0.0

@@ -106,3 +106,34 @@ def test_flatten_tensors_roundtrip():
     assert flat.dtype == torch.uint8 and flat.numel() % 256 == 0 and [m[0] for m in man] == ["a", "b", "z"]
     back = unflatten_tensors(flat, man)
     assert all(torch.equal(back[k], d[k]) and back[k].dtype == d[k].dtype for k in d)
+
+
+@pytest.mark.parametrize("mode", ["src_fails", "rank1_fails"])
+def test_sharded_entry_failure_reaches_every_rank_world2(mode):
+    """generate_batch_images_sharded: a failure on ONE rank -- src before the conditioning broadcast, or any rank while it
+    encodes / denoises its shard -- travels as the payload of the next collective and is raised on the ranks that need it; no
+    rank stays blocked in broadcast_object_list / gather_object (the workers would hit the timeout)."""
+    import json
+    import subprocess
+    world, port = 2, _free_port()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_fail_worker.py")
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, worker, mode], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    res = []
+    try:
+        for p in procs:
+            out, err = p.communicate(timeout=180)
+            assert p.returncode == 0, err[-2000:]
+            res.append(json.loads(next(l for l in out.splitlines() if l.startswith("RESULT "))[7:]))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    a, b = sorted(res, key=lambda d: d["rank"])
+    if mode == "src_fails":
+        assert a["got"].startswith("RuntimeError") and b["got"].startswith("RuntimeError") and "rank 0" in a["got"] and "rank 0" in b["got"], (a, b)
+    else:
+        assert a["got"].startswith("RuntimeError") and "boom on rank 1" in a["got"], a       # src re-raises what rank 1 reported
+        assert b["got"].startswith("RuntimeError") and "boom on rank 1" in b["got"], b

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(l, name), f"{name} declared in gligen_hip.h but not exported"
     assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
-    assert l.gl_abi_version() == _lib.ABI_VERSION == 13
+    assert l.gl_abi_version() == _lib.ABI_VERSION == 14
     assert l.gl_sizeof_gemm_args() == ctypes.sizeof(_lib.GemmArgs)
     assert l.gl_sizeof_conv_args() == ctypes.sizeof(_lib.ConvArgs)
     assert l.gl_sizeof_attn_args() == ctypes.sizeof(_lib.AttnArgs)
@@ -71,6 +71,35 @@ def test_engine_handle_plan_and_weight_table_without_a_gpu():
                 assert P.w[name].data_ptr() == P.flat.data_ptr() + off          # views into the flat buffer
         if cfg == UNetConfig():
             assert 2.4e9 < total < 2.7e9 and len(names) == 1102
+        # the split_weights table (strict mode): the same names, every matrix twice as wide ([Whi | Wlo] rows; the first conv and the
+        # three kinds of 1x1 conv keep their own split forms), and the packer fills it: Whi == the compact table's matrix, Whi + Wlo ~ W
+        import dataclasses
+        hs = _lib.create_engine(dataclasses.replace(cfg, split_weights=True))
+        table_s, total_s = _lib.weight_table(hs)
+        assert [t[0] for t in table_s] == names and total < total_s < 2 * total
+        for (name, _, _, dtype, shape), (_, _, _, dtype_s, shape_s) in zip(table, table_s):
+            assert dtype == dtype_s
+            if dtype == 0 and len(shape) == 2 and not name.startswith(("input_blocks.0.0.", "sd_first_conv.")) \
+                    and not name.endswith((".skip_connection.w", ".proj_in.w", ".proj_out.w")):
+                assert tuple(shape_s) == (shape[0], 2 * shape[1]), name
+            else:
+                assert tuple(shape_s) == tuple(shape), name
+        assert l.gl_destroy(hs) == 0
+        if cfg is TINY:
+            Ps = pack_state_dict(recipe.state_dict(TINY, 0), dataclasses.replace(TINY, split_weights=True), "cpu", recipe.sd_first_conv(TINY, 0))
+            assert Ps.flat.numel() == total_s
+            for name, _, _, dtype, shape in table:
+                if tuple(Ps.w[name].shape) != tuple(shape):
+                    k = shape[1]
+                    assert torch.equal(Ps.w[name][:, :k], P.w[name]), name
+                    assert float(Ps.w[name][:, k:].float().abs().max()) < 2.0 ** -10 * float(P.w[name].float().abs().max()), name
+            sd0 = recipe.state_dict(TINY, 0)
+            w32 = torch.from_numpy(np.asarray(sd0["output_blocks.2.0.in_layers.2.weight"])).float()
+            from layoutllm_t2i_amd.weights import pack_conv3x3
+            got = Ps.w["output_blocks.2.0.in_layers.2.w"].float()
+            k = got.shape[1] // 2
+            want = pack_conv3x3(w32).float() + pack_conv3x3(w32 - w32.half().float()).float()
+            assert torch.equal(got[:, :k] + got[:, k:], want)
         # nothing loaded / no conditioning: the compute entry points must refuse, not crash
         assert l.gl_unet_forward(h, None, None, 0.0, 1, 1.0, 0, None, 1, None) == -1
         assert l.gl_set_conditioning(h, None, None, None, None, None, 1, 77, 10, 16, None) == -1
