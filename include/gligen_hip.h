@@ -535,7 +535,16 @@ int gl_sizeof_gn_args(void);
  * maps and below at 2B = 8): bit 0 = convs whose 256-row plan leaves <= 16 K-tiles per split-K slice, bit 1 = plain GEMMs, bit 2 = every
  * conv (A/B), bit 3 = multi-round plain GEMMs whose 256-row grid ends in a mostly empty round while the 128-row grid fills its rounds;
  * default 11, 0 = 256-row tiles only.  Results differ from the 256-row plan only through the number of split-K slices.
- * key 47 = plain GEMMs use the 8-wave kernel from this many blocks (tiles x K slices) on (default 100; the split-K decision keeps key 31). */
+ * key 47 = plain GEMMs use the 8-wave kernel from this many blocks (tiles x K slices) on (default 100; the split-K decision keeps key 31).
+ * key 50 = STRICT mode (0 default; handles created with gl_unet_config.split_weights only, GL_ERR_BAD_ARG otherwise): every matrix product of
+ * the forward takes split-fp16 operands -- activations as [hi | lo] (LayerNorm / GroupNorm / GEGLU / attention / projection epilogues write
+ * both halves, gl_split_f32 for stream tensors entering a down / up conv), 3x3 convs with gl_conv_args.in_split, attention with
+ * gl_attn_args.q_lo / k_lo / vt_lo (three passes for Q.K^T and P.V, P split in registers) -- so that the output is within north_star's
+ * rtol 1e-3 / atol 1e-4 of the fp32 reference for > 99 % of the elements (measured 0.1-0.2 % outside, rel-L2 < 1e-4, at 2-3x the
+ * default mode's time).  The relation chain of rela_fuse (1/30 weight, 3e-6 of the result) and the fused first conv keep their forms.
+ * key 51 = strict mode's third pass x.Wlo (1 default; 0 = activations split only: exact for fp16-representable weights except the
+ * folded softmax scale of the q projections).  gl_set_conditioning reads keys 50 / 51 too (its strict hoists follow key 51): call it
+ * again after changing key 51. */
 int gl_set_option(int key, int value);
 /* gl_set_option writes the PROCESS defaults (op-level calls and every handle without an override see them).  A handle can
  * override individual keys for itself: while one of ITS entry points (gl_set_conditioning / gl_unet_forward / gl_plms_step,

@@ -517,7 +517,10 @@ __global__ __launch_bounds__(256) void attn_split_kernel(gl_attn_args p) {
             for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
         uint4 pfh[4], pfl[4];
         float psum = 0.0f;
-        const float nm = -m_run;
+        // probabilities are kept scaled by 2^13 (P <= 8192; O and the row sum carry the same factor, which cancels in O / l): every P below
+        // fp16's smallest normal (6.1e-5) loses its mantissa bits -- and its lo half -- to the subnormal quantum; at 1024+ keys that tail
+        // carried 1e-4 of the result (tiny UNet at 32x32 latents: 9.9e-5 unscaled, 6.2e-6 scaled by 2^8)
+        const float nm = 13.0f - m_run;
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh)
 #pragma unroll

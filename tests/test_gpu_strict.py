@@ -52,6 +52,13 @@ def test_split_f32_is_exact():
     hi, lo = split(x)
     assert torch.equal(y[:, :320].cpu(), hi) and torch.equal(y[:, 320:].cpu(), lo)
     assert rel(y[:, :320].float() + y[:, 320:].float(), x) < 3e-7
+    # small magnitudes: the lo halves (and below 6.1e-5 the hi halves) are fp16 SUBNORMALS and must survive the conversion
+    xs = rnd("sps", (64, 320)) * 0.01
+    ys = torch.empty(64, 640, dtype=torch.float16, device=DEV)
+    ops.split_f32(xs.to(DEV), ys)
+    his, los = split(xs)
+    assert float(los.float().abs().max()) < 6.1e-5 and float(los.float().abs().max()) > 0
+    assert torch.equal(ys[:, :320].cpu(), his) and torch.equal(ys[:, 320:].cpu(), los), "fp16 subnormals flushed by the device conversion"
 
 
 @pytest.mark.parametrize("C,rows,rows2", [(320, 200, 0), (640, 70, 0), (1280, 33, 0), (320, 64, 30), (64, 256, 30)])

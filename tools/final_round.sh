@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-end evidence on the GPU box (run via gpurun): bash tools/final_round.sh <tag>   e.g. r4
 # GPU suite, the three bench configs, smoke, rocprofv3 kernel stats + PMC traffic, per-shape table, fuzz sweeps.
-T=${1:-r4}
+T=${1:-r5}
 cd $GRAFT_REPO_ROOT
 O=gpurun_out
 mkdir -p $O
