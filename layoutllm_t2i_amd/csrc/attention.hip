@@ -638,7 +638,10 @@ int launch_attn(const gl_attn_args& a, hipStream_t st) {
     return 0;
 }
 
-// 4-wave (128-query) or 8-wave (256-query) blocks.  Round-1 variants that lost (64 queries per wave: 280 registers ->
+// 4-wave (128-query) or 8-wave (256-query) blocks.  Round 5: a barrier-enforced two-group ping-pong form (waves w / w + 4 one phase
+// apart: P.V(i-1) + Q.K^T(i) MFMAs in one group while the other runs the softmax of its tile; K / V^T staging split by group,
+// bitwise equal to this kernel) measured 248 vs 230 us at d = 40, N = 4096 and 35.6 vs 31.6 us at d = 80 (profiles/r5_ab_attn_pingpong.txt);
+// removed.  Round-1 variants that lost (64 queries per wave: 280 registers ->
 // 1 wave/SIMD, 651 vs 479 us; a software-pipelined S(t+1) || softmax(t) kernel with a 3-slot LDS ring: -10 % at d = 40)
 // are recorded in DESIGN.md and no longer compiled.
 template <int DQK>
