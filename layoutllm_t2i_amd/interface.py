@@ -120,9 +120,14 @@ def find_sd_first_conv(ckpt_path=None):
     return None
 
 
-def load_ckpt(ckpt_path, device="cuda"):
+def load_ckpt(ckpt_path, device="cuda", strict=None):
     """interface.py:78-101.  The UNet ('model') is built by this package from saved_ckpt['model'];
     autoencoder / text_encoder / grounding tokenizer are instantiated from the checkpoint's config.
+
+    ``strict`` (default: the environment variable ``GLIGEN_STRICT=1``): pack the UNet's weights in the split layout ([Whi | Wlo] for
+    every matrix, twice the bytes) and run the engine in STRICT mode (gl_set_handle_option 50: split-fp16 operands for every matrix
+    product): the UNet output is then within rtol 1e-3 / atol 1e-4 of the fp32 reference (measured rel-L2 < 1e-5) at ~0.47 x the default
+    mode's images/s.  ``model.set_strict(False)`` switches the same handle back to the default (fast) arithmetic.
 
     Like the reference (openaimodel.py:393-405) the SD first-conv file is needed as soon as a fuser-scale-0 step runs:
     a missing file warns here and raises in ``restore_first_conv_from_SD`` (where the reference fails), never silently
@@ -130,6 +135,11 @@ def load_ckpt(ckpt_path, device="cuda"):
     saved_ckpt = torch.load(ckpt_path, map_location="cpu")
     config = saved_ckpt["config_dict"]["_content"]
     cfg = UNetConfig.from_dict(config["model"]["params"])
+    if strict is None:
+        strict = os.environ.get("GLIGEN_STRICT") == "1"
+    if strict:
+        import dataclasses
+        cfg = dataclasses.replace(cfg, split_weights=True)
     sd_path = find_sd_first_conv(ckpt_path)
     allow_missing = os.environ.get("GLIGEN_ALLOW_NO_SD_CONV") == "1"
     if sd_path is None and not allow_missing:
@@ -140,6 +150,8 @@ def load_ckpt(ckpt_path, device="cuda"):
             "instead (results then differ from the reference).")
     model = UNetModel(cfg, saved_ckpt["model"], device=device, sd_first_conv=load_sd_first_conv(sd_path),
                       allow_missing_sd_conv=sd_path is None and allow_missing)
+    if strict:
+        model.set_strict(True)
     dparams = config["diffusion"].get("params", {})
     diffusion = LatentDiffusion(linear_start=dparams.get("linear_start", 0.00085), linear_end=dparams.get("linear_end", 0.012),
                                 timesteps=dparams.get("timesteps", 1000), device=device)
@@ -162,9 +174,9 @@ def load_ckpt(ckpt_path, device="cuda"):
     return model, autoencoder, text_encoder, diffusion, config
 
 
-def load_all_models(ckpt, device):
-    """interface.py:366-373."""
-    model, autoencoder, text_encoder, diffusion, config = load_ckpt(ckpt, device)
+def load_all_models(ckpt, device, strict=None):
+    """interface.py:366-373 (``strict``: see load_ckpt)."""
+    model, autoencoder, text_encoder, diffusion, config = load_ckpt(ckpt, device, strict=strict)
     model.grounding_tokenizer_input = GroundingNetInput()
     return model, autoencoder, text_encoder, diffusion, config
 
@@ -422,10 +434,11 @@ def _unet_facade(packed, cfg, device, allow_missing_sd_conv=False):
     m.grounding_tokenizer_input = GroundingNetInput()
     m.fuser_scale, m.training, m._cond_key = 1.0, False, None
     m.engine = UNetEngine(packed)
+    m.strict = False
     return m
 
 
-def load_all_models_sharded(ckpt, device, src=0):
+def load_all_models_sharded(ckpt, device, src=0, strict=None):
     """``load_all_models`` for a torch.distributed job: only rank ``src`` touches the checkpoint file; the others receive the
     packed UNet (the C engine's flat weight buffer), the packed VAE decoder and -- when the checkpoint's text encoder runs on the HIP
     tower -- its weights in dist.broadcast_bundle's single collective, plus the config dict.  With a reference torch text encoder
@@ -434,10 +447,10 @@ def load_all_models_sharded(ckpt, device, src=0):
     import torch.distributed as dist
     from .dist import broadcast_bundle
     if not (dist.is_available() and dist.is_initialized()):
-        return load_all_models(ckpt, device)
+        return load_all_models(ckpt, device, strict=strict)
     rank = dist.get_rank()
     if rank == src:
-        am = load_all_models(ckpt, device)
+        am = load_all_models(ckpt, device, strict=strict)
         model, autoencoder, text_encoder, diffusion, config = am
         if not isinstance(autoencoder, VAEDecoder):
             raise NotImplementedError("the sharded entry broadcasts the HIP VAE decoder's packed weights (unset GLIGEN_REFERENCE_VAE)")
@@ -448,11 +461,14 @@ def load_all_models_sharded(ckpt, device, src=0):
         te_extra = dict(tokenizer=text_encoder.tokenizer, heads=text_encoder.heads, max_length=text_encoder.max_length) if hip_te else None
         broadcast_bundle(model.engine.P, autoencoder.W, model.cfg, device, src,
                          extra=dict(config=config, vcfg=autoencoder.cfg, diffusion=dcfg, text_encoder=te_extra,
-                                    allow_missing_sd_conv=bool(getattr(model, "allow_missing_sd_conv", False))),
+                                    allow_missing_sd_conv=bool(getattr(model, "allow_missing_sd_conv", False)),
+                                    strict=bool(getattr(model, "strict", False))),
                          aux=dict(text_encoder=text_encoder.towers_state_dict()) if hip_te else None)
         return am
     P, vw, extra, aux = broadcast_bundle(None, None, None, device, src, want_aux=True)
     model = _unet_facade(P, P.cfg, device, extra.get("allow_missing_sd_conv", False))     # src's GLIGEN_ALLOW_NO_SD_CONV applies to every rank
+    if extra.get("strict"):                 # ... and so does its strict mode (the split weight layout travelled in the broadcast)
+        model.set_strict(True)
     autoencoder = VAEDecoder.from_packed(vw, extra["vcfg"], device)
     d = extra["diffusion"]
     diffusion = LatentDiffusion(linear_start=d["linear_start"], linear_end=d["linear_end"], timesteps=d["timesteps"], device=device)

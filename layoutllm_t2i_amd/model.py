@@ -109,6 +109,19 @@ class UNetModel:
         packed = pack_state_dict(state_dict, cfg, self.device, sd_first_conv)
         self.engine = UNetEngine(packed)
         self._cond_key = None
+        self.strict = False
+
+    def set_strict(self, on: bool = True):
+        """STRICT mode of the engine (gl_set_handle_option 50; include/gligen_hip.h): every matrix product on split-fp16 operands, output
+        within north_star's rtol 1e-3 / atol 1e-4 of the fp32 reference.  Needs weights packed in the split layout
+        (``UNetConfig.split_weights``; ``interface.load_ckpt(..., strict=True)`` does both)."""
+        if on and not getattr(self.cfg, "split_weights", False):
+            raise RuntimeError("strict mode needs the split weight layout: build the model with dataclasses.replace(cfg, split_weights=True) "
+                               "(interface.load_ckpt(..., strict=True) / GLIGEN_STRICT=1 do)")
+        self.engine.set_option(50, 1 if on else 0)
+        self.strict = bool(on)
+        self._cond_key = None           # the conditioning hoists are option-dependent: recompute on the next call
+        return self
 
     def eval(self):
         return self

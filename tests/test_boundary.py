@@ -200,6 +200,50 @@ def test_run_batch_images_equals_the_oracle_pipeline(loaded):
 
 
 @pytest.mark.gpu
+def test_run_batch_images_strict_mode_equals_the_oracle_pipeline(loaded, monkeypatch):
+    """load_all_models(..., strict=True) / GLIGEN_STRICT=1: the same boundary run in the engine's STRICT mode (split-fp16 operands for every
+    matrix product; split weight layout).  The final latent after 4 PLMS steps (10 chained UNet evaluations) must sit ~100 x closer to the
+    fp32 oracle pipeline than the default mode's 1.7e-3; the decoded image keeps the (single-fp16) VAE's own error."""
+    p, am0, clip, proc = loaded
+    monkeypatch.setenv("GLIGEN_STRICT", "1")
+    am = itf.load_all_models(p, DEV)
+    monkeypatch.delenv("GLIGEN_STRICT")
+    model, autoencoder, text_encoder, diffusion, config = am
+    assert model.strict and model.cfg.split_weights and not am0[0].strict
+    with pytest.raises(RuntimeError):
+        am0[0].set_strict(True)                      # compact weight layout: refused loudly
+    torch.manual_seed(123)
+    noise = torch.randn(2, 4, 16, 16)
+    captured = {}
+    dec = autoencoder.decode
+    autoencoder.decode = lambda z: captured.setdefault("img", dec(captured.setdefault("lat", z.clone())))
+    try:
+        args = dict(batch_size=2, no_plms=False, guidance_scale=7.5, steps=4)
+        meta = dict(prompts=PROMPTS, phrases=PHRASES, locations=BOXES_LTRB, alpha_type=[0.5, 0.0, 0.5])
+        itf.run_batch_images(am, args, meta, noise.to(DEV), clip, proc, device=DEV)
+    finally:
+        autoencoder.decode = dec
+    cond = _expected_conditioning(PROMPTS, PHRASES, BOXES_LTRB, text_encoder.to("cpu"), clip.cpu(), proc, 10)
+    text_encoder.to(DEV), clip.to(DEV)
+    lat_ref, img_ref = _oracle_pipeline(cond, noise, 4, [0.5, 0.0, 0.5])
+    rl = float((captured["lat"].cpu() - lat_ref).norm() / lat_ref.norm())
+    out = float(((captured["lat"].cpu() - lat_ref).abs() > 1e-4 + 1e-3 * lat_ref.abs()).float().mean())
+    print(f"[boundary, strict] latent rel_l2={rl:.3e}, {100 * out:.2f} % of the latent outside rtol 1e-3 / atol 1e-4 after 10 chained evaluations")
+    assert rl < 1e-4 and out < 0.01, (rl, out)
+    # the same handle back in the default arithmetic: equal to a compact-layout model up to the fused FeedForward (not used on split tables)
+    model.set_strict(False)
+    model.first_conv_type = "GLIGEN"
+    captured.clear()
+    autoencoder.decode = lambda z: captured.setdefault("img", dec(captured.setdefault("lat", z.clone())))
+    try:
+        itf.run_batch_images(am, args, meta, noise.to(DEV), clip, proc, device=DEV)
+    finally:
+        autoencoder.decode = dec
+    rl0 = float((captured["lat"].cpu() - lat_ref).norm() / lat_ref.norm())
+    assert 2e-4 < rl0 < 2.7e-3, rl0
+
+
+@pytest.mark.gpu
 def test_generate_batch_and_one_image_contracts(loaded):
     """generate_batch_images (interface.py:551-570) and generate_one_image (:376-395) as train_rl.py / txt2img.py call
     them: list[PIL] of the right length / size, 64x64 noise from the GLOBAL CPU RNG, boxes passed through UNconverted by

@@ -1,7 +1,9 @@
 """Randomised ARCHITECTURE sweep of the C++ engine (GPU box): small UNets with random widths, level counts, attention
 levels, head counts, residual-block counts, latent sizes, batch sizes, box / relation counts and random layouts (including
 degenerate and out-of-range boxes), each forward compared with the fp32 oracle on the host CPU (fp16-rounded weights) in
-three modes: grounded, null grounding, fuser scale 0 with the SD first conv.  usage: python tools/fuzz_engine.py [seconds] [seed]"""
+three modes: grounded, null grounding, fuser scale 0 with the SD first conv.  usage: python tools/fuzz_engine.py [seconds] [seed]
+FUZZ_STRICT=1: the engine's STRICT mode (split weight layout, gl_set_handle_option 50) against the oracle on the UNROUNDED fp32 weights,
+latent and conditioning tensors; a forward fails above rel-L2 1e-4 (default mode: 4e-3)."""
 import os
 import random
 import sys
@@ -29,6 +31,8 @@ _fz_init(0)
 for _kv in filter(None, os.environ.get("FUZZ_OPTS", "").split(",")):
     _fz_ops.set_option(int(_kv.split("=")[0]), int(_kv.split("=")[1]))
 torch.set_num_threads(16)
+STRICT = os.environ.get("FUZZ_STRICT") == "1"
+BOUND = 1e-4 if STRICT else 4e-3
 
 
 def rel_l2(a, b):
@@ -67,10 +71,17 @@ while time.time() - t0 < budget:
     lr = random.Random(layout_seed)
     try:
         sd = recipe.state_dict(cfg, seed)
-        # arithmetic parity: fp16-representable weight matrices on both sides (the engine's split 1x1-conv weights then have Wlo = 0)
-        sd = {k: (np.asarray(v).astype(np.float16).astype(np.float32) if np.asarray(v).ndim >= 2 else np.asarray(v)) for k, v in sd.items()}
+        # arithmetic parity: fp16-representable weight matrices on both sides (the engine's split 1x1-conv weights then have Wlo = 0);
+        # strict mode: the fp32 weights themselves
+        rw = (lambda a: a) if STRICT else (lambda a: a.astype(np.float16).astype(np.float32))
+        sd = {k: (rw(np.asarray(v)) if np.asarray(v).ndim >= 2 else np.asarray(v)) for k, v in sd.items()}
         fc = recipe.sd_first_conv(cfg, seed)
-        m = UNetModel(cfg, sd, device=DEV, sd_first_conv=fc)
+        if STRICT:
+            import dataclasses
+            m = UNetModel(dataclasses.replace(cfg, split_weights=True), sd, device=DEV, sd_first_conv=fc)
+            m.set_strict(True)
+        else:
+            m = UNetModel(cfg, sd, device=DEV, sd_first_conv=fc)
         m.grounding_tokenizer_input = GroundingNetInput()
         # random layouts: mostly sane boxes, sometimes degenerate / inverted / partly outside [0, 1]
         bx = []
@@ -84,27 +95,28 @@ while time.time() - t0 < budget:
                 row.append((x0, y0, min(x0 + w, 1.2), min(y0 + h, 1.2)))
             bx.append(row)
         inp = {k: T(v) for k, v in recipe.synth_inputs(cfg, B, hw, n_boxes=nb, n_rel=nr, seed=seed, boxes=bx if nb else None).items()}
-        osd = {k: (T(np.asarray(v)).float().half().float() if np.asarray(v).ndim >= 2 else T(np.asarray(v)).float()) for k, v in sd.items()}
-        ofc = {k: (T(np.asarray(v)).float().half().float() if np.asarray(v).ndim >= 2 else T(np.asarray(v)).float()) for k, v in fc.items()}
+        rt = (lambda t_: t_) if STRICT else (lambda t_: t_.half().float())
+        osd = {k: (rt(T(np.asarray(v)).float()) if np.asarray(v).ndim >= 2 else T(np.asarray(v)).float()) for k, v in sd.items()}
+        ofc = {k: (rt(T(np.asarray(v)).float()) if np.asarray(v).ndim >= 2 else T(np.asarray(v)).float()) for k, v in fc.items()}
         eng = m.engine
         z = torch.zeros_like
-        x = inp["x"].half().float().to(DEV)          # the oracle takes the fp16-rounded latent (xh below)
+        x = rt(inp["x"]).to(DEV)          # the oracle takes the fp16-rounded latent (xh below); strict: the fp32 latent
         tval = float(lr.choice([1, 201, 481, 981]))
         tt = torch.full((B,), int(tval), dtype=torch.long)
-        xh = inp["x"].half().float()
+        xh = rt(inp["x"])
         for mode in ("cond", "null", "scale0_sd"):
             if mode == "null":
                 eng.set_conditioning(inp["uc"], inp["relations"], z(inp["boxes"]), z(inp["masks"]), z(inp["positive_embeddings"]), hw)
                 out = eng.forward(x, tval, 1.0, False, 1).clone()
                 with torch.no_grad():
-                    ref = unet_ref.unet_forward(osd, cfg, xh, tt, inp["uc"].half().float(), inp["relations"].half().float(), z(inp["boxes"]),
+                    ref = unet_ref.unet_forward(osd, cfg, xh, tt, rt(inp["uc"]), rt(inp["relations"]), z(inp["boxes"]),
                                                 z(inp["masks"]), z(inp["positive_embeddings"]))
             else:
                 eng.set_conditioning(inp["context"], inp["relations"], inp["boxes"], inp["masks"], inp["positive_embeddings"], hw)
                 sc, sdc = (1.0, False) if mode == "cond" else (0.0, True)
                 out = eng.forward(x, tval, sc, sdc, 1).clone()
                 with torch.no_grad():
-                    ref = unet_ref.unet_forward(osd, cfg, xh, tt, inp["context"].half().float(), inp["relations"].half().float(), inp["boxes"],
+                    ref = unet_ref.unet_forward(osd, cfg, xh, tt, rt(inp["context"]), rt(inp["relations"]), inp["boxes"],
                                                 inp["masks"], inp["positive_embeddings"], fuser_scale=sc, first_conv=ofc if sdc else None)
             n += 1
             nan_ref = torch.isnan(ref)
@@ -122,10 +134,10 @@ while time.time() - t0 < budget:
             worst = max(worst, r)
             if os.environ.get("FUZZ_CASE"):
                 print(f"{mode}: rel_l2 {r:.3e}  max|err| {float((out.cpu() - ref).abs().max()):.3e}  |ref|max {float(ref.abs().max()):.3f}")
-            if r > 4e-3:
+            if r > BOUND:
                 raise AssertionError(f"{mode}: rel_l2 {r:.3e}")
         del m, eng
     except Exception as e:  # noqa: BLE001
         fails += 1
         print(f"FAIL [{desc}]: {type(e).__name__}: {traceback.format_exc().strip().splitlines()[-1][:300]}", flush=True)
-print(f"fuzz_engine: {n} forwards checked, {fails} failing architectures, worst rel_l2 {worst:.2e}, {time.time() - t0:.0f} s")
+print(f"fuzz_engine{' (STRICT mode)' if STRICT else ''}: {n} forwards checked, {fails} failing architectures, worst rel_l2 {worst:.2e}, {time.time() - t0:.0f} s")
