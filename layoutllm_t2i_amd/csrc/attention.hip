@@ -382,17 +382,20 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(gl_attn_args p, int flags
 // the score registers); 4 waves x 32 queries, ONE LDS buffer set (K hi / lo, V^T hi / lo: 89 KB at d = 160, dynamic LDS)
 // with two barriers per 64-key tile, the FMA form of the online softmax.  Three times the matrix work of attn_kernel by
 // construction: this is the parity mode, not the fast one.
-template <int DQK>
-__global__ __launch_bounds__(256) void attn_split_kernel(gl_attn_args p) {
-    constexpr int NW = 4, NTHR = 64 * NW;
+template <int DQK, int NW, bool DBUF>
+__global__ __launch_bounds__(64 * NW) void attn_split_kernel(gl_attn_args p) {
+    // NW = 4 or 8 waves (8: 256 queries share every staged tile).  DBUF: the next tile's rows are loaded into registers before the
+    // MFMAs of the current one and stored to the OTHER LDS buffer set after them (one barrier per tile, loads in flight under the
+    // compute, as attn_kernel); without it one buffer set and two barriers per tile (the large head dims: 89 KB per set at d = 160).
+    constexpr int NTHR = 64 * NW;
     constexpr int NKS = DQK / 16, NDT = (DQK + 31) / 32, KSTR = DQK + 8, KCH = DQK / 8;
     constexpr int K_ITEMS = KT * KCH, K_PER_T = (K_ITEMS + NTHR - 1) / NTHR;
     constexpr int V_ITEMS = NDT * 32 * (KT / 8), V_PER_T = (V_ITEMS + NTHR - 1) / NTHR;
     constexpr int QBLK = NW * 32;
     constexpr int KBUF = KT * KSTR, VBUF = NDT * 32 * VSTR2;
+    constexpr int SET = 2 * KBUF + 2 * VBUF;                    // one buffer set: K hi, K lo, V^T hi, V^T lo
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_attn[];
-    half_t* Ksm = reinterpret_cast<half_t*>(smem_attn);         // [2 (hi, lo)][KBUF]
-    half_t* Vsm = Ksm + 2 * KBUF;                               // [2 (hi, lo)][VBUF]
+    half_t* sm = reinterpret_cast<half_t*>(smem_attn);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ql = lane & 31, hi = lane >> 5;
     const int nqb = (p.Nq + QBLK - 1) / QBLK;
@@ -434,52 +437,79 @@ __global__ __launch_bounds__(256) void attn_split_kernel(gl_attn_args p) {
     float m_run = -INFINITY, l_run = 0.0f;
     const float c_scale = p.q_prescaled ? 1.0f : p.scale * 1.4426950408889634f;
 
-    const int ntiles = (Nk + KT - 1) / KT;
-    for (int t = 0; t < ntiles; ++t) {
-        const int key0 = t * KT;
-        // ---- stage K hi / lo [64][d] and V^T hi / lo [d][64] (zero padding, keys >= Nk masked: see attn_kernel)
+    // ---- staging: rows of K hi / lo [64][d] and V^T hi / lo [d][64] (zero padding, keys >= Nk masked: see attn_kernel)
+    uint4 rk[2][K_PER_T], rv[2][V_PER_T];
+    auto load_tile = [&](const int key0) __attribute__((always_inline)) {
 #pragma unroll
         for (int part = 0; part < 2; ++part) {
 #pragma unroll
             for (int i = 0; i < K_PER_T; ++i) {
                 const int idx = tid + NTHR * i;
-                if (idx < K_ITEMS) {
-                    const int row = idx / KCH, c = idx - row * KCH;
-                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                    if (c * 8 < d && key0 + row < Nk) v = ld16(Kg[part] + (size_t)(key0 + row) * p.ldk + c * 8);
-                    st16(Ksm + part * KBUF + row * KSTR + c * 8, v);
-                }
+                const int row = idx / KCH, c = idx - row * KCH;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (idx < K_ITEMS && c * 8 < d && key0 + row < Nk) v = ld16(Kg[part] + (size_t)(key0 + row) * p.ldk + c * 8);
+                rk[part][i] = v;
             }
 #pragma unroll
             for (int i = 0; i < V_PER_T; ++i) {
                 const int idx = tid + NTHR * i;
-                if (idx < V_ITEMS) {
-                    const int row = idx >> 3, c = idx & 7;
-                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                    if (row < d) {
-                        v = ld16(Vg[part] + (size_t)row * p.ldvt + key0 + c * 8);
-                        const int kfirst = key0 + c * 8;
-                        if (kfirst + 8 > Nk) {
-                            const int keep = Nk - kfirst;
-                            unsigned w[4] = {v.x, v.y, v.z, v.w};
+                const int row = idx >> 3, c = idx & 7;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (idx < V_ITEMS && row < d) {
+                    v = ld16(Vg[part] + (size_t)row * p.ldvt + key0 + c * 8);
+                    const int kfirst = key0 + c * 8;
+                    if (kfirst + 8 > Nk) {
+                        const int keep = Nk - kfirst;
+                        unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                if (2 * q >= keep) w[q] = 0u;
-                                else if (2 * q + 1 >= keep) w[q] &= 0xFFFFu;
-                            }
-                            v = make_uint4(w[0], w[1], w[2], w[3]);
+                        for (int q = 0; q < 4; ++q) {
+                            if (2 * q >= keep) w[q] = 0u;
+                            else if (2 * q + 1 >= keep) w[q] &= 0xFFFFu;
                         }
+                        v = make_uint4(w[0], w[1], w[2], w[3]);
                     }
-                    uint2* dst = reinterpret_cast<uint2*>(Vsm + part * VBUF + row * VSTR2 + 16 * (c >> 1) + 4 * (c & 1));
-                    dst[0] = make_uint2(v.x, v.y);
-                    dst[2] = make_uint2(v.z, v.w);
+                }
+                rv[part][i] = v;
+            }
+        }
+    };
+    auto store_tile = [&](const int buf) __attribute__((always_inline)) {
+        half_t* base = sm + buf * SET;
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+#pragma unroll
+            for (int i = 0; i < K_PER_T; ++i) {
+                const int idx = tid + NTHR * i;
+                const int row = idx / KCH, c = idx - row * KCH;
+                if (idx < K_ITEMS) st16(base + part * KBUF + row * KSTR + c * 8, rk[part][i]);
+            }
+#pragma unroll
+            for (int i = 0; i < V_PER_T; ++i) {
+                const int idx = tid + NTHR * i;
+                const int row = idx >> 3, c = idx & 7;
+                if (idx < V_ITEMS) {
+                    uint2* dst = reinterpret_cast<uint2*>(base + 2 * KBUF + part * VBUF + row * VSTR2 + 16 * (c >> 1) + 4 * (c & 1));
+                    dst[0] = make_uint2(rv[part][i].x, rv[part][i].y);
+                    dst[2] = make_uint2(rv[part][i].z, rv[part][i].w);
                 }
             }
         }
-        __syncthreads();
+    };
+
+    const int ntiles = (Nk + KT - 1) / KT;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int key0 = t * KT;
+        const int cur = DBUF ? (t & 1) : 0;
+        const half_t* Ksm = sm + cur * SET;
+        const half_t* Vsm = Ksm + 2 * KBUF;
+        if (DBUF && t + 1 < ntiles) load_tile(key0 + KT);          // global -> registers, in flight under the MFMAs below
         const bool tail = (key0 + KT > Nk);
         // ---- S^T = K . Q^T in three passes (small terms first)
         f32x16 s[2];
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
 #pragma unroll
@@ -493,6 +523,7 @@ __global__ __launch_bounds__(256) void attn_split_kernel(gl_attn_args p) {
                 s[kh] = mfma32(kfh, qf[0][ks], s[kh]);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
         if (tail) {
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh)
@@ -540,6 +571,7 @@ __global__ __launch_bounds__(256) void attn_split_kernel(gl_attn_args p) {
             }
         l_run += psum;
         // ---- O^T += V^T . P^T in three passes
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -550,7 +582,18 @@ __global__ __launch_bounds__(256) void attn_split_kernel(gl_attn_args p) {
                 o[dt] = mfma32(vfh, *reinterpret_cast<const half8_t*>(&pfl[j]), o[dt]);
                 o[dt] = mfma32(vfh, *reinterpret_cast<const half8_t*>(&pfh[j]), o[dt]);
             }
-        __syncthreads();       // every wave is done with the tile before the next one is staged
+        __builtin_amdgcn_s_setprio(0);
+        if constexpr (DBUF) {
+            if (t + 1 < ntiles) store_tile((t + 1) & 1);       // the other set: last read one iteration ago, before the barrier
+            __syncthreads();
+        } else {
+            __syncthreads();       // every wave is done with the tile before the next one is staged
+            if (t + 1 < ntiles) {
+                load_tile(key0 + KT);
+                store_tile(0);
+                __syncthreads();
+            }
+        }
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
@@ -579,15 +622,36 @@ __global__ __launch_bounds__(256) void attn_split_kernel(gl_attn_args p) {
     }
 }
 
-template <int DQK>
-constexpr int attn_split_lds() { return 2 * (KT * (DQK + 8) + ((DQK + 31) / 32) * 32 * VSTR2) * (int)sizeof(half_t); }
+template <int DQK, bool DBUF>
+constexpr int attn_split_lds() { return (DBUF ? 2 : 1) * 2 * (KT * (DQK + 8) + ((DQK + 31) / 32) * 32 * VSTR2) * (int)sizeof(half_t); }
 
+// 8-wave double-buffered blocks for the small head dims on long query ranges (d = 40 at N = 4096: 1.35 ms -> see DESIGN.md 3), 4-wave double-buffered
+// up to d = 80, single buffer set above (2 x 89 KB would not fit at d = 160)
 template <int DQK>
 int launch_attn_split(const gl_attn_args& a, hipStream_t st) {
-    dim3 grid(gl_cdiv(a.Nq, 128) * a.H * a.B);
-    attn_split_kernel<DQK><<<grid, dim3(256), attn_split_lds<DQK>(), st>>>(a);
+    if constexpr (DQK <= 48) {
+        if (a.Nq >= 512) {
+            attn_split_kernel<DQK, 8, true><<<dim3(gl_cdiv(a.Nq, 256) * a.H * a.B), dim3(512), attn_split_lds<DQK, true>(), st>>>(a);
+            GL_CHECK_LAUNCH();
+            return 0;
+        }
+    }
+    if constexpr (DQK <= 80) attn_split_kernel<DQK, 4, true><<<dim3(gl_cdiv(a.Nq, 128) * a.H * a.B), dim3(256), attn_split_lds<DQK, true>(), st>>>(a);
+    else attn_split_kernel<DQK, 4, false><<<dim3(gl_cdiv(a.Nq, 128) * a.H * a.B), dim3(256), attn_split_lds<DQK, false>(), st>>>(a);
     GL_CHECK_LAUNCH();
     return 0;
+}
+
+template <int DQK>
+int set_attr_split() {
+    hipError_t e = hipSuccess;
+    if constexpr (DQK <= 48) e = hipFuncSetAttribute((const void*)attn_split_kernel<DQK, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_split_lds<DQK, true>());
+    if constexpr (DQK <= 80) {
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_split_kernel<DQK, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_split_lds<DQK, true>());
+    } else {
+        e = hipFuncSetAttribute((const void*)attn_split_kernel<DQK, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_split_lds<DQK, false>());
+    }
+    return e == hipSuccess ? 0 : (int)e;
 }
 
 // V [B, Nk, *] -> V^T [B, H, d, ldvt] with zero fill of keys >= Nk.  One block per (64 keys, head, sample): 16-byte
@@ -685,10 +749,12 @@ extern "C" int gl_attention(const gl_attn_args* a, void* stream) {
 }
 
 extern "C" int gl_init_attn(void) {
-    // the split-fp16 kernel's LDS exceeds the 64 KB static limit at the largest head dims
-    hipError_t e = hipFuncSetAttribute((const void*)attn_split_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_split_lds<128>());
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_split_kernel<160>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_split_lds<160>());
-    return e == hipSuccess ? 0 : (int)e;
+    // the split-fp16 kernels' dynamic LDS (above the 64 KB static limit for the double-buffered and the large-head-dim forms)
+    int e;
+    if ((e = set_attr_split<16>()) || (e = set_attr_split<32>()) || (e = set_attr_split<48>()) || (e = set_attr_split<64>()) || (e = set_attr_split<80>()) ||
+        (e = set_attr_split<128>()) || (e = set_attr_split<160>()))
+        return e;
+    return 0;
 }
 
 extern "C" int gl_transpose_v(const void* v, int64_t v_bstride, int32_t ldv, void* vt, int32_t ldvt, int32_t B,
