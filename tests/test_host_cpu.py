@@ -272,7 +272,9 @@ def test_interface_surface_matches_reference_names():
     assert sig(I.generate_one_image) == ["all_models", "caption", "label", "bbox", "clip_model", "clip_processor", "device"]
     assert sig(I.run_batch_images) == ["all_models", "args", "meta", "starting_noise", "clip_model", "clip_processor", "device"]
     assert sig(I.run_one_image) == sig(I.run_batch_images)
-    assert sig(I.load_all_models) == ["ckpt", "device"] and sig(I.load_ckpt) == ["ckpt_path", "device"]
+    # the reference's positional parameters, plus this build's optional keyword (default None = GLIGEN_STRICT from the environment)
+    assert sig(I.load_all_models) == ["ckpt", "device", "strict"] and sig(I.load_ckpt) == ["ckpt_path", "device", "strict"]
+    assert inspect.signature(I.load_all_models).parameters["strict"].default is None and inspect.signature(I.load_ckpt).parameters["strict"].default is None
     assert sig(PLMSSampler.sample) == ["self", "S", "shape", "input", "uc", "guidance_scale", "mask", "x0"]
     assert sig(PLMSSampler.__init__) == ["self", "diffusion", "model", "schedule", "alpha_generator_func", "set_alpha_scale"]
     assert I.convert_xywh_to_ltrb([0.1, 0.2, 0.3, 0.4]) == pytest.approx([0.1, 0.2, 0.4, 0.6])
