@@ -128,6 +128,8 @@ def parse():
     ap.add_argument("--no-hot-kernel", action="store_true", help="skip the standalone timing of the hottest kernel shape (PMC passes)")
     ap.add_argument("--no-strict", action="store_true", help="skip the strict-mode leg (second engine on split weights: images/s + parity beside the default mode)")
     ap.add_argument("--strict-steps", type=int, default=2, help="timed denoise steps of the strict-mode leg")
+    ap.add_argument("--strict-main", action="store_true", help="run the MAIN timed loop in strict mode (any config; the line then says so in dtype / config; "
+                    "not the headline: the headline is the default mode)")
     ap.add_argument("--no-vae", action="store_true", help="stop at the final latent (exclude the VAE decode stage from the step)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
                     help="gl_set_option tuning knob for same-box A/B runs (see include/gligen_hip.h), repeatable")
@@ -173,6 +175,10 @@ def main():
     from layoutllm_t2i_amd.weights import pack_state_dict, random_state_dict, random_vae_state_dict
 
     cfg = TINY if args.tiny else UNetConfig()
+    if args.strict_main:
+        import dataclasses as _dcs
+        cfg = _dcs.replace(cfg, split_weights=True)
+        args.no_strict = True
     cnum = args.config or (2 if world == 1 else 4)
     cidx, B, side, nbox = CONFIGS[cnum]
     B, side, nbox = args.batch or B, args.latent or side, args.boxes or nbox
@@ -234,6 +240,8 @@ def main():
         m_.engine = UNetEngine(packed_)
         return m_
     model = make_model(packed)
+    if args.strict_main:
+        model.engine.set_option(50, 1)
     diffusion = LatentDiffusion(device=dev)
     all_models = (model, vae, None, diffusion, {})
     setup_s = time.time() - t0
@@ -467,7 +475,7 @@ def main():
         "metric": f"{side * 8}x{side * 8} {args.plms_steps}-step images/sec (PLMS, CFG 7.5, layout-conditioned GLIGEN UNet)",
         "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "fp16 (fp32 accumulate)", "data": "synthetic inputs, random-init weights of the reference architecture",
+        "vs_baseline": None, "dtype": "split-fp16 operands, 3 MFMA passes (STRICT mode), fp32 accumulate" if args.strict_main else "fp16 (fp32 accumulate)", "data": "synthetic inputs, random-init weights of the reference architecture",
         "config": {"workload": ("custom (flags override the named config): " if overridden else f"configs[{cidx}]: ")
                    + f"{'TINY debug UNet, ' if args.tiny else ''}{side * 8}x{side * 8}, {args.plms_steps} PLMS steps, batch={B}/GPU, {args.boxes} grounding boxes/image, fp16",
                    "survey_config": cnum,
