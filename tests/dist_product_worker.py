@@ -40,7 +40,8 @@ def main():
     torch.load = counting_load
     try:
         stubs.install_fake_sng_parser()
-        am = itf.load_all_models_sharded(ckpt, dev, src=0)
+        strict = os.environ.get("W_STRICT") == "1"          # rank 0 decides (its argument); the flag and the split layout travel in the bundle
+        am = itf.load_all_models_sharded(ckpt, dev, src=0, strict=strict if rank == 0 else None)
         if os.environ.get("W_CLIP_TOWER"):
             # checkpoint with a CLIP text tower: the HIP encoder is on every rank (its weights came in the bundle), rank 0 only tokenises;
             # grounding phrases go through the same tower (clip_model None on every rank)
@@ -53,7 +54,8 @@ def main():
         if rank == 0:
             np.savez(os.path.join(out_dir, "images.npz"), imgs=np.stack([np.asarray(im) for im in imgs]))
         print("RESULT " + json.dumps(dict(rank=rank, ckpt_reads=reads["n"], text_encoder=am[2] is not None, text_encoder_type=type(am[2]).__name__,
-                                          n_images=None if imgs is None else len(imgs))), flush=True)
+                                          n_images=None if imgs is None else len(imgs), strict=bool(getattr(am[0], "strict", False)),
+                                          split_weights=bool(getattr(am[0].cfg, "split_weights", False)))), flush=True)
     finally:
         dist.destroy_process_group()
 

@@ -163,6 +163,50 @@ def test_product_entry_two_ranks_hip_text_encoder_each_rank_encodes_its_own_shar
         assert np.array_equal(got[mine], ref), f"rank {r}: {np.abs(got[mine].astype(int) - ref.astype(int)).max()}"
 
 
+def test_product_entry_two_ranks_strict_mode(tmp_path):
+    """load_all_models_sharded(..., strict=True) on rank 0 only: the SPLIT weight layout and the strict flag travel in the one bundle broadcast, rank 1
+    (which never opens the checkpoint) runs its shard in strict mode too, and the gathered images equal -- bitwise -- this process's own strict load."""
+    import stubs
+    import dist_product_worker as W
+    from layoutllm_t2i_amd import interface as itf
+    from layoutllm_t2i_amd.arch import TINY, VAE_TINY
+    from layoutllm_t2i_amd.dist import shard_indices
+    ckpt = str(tmp_path / "tiny_gligen.pth")
+    stubs.write_synthetic_checkpoint(ckpt, TINY, VAE_TINY, max_relations=10)
+    world, port = 2, _free_port()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_product_worker.py")
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2", W_STRICT="1")
+        procs.append(subprocess.Popen([sys.executable, worker, ckpt, str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    res = []
+    try:
+        for p in procs:
+            out, err = p.communicate(timeout=600)
+            assert p.returncode == 0, err[-3000:]
+            res.append(json.loads(next(l for l in out.splitlines() if l.startswith("RESULT "))[7:]))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    a, b = sorted(res, key=lambda d: d["rank"])
+    assert a["ckpt_reads"] >= 1 and b["ckpt_reads"] == 0
+    assert a["strict"] and b["strict"] and a["split_weights"] and b["split_weights"], (a, b)
+    got = np.load(tmp_path / "images.npz")["imgs"]
+    dev = "cuda:0"
+    stubs.install_fake_sng_parser()
+    am = itf.load_all_models(ckpt, dev, strict=True)
+    cond = itf.prepare_conditioning(am, W.PROMPTS, W.PHRASES, W.BOXES, stubs.toy_clip().to(dev), stubs.ToyProcessor(), dev)
+    for r in range(world):
+        mine = shard_indices(len(W.PROMPTS), r, world)
+        ref = itf.run_shard(am, {k: v[mine] for k, v in cond.items()}, itf.prompt_noise([W.SEEDS[i] for i in mine], W.LATENT), dev, steps=W.STEPS)
+        assert np.array_equal(got[mine], ref), f"rank {r}: {np.abs(got[mine].astype(int) - ref.astype(int)).max()}"
+    # and the strict images differ from the default mode's (the flag really travelled)
+    am0 = itf.load_all_models(ckpt, dev)
+    ref0 = itf.run_shard(am0, cond, itf.prompt_noise(W.SEEDS, W.LATENT), dev, steps=W.STEPS)
+    assert not np.array_equal(got, ref0)
+
+
 def test_rccl_path_of_the_bench_at_world_1():
     """The multi-rank code path of bench.py (RCCL process group bound to the device, bundle broadcast of UNet + VAE, barriers,
     max-over-ranks all-reduce) launched exactly as the driver launches N > 1, with ONE rank: every collective goes through
