@@ -544,7 +544,11 @@ int gl_sizeof_gn_args(void);
  * default mode's time).  The relation chain of rela_fuse (1/30 weight, 3e-6 of the result) and the fused first conv keep their forms.
  * key 51 = strict mode's third pass x.Wlo (1 default; 0 = activations split only: exact for fp16-representable weights except the
  * folded softmax scale of the q projections).  gl_set_conditioning reads keys 50 / 51 too (its strict hoists follow key 51): call it
- * again after changing key 51. */
+ * again after changing key 51.
+ * key 52 = three-pass split-fp16 products xhi.Whi + xlo.Whi + xhi.Wlo (gl_gemm with K = 3 * kwrap whose second source is the first one again;
+ * gl_conv3x3 with in_split = 3) run the DEDICATED three-pass main loop of the 8-wave kernel (1 default; csrc/gemm8.hip S3: a ring stage holds
+ * one 32-wide k slice of {xhi, xlo, Whi, Wlo} and feeds three MFMA groups, so no operand is staged twice); 0 = the K-walk over
+ * [xhi | xlo | xhi] x [Whi | Whi | Wlo].  Same products, other fp32 summation order. */
 int gl_set_option(int key, int value);
 /* gl_set_option writes the PROCESS defaults (op-level calls and every handle without an override see them).  A handle can
  * override individual keys for itself: while one of ITS entry points (gl_set_conditioning / gl_unet_forward / gl_plms_step,

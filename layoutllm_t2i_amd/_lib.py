@@ -10,7 +10,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgligen_hip.so")
+# GLIGEN_HIP_LIB: measurement hook -- the file name of an A/B build of the same library next to the product one
+# (csrc/build.py --variant); never a path outside this package, never a fallback: a missing file raises like the product library
+LIB_PATH = os.path.join(_HERE, os.path.basename(os.environ.get("GLIGEN_HIP_LIB", "") or "libgligen_hip.so"))
 ABI_VERSION = 14
 
 # enum gl_epilogue / gl_out_mode

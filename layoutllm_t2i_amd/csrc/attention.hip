@@ -21,11 +21,13 @@
 #include "common.h"
 #include "gligen_hip.h"
 #include "opts.h"
+#include <type_traits>
 
 namespace {
 
 #define g_attn_qt2 gl_opt(3)  // default 0;          // block shape: 0 auto, 3 always 8 waves, 4 always 4 waves
 #define g_attn_padmax gl_opt(29)  // default 1;       // running max carried in the operands' padding column where the head dim has one (gl_set_option 29; 0 = FMA path)
+#define g_attn_split_var gl_opt(53)  // split-fp16 attention, d <= 48: 0 = software-pipelined kernel (d = 32 / 40 / 48), 2 = the round-5 8-wave kernel, 1 = its 4-wave form, two blocks per CU (A/B)
 #define g_attn_setprio gl_opt(10)  // default -1;     // s_setprio(1) around the MFMA clusters: -1 auto (head dim <= 48: +6 %; d = 80: -4 %), 0 off, 1 on
 constexpr int KT = 64;          // keys per tile
 constexpr int VSTR2 = KT + 8;   // main kernel: 144 B rows = 9 x 16 B, conflict-free 16-byte fragment reads
@@ -622,6 +624,377 @@ __global__ __launch_bounds__(64 * NW) void attn_split_kernel(gl_attn_args p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// attn_split_pipe_kernel<D8> (round 6): the split-fp16 attention of the level-0 head dims (d = 8 * D8 in {32, 40, 48}), restructured.
+// attn_split_kernel runs [Q.K^T MFMAs] [softmax VALU] [P.V MFMAs] back to back in every wave, and the two waves of a SIMD, locked to one
+// barrier per tile, do the same thing at the same time: measured 757 us at (40, 4096, 4096) = exactly the SUM of its MFMA time (42 x 32
+// cycles) and its VALU time per wave-tile, i.e. the matrix pipe and the VALU never overlap.  Here:
+//   * software pipeline inside a wave: iteration t issues the MFMAs of P.V(t-1) and Q.K^T(t+1) interleaved with the softmax VALU of tile
+//     t (scores of tile t were produced one iteration earlier), so every MFMA has independent VALU work behind it in program order;
+//   * fewer MFMAs: Q.K^T as ONE product over the concatenated K dimension [khi | khi | klo] x [qhi | qlo | qhi] (3 d = 120 -> 8 steps of 16
+//     instead of 3 x 48 -> 9); P.V on the STACKED rows [vhi (d) | vlo (d)] of V^T: Phi multiplies all ceil(2 d / 32) row tiles, Plo only
+//     the tiles that hold vhi rows (it also meets the vlo rows that share such a tile: the 4th term Plo.Vlo of the exact product, 2^-22) --
+//     5 instead of 6 MFMAs per 16 keys at d = 40; the output is acc[row] + acc[row + d], which is the same lane, 4 D8 registers apart;
+//   * deferred rescale: the running max moves only when a tile's max exceeds it by more than 2 (P <= 2^15 in the 2^13-scaled fp16
+//     fragments), as a wave-uniform branch; packed fp32 VALU (v_pk_fma / v_pk_add / v_pk_mul) for the exponent, row sum and rescale.
+// 8 waves x 32 queries; K tiles [64][khi | klo] and stacked V^T tiles in two LDS slots each (K(t+1), V(t-1) are read while K(t+2), V(t)
+// are written; one barrier per tile); results agree with attn_split_kernel to fp32 summation order.
+template <int D8>
+__global__ __launch_bounds__(512) void attn_split_pipe_kernel(gl_attn_args p) {
+    constexpr int D = 8 * D8;
+    constexpr int NKS = D8 + (D8 + 1) / 2;          // 16-wide steps over the concatenated Q.K^T K dimension (3 d columns, see qcat)
+    constexpr int NT = (2 * D + 31) / 32;           // 32-row tiles of the stacked V^T
+    constexpr int NTL = (D + 31) / 32;              // ... that hold vhi rows
+    constexpr int KSTR = 2 * D + 8;                 // K row [khi | klo] + 16 bytes: (KSTR / 2) / 4 is odd -> conflict-free 16-byte fragment reads
+    constexpr int VROWS = NT * 32;
+    constexpr int KBUF = KT * KSTR, VBUF = VROWS * VSTR2;
+    constexpr int NTHR = 512;
+    static_assert(D8 >= 4 && D8 <= 6 && ((KSTR / 2) / 4) % 2 == 1, "head dims 32 / 40 / 48");
+    __shared__ __attribute__((aligned(16))) half_t sK[2][KBUF];
+    __shared__ __attribute__((aligned(16))) half_t sV[2][VBUF];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ql = lane & 31, hi = lane >> 5;
+    const int nqb = (p.Nq + 255) / 256;
+    int logical;
+    {
+        const int total = gridDim.x, L = blockIdx.x;
+        const int xcd = L & 7, qd = total >> 3, rm = total & 7;
+        logical = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (L >> 3);
+    }
+    const int qb = logical % nqb, bh = logical / nqb, h = bh % p.H, b = bh / p.H;
+    const int q0 = qb * 256 + wave * 32;
+    const int Nq = p.Nq, Nk = p.Nk;
+    const size_t qoff = (size_t)b * p.q_bstride + (size_t)h * D, koff = (size_t)b * p.k_bstride + (size_t)h * D;
+    const size_t voff = (size_t)(b * p.H + h) * D * p.ldvt;
+    const half_t* Kg[2] = {reinterpret_cast<const half_t*>(p.k) + koff, reinterpret_cast<const half_t*>(p.k_lo) + koff};
+    const half_t* Vg[2] = {reinterpret_cast<const half_t*>(p.vt) + voff, reinterpret_cast<const half_t*>(p.vt_lo) + voff};
+
+    // rows [2 D, VROWS) of both V slots are never staged: zero them once (they meet P in the MFMAs: 0, not stale LDS bits)
+    if constexpr (VROWS > 2 * D) {
+        constexpr int ZW = (VROWS - 2 * D) * VSTR2 / 8;
+        for (int i = tid; i < 2 * ZW; i += NTHR) st16(&sV[i / ZW][2 * D * VSTR2 + 8 * (i % ZW)], make_uint4(0u, 0u, 0u, 0u));
+    }
+
+    // The concatenated K dimension of Q.K^T, 16 columns (two 8-column chunks: lanes hi = 0 / 1) per MFMA step, paired so that the K-side
+    // fragment address is ONE per-lane base + a compile-time offset:
+    //   steps 0 .. D8-1        : hi = 0 -> khi chunk i x qhi chunk i,  hi = 1 -> klo chunk i x qhi chunk i   (K base A = row + hi * D)
+    //   steps D8 .. NKS-1 (m)  : khi chunk 2m + hi x qlo chunk 2m + hi (zero Q chunk past D8)                  (K base B = row + hi * 8)
+    half8_t qcat[NKS];
+    {
+        int q = q0 + ql;
+        if (q >= Nq) q = Nq - 1;
+        const half_t* qh = reinterpret_cast<const half_t*>(p.q) + qoff + (size_t)q * p.ldq;
+        const half_t* qlo = reinterpret_cast<const half_t*>(p.q_lo) + qoff + (size_t)q * p.ldq;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (ks < D8) v = ld16(qh + ks * 8);
+            else if (2 * (ks - D8) + hi < D8) v = ld16(qlo + (2 * (ks - D8) + hi) * 8);
+            qcat[ks] = *reinterpret_cast<half8_t*>(&v);
+        }
+    }
+    const int kbase_a = ql * KSTR + hi * D, kbase_b = ql * KSTR + hi * 8;
+    // halves added to kbase_a / kbase_b for step ks (the zero Q chunk of an odd D8 meets khi chunk D8 - 1 again: finite)
+    auto kfo = [&](const int ks) __attribute__((always_inline)) -> int {
+        if (ks < D8) return kbase_a + ks * 8;
+        const int m = ks - D8;
+        return (2 * m + 1 < D8) ? kbase_b + 16 * m : ql * KSTR + 16 * m;        // last step of an odd D8: both halves read chunk D8 - 1
+    };
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;
+    const float c_scale = p.q_prescaled ? 1.0f : p.scale * 1.4426950408889634f;
+
+    // ---- staging (global -> registers -> LDS): K rows [khi | klo], stacked V^T rows with the key order of the P fragments (attn_kernel)
+    // Staging: 4 D8 wave-level loads of 64 x 16 bytes per tile -- [khi | klo | vhi | vlo] x D8 -- dealt round-robin to the 8 waves, so that
+    // the KIND of a wave's load i (which source array, which tile) is wave-uniform: scalar base pointers and branches, one per-lane byte
+    // offset (loop-invariant) per load.  Chunk x = 64 (L % D8) + lane of a kind: K row x / D8, column chunk x % D8; V^T row x / 8, key chunk x % 8.
+    constexpr int NLOAD = 4 * D8;
+    constexpr int KV_PER_T = (NLOAD + 7) / 8;
+    uint4 rkv[KV_PER_T];
+    // per-thread, loop-invariant: byte offset inside the source array at key0 = 0 and destination (halves) inside sK[slot] / sV[slot].  Kept in
+    // LDS, not in registers: the main loop runs at the 256-register limit of two waves per SIMD, and a compiler spill of these would come back
+    // through scratch loads whose s_waitcnt vmcnt(0) also drains the K / V prefetch just issued
+    __shared__ unsigned sGoff[KV_PER_T][NTHR];
+    __shared__ int sSoff[KV_PER_T][NTHR];
+#pragma unroll
+    for (int i = 0; i < KV_PER_T; ++i) {
+        const int L = wave + 8 * i;                     // wave-uniform
+        const int kind = L / D8;                        // 0 khi, 1 klo, 2 vhi, 3 vlo (>= 4: nothing)
+        const int x = 64 * (L - kind * D8) + lane;
+        if (kind < 2) {
+            const int row = x / D8, c = x - row * D8;
+            sGoff[i][tid] = (unsigned)(row * p.ldk + c * 8) * 2u;
+            sSoff[i][tid] = row * KSTR + kind * D + c * 8;
+        } else {
+            const int row = x >> 3, c = x & 7;
+            sGoff[i][tid] = (unsigned)(row * p.ldvt + c * 8) * 2u;
+            sSoff[i][tid] = ((kind - 2) * D + row) * VSTR2 + 16 * (c >> 1) + 4 * (c & 1);
+        }
+    }
+    int soff[KV_PER_T];
+    auto load_kv = [&](const int key0_k, const bool do_k, const int key0_v, const bool do_v) __attribute__((always_inline)) {
+        // wave-uniform fast path: both tiles lie inside [0, Nk) -> no per-key masking (every tile but the last one or two)
+        const bool full = (!do_k || key0_k + KT <= Nk) && (!do_v || key0_v + KT <= Nk);
+#pragma unroll
+        for (int i = 0; i < KV_PER_T; ++i) {
+            const int L = __builtin_amdgcn_readfirstlane(wave) + 8 * i;
+            const int kind = L / D8;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (kind < 2) {
+                if (do_k) {
+                    const char* base = reinterpret_cast<const char*>(kind == 0 ? Kg[0] : Kg[1]) + (size_t)key0_k * p.ldk * 2;
+                    if (full || key0_k + (64 * (L - kind * D8) + lane) / D8 < Nk) v = ld16(base + sGoff[i][tid]);
+                }
+            } else if (kind < 4) {
+                if (do_v) {
+                    const char* base = reinterpret_cast<const char*>(kind == 2 ? Vg[0] : Vg[1]) + (size_t)key0_v * 2;
+                    v = ld16(base + sGoff[i][tid]);
+                    if (!full) {
+                        const int kfirst = key0_v + (lane & 7) * 8;
+                        if (kfirst + 8 > Nk) {          // pad keys: their V^T columns may hold anything (NaN included)
+                            const int keep = Nk - kfirst;
+                            unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                if (2 * q >= keep) w[q] = 0u;
+                                else if (2 * q + 1 >= keep) w[q] &= 0xFFFFu;
+                            }
+                            v = make_uint4(w[0], w[1], w[2], w[3]);
+                        }
+                    }
+                }
+            }
+            rkv[i] = v;
+            soff[i] = sSoff[i][tid];
+        }
+    };
+    auto store_kv = [&](const int kslot, const bool do_k, const int vslot, const bool do_v) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < KV_PER_T; ++i) {
+            const int L = __builtin_amdgcn_readfirstlane(wave) + 8 * i;
+            const int kind = L / D8;
+            if (kind < 2) {
+                if (do_k) st16(&sK[kslot][soff[i]], rkv[i]);
+            } else if (kind < 4) {
+                if (do_v) {
+                    uint2* dst = reinterpret_cast<uint2*>(&sV[vslot][soff[i]]);
+                    dst[0] = make_uint2(rkv[i].x, rkv[i].y);
+                    dst[2] = make_uint2(rkv[i].z, rkv[i].w);
+                }
+            }
+        }
+    };
+    // fragment loads (LDS -> registers); every consumer below prefetches one group ahead of its MFMAs
+    auto load_vf = [&](const half_t* Vsm, const int j, half8_t (&vf)[NT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) vf[i] = *reinterpret_cast<const half8_t*>(Vsm + (i * 32 + ql) * VSTR2 + 16 * j + 8 * hi);
+    };
+    constexpr int KG = 2;                               // K fragments per prefetch group (registers: two groups are in flight)
+    constexpr int NKG = (NKS + KG - 1) / KG;            // groups per 32-key half
+    auto load_kf = [&](const half_t* Ksm, const int kh, const int g, half8_t (&kf)[KG]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < KG; ++i)
+            if (g * KG + i < NKS) kf[i] = *reinterpret_cast<const half8_t*>(Ksm + kh * 32 * KSTR + kfo(g * KG + i));
+    };
+    // O^T += stacked V^T . P^T for the 16 keys of fragment j: Phi meets every row tile, Plo the tiles that hold vhi rows
+    auto pv_mfma = [&](const half8_t (&vf)[NT], const uint4 (&fh)[4], const uint4 (&fl)[4], const int j) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) acc[i] = mfma32(vf[i], *reinterpret_cast<const half8_t*>(&fh[j]), acc[i]);
+#pragma unroll
+        for (int i = 0; i < NTL; ++i) acc[i] = mfma32(vf[i], *reinterpret_cast<const half8_t*>(&fl[j]), acc[i]);
+    };
+    // probabilities of fragment g (8 scores of this lane's query) of the tile whose scores sit in s: p = 2^13 exp2(s c - m), split hi + lo
+    f32x2 ps2 = {0.0f, 0.0f};
+    float nm = 0.0f;
+    auto prob_group = [&](const f32x16 (&s)[2], const int g, uint4& fh, uint4& fl) __attribute__((always_inline)) {
+        const int kh = g >> 1, r0 = (g & 1) * 8;
+        unsigned hw[4], lw[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            f32x2 sv = {s[kh][r0 + 2 * e], s[kh][r0 + 2 * e + 1]};
+            f32x2 ar = sv * c_scale + nm;
+            f32x2 pv;
+            pv[0] = __builtin_amdgcn_exp2f(ar[0]);
+            pv[1] = __builtin_amdgcn_exp2f(ar[1]);
+            asm("" : "+v"(pv));                         // hi and lo from ONE value (common.h pin_value)
+            ps2 += pv;
+            const half2_t ph = __builtin_convertvector(pv, half2_t);
+            f32x2 pr = pv - __builtin_convertvector(ph, f32x2);
+            const half2_t pl = __builtin_convertvector(pr, half2_t);
+            hw[e] = *reinterpret_cast<const unsigned*>(&ph);
+            lw[e] = *reinterpret_cast<const unsigned*>(&pl);
+            // the fragments are only CONSUMED one iteration later: without a use here the compiler sinks the conversions past the MFMAs,
+            // to the end of the iteration, where nothing covers them
+            asm volatile("" : "+v"(hw[e]), "+v"(lw[e]));
+        }
+        fh = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+        fl = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+    };
+
+    const int ntiles = (Nk + KT - 1) / KT;
+    // prologue: K(0), K(1) staged; scores of tile 0
+    load_kv(0, true, 0, false);
+    store_kv(0, true, 0, false);
+    if (ntiles > 1) { load_kv(KT, true, 0, false); store_kv(1, true, 0, false); }
+    __syncthreads();
+    f32x16 s[2];                            // scores of the current tile; overwritten IN PLACE by the next tile's, half by half, as its probabilities are done
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.0f;
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+#pragma unroll
+        for (int g = 0; g < NKG; ++g) {
+            half8_t kf[KG];
+            load_kf(sK[0], kh, g, kf);
+#pragma unroll
+            for (int i = 0; i < KG; ++i)
+                if (g * KG + i < NKS) s[kh] = mfma32(kf[i], qcat[g * KG + i], (g | i) == 0 ? zero16 : s[kh]);
+        }
+    }
+    uint4 pfh[4], pfl[4];                   // P fragments: of tile t-1 while its P.V MFMAs run, replaced IN PLACE by tile t's, fragment by fragment
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { pfh[j] = make_uint4(0u, 0u, 0u, 0u); pfl[j] = make_uint4(0u, 0u, 0u, 0u); }
+
+    // One iteration (tile t).  MFMA stream: P.V(t-1) [4 fragments] -> Q.K^T(t+1) keys 0-31 -> Q.K^T(t+1) keys 32-63; VALU stream beside it:
+    // running max + probabilities of fragments 0, 1 (scores s[0]) | fragments 2, 3 (s[1]; s[0] is being overwritten) | row sum, rare rescale.
+    // has_prev / has_next / tail are compile-time so that an iteration is ONE basic block apart from the staging loads and the rare rescale.
+    auto body = [&](auto prev_c, auto next_c, auto tail_c, const int t) __attribute__((always_inline)) {
+        constexpr bool has_prev = decltype(prev_c)::value, has_next = decltype(next_c)::value, tail = decltype(tail_c)::value;
+        const int key0 = t * KT;
+        const bool more_k = t + 2 < ntiles;
+        const half_t* Ksm = sK[(t + 1) & 1];            // K(t+1)
+        const half_t* Vsm = sV[(t + 1) & 1];            // V(t-1)
+        half8_t vf[NT];                                 // ONE buffer: the next fragment's loads are issued right behind the MFMAs that read it
+        if constexpr (has_prev) load_vf(Vsm, 0, vf);
+        load_kv(key0 + 2 * KT, more_k, key0, true);
+        if constexpr (tail) {
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key0 + kh * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (key >= Nk) s[kh][r] = -INFINITY;
+                }
+        }
+        float tmax = fmaxf(fmaxf(s[0][0], s[0][1]), s[0][2]);
+#pragma unroll
+        for (int i = 3; i + 1 < 32; i += 2) tmax = fmaxf(fmaxf(tmax, s[i >> 4][i & 15]), s[(i + 1) >> 4][(i + 1) & 15]);
+        tmax = fmaxf(tmax, s[1][15]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * c_scale;
+        // deferred rescale (wave-uniform): the running max follows only when some query's tile max exceeds it by more than 2 -- the
+        // probabilities, kept scaled by 2^13 (attn_split_kernel), then stay below 2^15 in their fp16 fragments
+        float alpha = 1.0f;
+        const bool resc = __any(tmax > m_run + 2.0f) != 0;
+        if (resc) {
+            const float m_new = fmaxf(m_run, tmax);
+            alpha = __builtin_amdgcn_exp2f(m_run - m_new);       // first tile: exp2(-inf) = 0 on zero accumulators
+            m_run = m_new;
+        }
+        nm = 13.0f - m_run;
+        ps2[0] = 0.0f; ps2[1] = 0.0f;
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- segment A: P.V(t-1), fragments 0..3 (V fragments one step ahead) | probabilities of fragments 0, 1 of tile t
+        // (a fragment of tile t replaces the fragment of tile t-1 IN PLACE right after the MFMAs that consumed it, in program order)
+        half8_t kfa[KG], kfb[KG];
+        if constexpr (has_prev) { pv_mfma(vf, pfh, pfl, 0); load_vf(Vsm, 1, vf); }
+        prob_group(s, 0, pfh[0], pfl[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (has_prev) { pv_mfma(vf, pfh, pfl, 1); load_vf(Vsm, 2, vf); }
+        prob_group(s, 1, pfh[1], pfl[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (has_prev) { pv_mfma(vf, pfh, pfl, 2); load_vf(Vsm, 3, vf); }
+        if constexpr (has_next) load_kf(Ksm, 0, 0, kfa);
+        prob_group(s, 2, pfh[2], pfl[2]);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- segment B: last P.V fragment, then Q.K^T(t+1) keys 0-31 into s[0] | probabilities of fragment 3 (scores s[1])
+        if constexpr (has_prev) pv_mfma(vf, pfh, pfl, 3);
+        if constexpr (has_next) {
+#pragma unroll
+            for (int g = 0; g < NKG; ++g) {
+                // next group (or the first group of the other half) in flight under this group's MFMAs
+                if (g + 1 < NKG) load_kf(Ksm, 0, g + 1, (g & 1) ? kfa : kfb);
+                else load_kf(Ksm, 1, 0, (g & 1) ? kfa : kfb);
+#pragma unroll
+                for (int i = 0; i < KG; ++i)
+                    if (g * KG + i < NKS) s[0] = mfma32(((g & 1) ? kfb : kfa)[i], qcat[g * KG + i], (g | i) == 0 ? zero16 : s[0]);      // C = 0: inline constant
+                if (g == 0) prob_group(s, 3, pfh[3], pfl[3]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- segment C: Q.K^T(t+1) keys 32-63 into s[1] | row sum
+#pragma unroll
+            for (int g = 0; g < NKG; ++g) {
+                constexpr int base = NKG & 1;           // buffer parity continues from segment B
+                if (g + 1 < NKG) load_kf(Ksm, 1, g + 1, ((g + base) & 1) ? kfa : kfb);
+#pragma unroll
+                for (int i = 0; i < KG; ++i)
+                    if (g * KG + i < NKS) s[1] = mfma32((((g + base) & 1) ? kfb : kfa)[i], qcat[g * KG + i], (g | i) == 0 ? zero16 : s[1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            prob_group(s, 3, pfh[3], pfl[3]);
+        }
+        l_run = l_run * alpha + (ps2[0] + ps2[1]);
+        if (resc) {
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
+        }
+        // ---- stage K(t+2) and V(t) into the slots last read one iteration ago; one barrier per tile
+        store_kv(t & 1, more_k, t & 1, true);
+        __syncthreads();
+    };
+    {
+        using T = std::true_type;
+        using F = std::false_type;
+        if (ntiles == 1) body(F{}, F{}, T{}, 0);
+        else {
+            body(F{}, T{}, F{}, 0);
+            for (int t = 1; t + 1 < ntiles; ++t) body(T{}, T{}, F{}, t);
+            body(T{}, F{}, T{}, ntiles - 1);
+        }
+    }
+    // P.V of the last tile
+    {
+        const half_t* Vsm = sV[(ntiles + 1) & 1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            half8_t vf[NT];
+            load_vf(Vsm, j, vf);
+            pv_mfma(vf, pfh, pfl, j);
+        }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + ql;
+    if (q < Nq) {
+        const size_t orow = (size_t)b * p.o_bstride + (size_t)q * p.ldo + (size_t)h * D;
+        half_t* oh = reinterpret_cast<half_t*>(p.out) + orow;
+        half_t* ol = p.out_lo ? reinterpret_cast<half_t*>(p.out_lo) + orow : nullptr;
+        // output row c (channel) = acc row c (P . vhi, + Plo . vhi) + acc row D + c (Phi . vlo): flat accumulator registers f and f + 4 D8
+#pragma unroll
+        for (int f4 = 0; f4 < D8; ++f4) {
+            const int c = 8 * f4 + 4 * hi;
+            half4_t ov, lv;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int f = 4 * f4 + jj, g = f + 4 * D8;
+                const float v = pin_value((acc[f >> 4][f & 15] + acc[g >> 4][g & 15]) * inv);
+                ov[jj] = (half_t)v;
+                lv[jj] = (half_t)(v - (float)ov[jj]);
+            }
+            *reinterpret_cast<half4_t*>(oh + c) = ov;
+            if (ol) *reinterpret_cast<half4_t*>(ol + c) = lv;
+        }
+    }
+}
+
 template <int DQK, bool DBUF>
 constexpr int attn_split_lds() { return (DBUF ? 2 : 1) * 2 * (KT * (DQK + 8) + ((DQK + 31) / 32) * 32 * VSTR2) * (int)sizeof(half_t); }
 
@@ -629,8 +1002,19 @@ constexpr int attn_split_lds() { return (DBUF ? 2 : 1) * 2 * (KT * (DQK + 8) + (
 // up to d = 80, single buffer set above (2 x 89 KB would not fit at d = 160)
 template <int DQK>
 int launch_attn_split(const gl_attn_args& a, hipStream_t st) {
+    if constexpr (DQK == 32 || DQK == 48) {
+        // level-0 head dims on long query ranges: the software-pipelined kernel (key 53 = 2: the round-5 kernel, A/B)
+        if (a.Nq >= 512 && g_attn_split_var == 0 && (a.d == 32 || a.d == 40 || a.d == 48)) {
+            const dim3 grid(gl_cdiv(a.Nq, 256) * a.H * a.B);
+            if (a.d == 32) attn_split_pipe_kernel<4><<<grid, dim3(512), 0, st>>>(a);
+            else if (a.d == 40) attn_split_pipe_kernel<5><<<grid, dim3(512), 0, st>>>(a);
+            else attn_split_pipe_kernel<6><<<grid, dim3(512), 0, st>>>(a);
+            GL_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     if constexpr (DQK <= 48) {
-        if (a.Nq >= 512) {
+        if (a.Nq >= 512 && g_attn_split_var != 1) {
             attn_split_kernel<DQK, 8, true><<<dim3(gl_cdiv(a.Nq, 256) * a.H * a.B), dim3(512), attn_split_lds<DQK, true>(), st>>>(a);
             GL_CHECK_LAUNCH();
             return 0;

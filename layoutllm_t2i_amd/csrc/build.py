@@ -32,11 +32,16 @@ def _newer(a: str, b: str) -> bool:
     return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, variant: str = "", defines=()) -> str:
+    """``variant`` / ``defines``: a same-box A/B build of compile-time alternatives -- objects under build_<variant>/, library
+    libgligen_hip_<variant>.so next to the product library (selected at run time with GLIGEN_HIP_LIB, see _lib.py); the product
+    build takes neither."""
     hipcc = _hipcc()
+    OBJDIR = os.path.join(HERE, "build_" + variant) if variant else globals()["OBJDIR"]
+    LIB = os.path.join(PKG, f"libgligen_hip_{variant}.so") if variant else globals()["LIB"]
     os.makedirs(OBJDIR, exist_ok=True)
     deps = [os.path.join(HERE, "common.h"), os.path.join(HERE, "gemm_shared.h"), os.path.join(HERE, "opts.h"), os.path.join(REPO, "include", "gligen_hip.h")]
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(REPO, "include"), "-I" + HERE]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(REPO, "include"), "-I" + HERE, *["-D" + d for d in defines]]
 
     # per-file extras: attention keeps MFMA results in VGPRs (no v_accvgpr_read/write round trips in the
     # softmax, which is VALU-bound; measured 223 -> 0 AGPR moves per 64-key tile)
@@ -63,4 +68,6 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    # python -m layoutllm_t2i_amd.csrc.build [--force] [--variant NAME -DX=Y ...]
+    _v = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else ""
+    print(build(force="--force" in sys.argv, variant=_v, defines=[a[2:] for a in sys.argv if a.startswith("-D")]))

@@ -33,6 +33,10 @@
 #include "opts.h"
 #include <type_traits>
 
+#ifndef G8_S3_PHASES
+#define G8_S3_PHASES 3          // phases per stage of the three-pass loop (2 = A/B build, see ktile3)
+#endif
+
 namespace {
 
 template <int BM_, int BN>
@@ -81,9 +85,18 @@ __device__ __forceinline__ f32x4 mfma16(half8_t a, half8_t b, f32x4 c) {
 // cost of fetching operand bytes from the cost of issuing / landing LDS-DMA instructions)
 __device__ unsigned long long g8_stamps[4 * 4096];
 
-template <int BM, int BN, bool CONV, int DBG = 0>
+// S3 (round 6): the dedicated THREE-PASS main loop of the split-fp16 product x.W = xhi.Whi + xlo.Whi + xhi.Wlo (strict mode, and the
+// default mode's [hi | lo] 1x1 convs).  The K-walk form of the same product (kwrap: K = 3 * kwrap against [Whi | Whi | Wlo]) stages xhi
+// and Whi twice.  Here a ring stage holds ONE 32-wide k slice of all four operands -- every 128-byte LDS row is [hi(32) | lo(32)] of
+// its source row, so the stage has the same size, image, swizzle and LDS-DMA instruction count as a plain 64-wide K-tile, and the
+// fragment reads of "k half 0 / 1" ARE the hi / lo fragments -- and three MFMA groups are issued from it: 60 MFMAs per wave and stage
+// for the staging work of 40, every staged byte used 1.5-2 x.  Three phases per stage: [read Ahi, Whi] hi.hi, [read Alo] lo.hi,
+// [read Wlo] hi.lo.  Arguments as for the K-walk (p.kwrap = the true K; A rows [hi | lo] with lo p.kwrap columns to the right, for a
+// conv cg.Cin / 2 channels to the right; weight rows [Whi | Wlo], Wlo p.kwrap columns to the right); kt_per_split counts 32-wide tiles.
+template <int BM, int BN, bool CONV, int DBG = 0, bool S3 = false>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom cg, int splitk, int kt_per_split, int order_flags) {
     using C = G8<BM, BN>;
+    constexpr int KT = S3 ? 32 : 64;                   // k columns of the product one ring stage covers
     constexpr int NA = C::NA, MI = C::MI, MH = C::MH;
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
     if constexpr (DBG & 1) ts0 = __builtin_readcyclecounter();
@@ -95,7 +108,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2;             // N half; also the stagger group (waves w and w + 4 share a SIMD)
     const int wm = wave & 3;               // (BM / 4)-row slice of the block tile
-    const int M = p.M, N = p.N, K = p.K;
+    const int M = p.M, N = p.N, K = S3 ? p.kwrap : p.K;      // S3: the true K (p.K = 3 * kwrap describes the K-walk form)
 
     // tile order: as gemm_conv.hip (XCD-contiguous runs of logical tiles, M-tiles fastest when the weights are the larger operand)
     const int nt = (N + BN - 1) / BN;
@@ -114,7 +127,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
     const int m0 = tmi * C::BM;
     const int n0 = (order_m ? tile / mt_ : tile - tmi * nt) * BN;
     const int kt_begin = blockIdx.z * kt_per_split;
-    const int kt_end = min(K / 64, kt_begin + kt_per_split);
+    const int kt_end = min(K / KT, kt_begin + kt_per_split);
     const int nkt = kt_end - kt_begin;
 
     const half_t* __restrict__ Ag = reinterpret_cast<const half_t*>(p.a);
@@ -130,14 +143,20 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
     const half_t* aptr[NA];
     unsigned amask = 0u;
     unsigned cmask[NA];
-    const int k_first = kt_begin * 64;
+    const int k_first = kt_begin * KT;
+    // S3: logical 16-byte chunk c of a staged row is k columns 8 (c & 3) .. + 8 of the hi half (c < 4) or of the lo half (c >= 4)
+    const int a_lo = S3 ? (CONV ? (cg.Cin >> 1) : p.kwrap) : 0;
+    auto chunk_off = [&](const int c, const int lo_off) __attribute__((always_inline)) -> int {
+        if constexpr (S3) return ((c & 3) << 3) + ((c >> 2) ? lo_off : 0);
+        else return c << 3;
+    };
 #pragma unroll
     for (int u = 0; u < NA; ++u) {
         // a wave pair stages 16 * NA consecutive rows
         const int trow0 = (16 * NA) * (wave >> 1) + 16 * (wave & 1) + 8 * (u & 1) + 32 * (u >> 1);
         a_dst[u] = trow0 * 128;
         const int r = trow0 + srow;
-        const int gc = (sslot ^ ((r >> 1) & 7)) << 3;
+        const int gc = chunk_off(sslot ^ ((r >> 1) & 7), a_lo);
         const int m = m0 + r;
         const bool rowok = m < M;
         aptr[u] = zsrc; cmask[u] = 0u;
@@ -172,7 +191,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
             }
         } else {
             if (rowok) {
-                if (A2g != nullptr && k_first >= p.ksplit) aptr[u] = A2g + (size_t)m * p.lda2 + (k_first - p.ksplit) + gc;
+                if (!S3 && A2g != nullptr && k_first >= p.ksplit) aptr[u] = A2g + (size_t)m * p.lda2 + (k_first - p.ksplit) + gc;
                 else aptr[u] = Ag + (size_t)m * p.lda + k_first + gc;
                 amask |= 1u << u;
             }
@@ -186,7 +205,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
 #pragma unroll
     for (int j = 0; j < C::NB0; ++j) {
         const int r = 8 * (bunit0 + j) + srow;
-        const int gc = (sslot ^ ((r >> 1) & 7)) << 3;
+        const int gc = chunk_off(sslot ^ ((r >> 1) & 7), p.kwrap);
         const int n = n0 + r;
         const bool ok = (j < nb) && (r < BN) && (n < N);
         bptr[j] = ok ? (Wg + (size_t)n * p.ldw + gc) : zsrc;       // + the K-tile's offset at issue time (gl_conv3x3 sets ldw too)
@@ -201,8 +220,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
     int is_out = 0, is_in = 0;
     int is_cblk = 0, is_tap = 0;           // of the K-tile being issued (set by issue_begin)
     if constexpr (CONV) {
-        is_out = kt_begin / in_lim;
-        is_in = kt_begin - is_out * in_lim;
+        const int t64 = S3 ? (kt_begin >> 1) : kt_begin;       // S3: two 32-wide stages per (channel block, tap)
+        is_out = t64 / in_lim;
+        is_in = t64 - is_out * in_lim;
     }
     int is_kt = kt_begin;                  // index (in visiting order) of the K-tile the next issue refers to
 
@@ -211,7 +231,17 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
     int is_ky = 0, is_kx = 0, is_acb = 0;
     int is_boff = 0;                       // element offset of the K-tile inside a weight row
     auto issue_begin = [&]() __attribute__((always_inline)) {
-        if constexpr (CONV) {
+        if constexpr (CONV && S3) {
+            is_tap = tap_major ? is_out : is_in;
+            is_cblk = tap_major ? is_in : is_out;
+            is_ky = (is_tap * 11) >> 5;
+            is_kx = is_tap - is_ky * 3;
+            is_acb = (is_cblk << 1) + (is_kt & 1);      // in units of 32 channels: the stage's half of the channel block
+            is_off = ((is_ky - 1) * cg.Win + (is_kx - 1)) * cg.Cin + (is_acb << 5);
+            is_boff = ((is_cblk * 9 + is_tap) << 6) + ((is_kt & 1) << 5);
+        } else if constexpr (S3) {
+            is_boff = is_kt << 5;
+        } else if constexpr (CONV) {
             is_tap = tap_major ? is_out : is_in;
             is_cblk = tap_major ? is_in : is_out;
             is_ky = (is_tap * 11) >> 5;                 // tap / 3 for tap in [0, 9)
@@ -246,14 +276,14 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
                 int off = is_off;
                 if (cg.ups) {        // wave-uniform; this runs in the read section, outside the MFMA stream
                     const int ry = (is_ky - 1 + (int)((cmask[u] >> 9) & 1u)) >> 1, rx = (is_kx - 1 + (int)((cmask[u] >> 10) & 1u)) >> 1;
-                    off = (ry * cg.Win + rx) * cg.Cin + (is_acb << 6);
+                    off = (ry * cg.Win + rx) * cg.Cin + (is_acb << (S3 ? 5 : 6));
                 }
                 const uint64_t a = reinterpret_cast<uint64_t>(aptr[u] + off), z = reinterpret_cast<uint64_t>(zsrc);
                 const uint64_t keep = (uint64_t)0 - (uint64_t)((cmask[u] >> is_tap) & 1u);
                 src = reinterpret_cast<const half_t*>((a & keep) | (z & ~keep));
             } else {
                 src = aptr[u];
-                aptr[u] += ((amask >> u) & 1u) ? 64 : 0;
+                aptr[u] += ((amask >> u) & 1u) ? KT : 0;
             }
             if constexpr (DBG & 2) src = zsrc;
         } else {
@@ -276,7 +306,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
     auto issue_advance = [&]() __attribute__((always_inline)) {
         ++is_kt;
         if constexpr (CONV) {
-            if (++is_in == in_lim) { is_in = 0; ++is_out; }
+            if (!S3 || (is_kt & 1) == 0) {             // S3: the (channel block, tap) pair advances every second stage
+                if (++is_in == in_lim) { is_in = 0; ++is_out; }
+            }
         }
     };
     auto issue_all = [&](const int st) __attribute__((always_inline)) {
@@ -378,9 +410,95 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
         st_rd = (st_rd == 2) ? 0 : st_rd + 1;
         st_is = (st_is == 2) ? 0 : st_is + 1;
     };
+    // S3: one 32-wide stage = three phases [read Ahi + Whi] hi.hi | [read Alo] lo.hi | [read Wlo] hi.lo, each with the same
+    // barrier / priority / interleave structure as above; the LDS-DMA instructions of stage t+2 are spread P0 / P1 / P2 over the three
+    // MFMA clusters and the counted wait sits in the LAST phase's read section (P0 + P1 instructions of stage t+2 are then in flight
+    // behind all of stage t+1).  Hazards as above with "phase 1" read as "the last phase".
+    auto ktile3 = [&](auto more_c) __attribute__((always_inline)) {
+        constexpr bool MORE = decltype(more_c)::value;
+        constexpr int NU = NA + C::NB0;
+        // G8_S3_PHASES = 3: [Ahi Whi | hi.hi] [Alo | lo.hi] [Wlo | hi.lo];  2 (A/B build): [Ahi Alo Whi | hi.hi, lo.hi] [Wlo | hi.lo]
+        constexpr int NPH = G8_S3_PHASES;
+        constexpr int P0 = NPH == 3 ? 3 : NU - 2, P1 = NPH == 3 ? (NU - 3 + 1) / 2 : 2, P2 = NPH == 3 ? NU - 3 - P1 : 0;
+        static_assert(P0 <= 5 && P1 <= 3 && P2 <= 3 && P2 >= 0 && P0 + P1 + P2 == NU, "LDS-DMA instructions per MFMA cluster");
+        const unsigned char* rbase = smem + st_rd * C::STAGE;
+        half8_t ah[MI], al[MI], bf[TN];
+        auto phase = [&](auto ph_c) __attribute__((always_inline)) {
+            constexpr int ph = decltype(ph_c)::value;
+            constexpr bool LAST = ph == NPH - 1;
+            constexpr int first = ph == 0 ? 0 : (ph == 1 ? P0 : P0 + P1);
+            constexpr int cnt = ph == 0 ? P0 : (ph == 1 ? P1 : P2);
+            constexpr int NG = (NPH == 2 && ph == 0) ? 2 : 1;          // MFMA groups of this phase
+            constexpr int TOT = NG * NMF;
+            constexpr int GP = TOT / (cnt + 1);                         // an LDS-DMA instruction after every GP MFMAs
+            if constexpr (ph == 0) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) ah[mi] = *reinterpret_cast<const half8_t*>(rbase + (a_off + mi * 2048));
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) bf[ni] = *reinterpret_cast<const half8_t*>(rbase + (b_off + ni * 2048));
+            }
+            if constexpr ((NPH == 3 && ph == 1) || (NPH == 2 && ph == 0)) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) al[mi] = *reinterpret_cast<const half8_t*>(rbase + ((a_off ^ 64) + mi * 2048));
+            }
+            if constexpr (LAST) {
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) bf[ni] = *reinterpret_cast<const half8_t*>(rbase + ((b_off ^ 64) + ni * 2048));
+            }
+            const half_t* nsrc[5] = {zsrc, zsrc, zsrc, zsrc, zsrc};
+            if constexpr (MORE) {
+                if constexpr (ph == 0) issue_begin();
+                if constexpr (cnt > 0) nsrc[0] = unit_src(first + 0);
+                if constexpr (cnt > 1) nsrc[1] = unit_src(first + 1);
+                if constexpr (cnt > 2) nsrc[2] = unit_src(first + 2);
+                if constexpr (cnt > 3) nsrc[3] = unit_src(first + 3);
+                if constexpr (cnt > 4) nsrc[4] = unit_src(first + 4);
+            }
+            if constexpr (LAST) {
+                if constexpr (MORE) wait_vm<NU - cnt>();          // everything but this wave's stage-(t+2) instructions so far: all of stage t+1
+                else wait_vm<0>();
+            }
+            G8_SBAR();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < TOT; ++i) {
+                const int g = i / NMF, mi = (i % NMF) / TN, ni = i % TN;
+                const bool use_lo = (NPH == 3) ? (ph == 1) : (ph == 0 && g == 1);
+                acc[mi][ni] = mfma16(bf[ni], use_lo ? al[mi] : ah[mi], acc[mi][ni]);
+                if constexpr (MORE) {
+                    if constexpr (cnt > 0) { if (i == GP - 1) unit_fire(st_is, first + 0, nsrc[0]); }
+                    if constexpr (cnt > 1) { if (i == 2 * GP - 1) unit_fire(st_is, first + 1, nsrc[1]); }
+                    if constexpr (cnt > 2) { if (i == 3 * GP - 1) unit_fire(st_is, first + 2, nsrc[2]); }
+                    if constexpr (cnt > 3) { if (i == 4 * GP - 1) unit_fire(st_is, first + 3, nsrc[3]); }
+                    if constexpr (cnt > 4) { if (i == 5 * GP - 1) unit_fire(st_is, first + 4, nsrc[4]); }
+                }
+            }
+            if constexpr (MORE) {
+                if constexpr (cnt > 0) { __builtin_amdgcn_sched_group_barrier(0x008, GP, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+                if constexpr (cnt > 1) { __builtin_amdgcn_sched_group_barrier(0x008, GP, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+                if constexpr (cnt > 2) { __builtin_amdgcn_sched_group_barrier(0x008, GP, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+                if constexpr (cnt > 3) { __builtin_amdgcn_sched_group_barrier(0x008, GP, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+                if constexpr (cnt > 4) { __builtin_amdgcn_sched_group_barrier(0x008, GP, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+                __builtin_amdgcn_sched_group_barrier(0x008, TOT - cnt * GP, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            if constexpr (MORE && LAST) issue_advance();
+            G8_SBAR();
+        };
+        phase(std::integral_constant<int, 0>{});
+        phase(std::integral_constant<int, 1>{});
+        if constexpr (NPH == 3) phase(std::integral_constant<int, 2>{});
+        st_rd = (st_rd == 2) ? 0 : st_rd + 1;
+        st_is = (st_is == 2) ? 0 : st_is + 1;
+    };
     int t = 0;
-    for (; t + 2 < nkt; ++t) ktile(std::true_type{});
-    for (; t < nkt; ++t) ktile(std::false_type{});
+    if constexpr (S3) {
+        for (; t + 2 < nkt; ++t) ktile3(std::true_type{});
+        for (; t < nkt; ++t) ktile3(std::false_type{});
+    } else {
+        for (; t + 2 < nkt; ++t) ktile(std::true_type{});
+        for (; t < nkt; ++t) ktile(std::false_type{});
+    }
     if (grp == 0) G8_SBAR();               // equal barrier counts; after it no wave reads the operand stages any more
     if constexpr (DBG & 1) ts2 = __builtin_readcyclecounter();
 
@@ -519,13 +637,14 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
                         const float4 g1 = *reinterpret_cast<const float4*>(stage + r * EPS + pc + 36);
                         float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
                         float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-                        half8_t o, lo8;
+                        half8_t o, lo8 = {};
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             const float a = xv[j] + gg_bias[j], b = gv[j] + gg_bias[8 + j];
-                            const float y = pin_value(a * gelu_erf_f(b));
+                            float y = a * gelu_erf_f(b);
+                            if (p.out_mode == GL_OUT_F16_HILO) y = pin_value(y);      // hi and lo from ONE value; the default mode keeps its plain code
                             o[j] = (half_t)y;
-                            lo8[j] = (half_t)(y - (float)o[j]);
+                            if (p.out_mode == GL_OUT_F16_HILO) lo8[j] = (half_t)(y - (float)o[j]);
                         }
                         st16(outp + (size_t)m * p.ldc + (nbase >> 1) + pc, *reinterpret_cast<uint4*>(&o));
                         if (p.out_mode == GL_OUT_F16_HILO) st16(outp + (size_t)m * p.ldc + (N >> 1) + (nbase >> 1) + pc, *reinterpret_cast<uint4*>(&lo8));
@@ -562,7 +681,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
 constexpr int G8_MAX_DEVICES = 64;
 const half_t* g8_zero_page[G8_MAX_DEVICES] = {};   // per DEVICE: address of this translation unit's zero page on that device (gl8_init; __device__ symbols are per device)
 
-template <int BM, int BN, bool CONV>
+template <int BM, int BN, bool CONV, bool S3 = false>
 int launch8(const gl_gemm_args& g, const ConvGeom& cg_in, int zs, int kper, int order_m, hipStream_t st) {
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= G8_MAX_DEVICES) return GL_ERR_BAD_ARG;
@@ -572,7 +691,10 @@ int launch8(const gl_gemm_args& g, const ConvGeom& cg_in, int zs, int kper, int 
     const int mt = gl_cdiv(g.M, BM), nt = gl_cdiv(g.N, BN);
     dim3 grid(mt * nt, 1, zs);
     bool done = false;
-    if constexpr (BN == 160 && BM == 256) {
+    if constexpr (S3) {
+        gemm8_kernel<BM, BN, CONV, 0, true><<<grid, dim3(512), G8<BM, BN>::LDS, st>>>(g, cg, zs, kper, order_m);
+        done = true;
+    } else if constexpr (BN == 160 && BM == 256) {
         void (*k)(gl_gemm_args, ConvGeom, int, int, int) = nullptr;
         if (g8_dbg == 1) k = gemm8_kernel<BM, BN, CONV, 1>;
         if (g8_dbg == 3) k = gemm8_kernel<BM, BN, CONV, 3>;
@@ -589,6 +711,7 @@ int launch8(const gl_gemm_args& g, const ConvGeom& cg_in, int zs, int kper, int 
 template <int BM, int BN, bool CONV>
 int set_attr8() {
     hipError_t e = hipFuncSetAttribute((const void*)gemm8_kernel<BM, BN, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, G8<BM, BN>::LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm8_kernel<BM, BN, CONV, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G8<BM, BN>::LDS);
     if constexpr (BN == 160 && BM == 256) {
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm8_kernel<BM, BN, CONV, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, G8<BM, BN>::LDS);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm8_kernel<BM, BN, CONV, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, G8<BM, BN>::LDS);
@@ -615,12 +738,17 @@ int gl8_supported(const gl_gemm_args& g, bool conv, int* bn_out) {
 }
 
 // bm: 256, or 128 (half-height tiles: twice the blocks for grids that would leave CUs idle or split K)
-int gl8_launch(const gl_gemm_args& g, const ConvGeom& cg, bool conv, int bm, int bn, int zs, int kper, int order_m, hipStream_t st) {
-    if (bm == 256 && bn == 160) return conv ? launch8<256, 160, true>(g, cg, zs, kper, order_m, st) : launch8<256, 160, false>(g, cg, zs, kper, order_m, st);
-    if (bm == 256 && bn == 128) return conv ? launch8<256, 128, true>(g, cg, zs, kper, order_m, st) : launch8<256, 128, false>(g, cg, zs, kper, order_m, st);
-    if (bm == 128 && bn == 160) return conv ? launch8<128, 160, true>(g, cg, zs, kper, order_m, st) : launch8<128, 160, false>(g, cg, zs, kper, order_m, st);
-    if (bm == 128 && bn == 128) return conv ? launch8<128, 128, true>(g, cg, zs, kper, order_m, st) : launch8<128, 128, false>(g, cg, zs, kper, order_m, st);
+// s3: the dedicated three-pass loop (g describes the K-walk form: K = 3 * kwrap; kper counts 32-wide stages of the true K = kwrap)
+template <bool S3>
+static int gl8_launch_t(const gl_gemm_args& g, const ConvGeom& cg, bool conv, int bm, int bn, int zs, int kper, int order_m, hipStream_t st) {
+    if (bm == 256 && bn == 160) return conv ? launch8<256, 160, true, S3>(g, cg, zs, kper, order_m, st) : launch8<256, 160, false, S3>(g, cg, zs, kper, order_m, st);
+    if (bm == 256 && bn == 128) return conv ? launch8<256, 128, true, S3>(g, cg, zs, kper, order_m, st) : launch8<256, 128, false, S3>(g, cg, zs, kper, order_m, st);
+    if (bm == 128 && bn == 160) return conv ? launch8<128, 160, true, S3>(g, cg, zs, kper, order_m, st) : launch8<128, 160, false, S3>(g, cg, zs, kper, order_m, st);
+    if (bm == 128 && bn == 128) return conv ? launch8<128, 128, true, S3>(g, cg, zs, kper, order_m, st) : launch8<128, 128, false, S3>(g, cg, zs, kper, order_m, st);
     return GL_ERR_UNSUPPORTED;
+}
+int gl8_launch(const gl_gemm_args& g, const ConvGeom& cg, bool conv, int bm, int bn, int zs, int kper, int order_m, hipStream_t st, bool s3) {
+    return s3 ? gl8_launch_t<true>(g, cg, conv, bm, bn, zs, kper, order_m, st) : gl8_launch_t<false>(g, cg, conv, bm, bn, zs, kper, order_m, st);
 }
 
 int gl8_init(void) {

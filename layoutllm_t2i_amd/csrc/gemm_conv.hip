@@ -54,6 +54,7 @@ std::atomic<uint64_t> g8_launches{0};   // launches that went to the 8-wave kern
 #define g_opt_g8_shortk gl_opt(37)  // default 1: 8-wave kernel also for short-K multi-round grids that fill >= 80 % of their rounds
 #define g_opt_g8_bm128 gl_opt(46)  // default set in misc.hip: half-height (128-row) tiles of the 8-wave kernel for under-filled grids: bit 0 convs, bit 1 plain GEMMs
 #define g_opt_g8_minblk gl_opt(47)  // default 100: plain GEMMs use the 8-wave kernel from this many blocks (tiles x slices) on
+#define g_opt_g8_s3 gl_opt(52)  // default 1: three-pass split-fp16 products (K = 3 * kwrap) run the dedicated three-pass loop of the 8-wave kernel (0 = K-walk)
 #define g_opt_g8_minnk gl_opt(35)  // default 5;      // 8-wave kernel only for K >= 64 * this
 
 template <int BM, int BN, int BKT, int NW = 4>
@@ -508,14 +509,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
                         const float4 g1 = *reinterpret_cast<const float4*>(stage + r * EPS + pc + 36);
                         float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
                         float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-                        half8_t o, lo8;
+                        half8_t o, lo8 = {};
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             float a = xv[j], b = gv[j];
                             if (bias) { a += bias[nx + j]; b += bias[nx + 32 + j]; }
-                            const float y = pin_value(a * gelu_erf_f(b));
+                            float y = a * gelu_erf_f(b);
+                            if (p.out_mode == GL_OUT_F16_HILO) y = pin_value(y);      // hi and lo from ONE value; the default mode keeps its plain code
                             o[j] = (half_t)y;
-                            lo8[j] = (half_t)(y - (float)o[j]);
+                            if (p.out_mode == GL_OUT_F16_HILO) lo8[j] = (half_t)(y - (float)o[j]);
                         }
                         st16(outp + (size_t)m * p.ldc + (nbase >> 1) + pc, *reinterpret_cast<uint4*>(&o));
                         // [hi | lo] rows for a split-fp16 FeedForward output projection: lo goes N / 2 (the output width) columns to the right
@@ -851,10 +853,15 @@ int dispatch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
                 enough = nk >= 16 || blocks <= 256 || (g.epi == GL_EPI_GEGLU && (nk >= 10 || full_rounds)) || (full_rounds && blocks <= 2048);
             }
             if (g_opt_g8 == 2 || enough) {
-                const int kper = gl_cdiv(nk, splitk);
-                const int zs = gl_cdiv(nk, kper);
+                // the three-pass product xhi.Whi + xlo.Whi + xhi.Wlo in its K-walk description (K = 3 * kwrap; GEMM: the third A segment is
+                // the first one again; conv: in_split == 3) -> the dedicated three-pass loop: same slices, counted in 32-wide stages of kwrap
+                const bool s3 = g_opt_g8_s3 != 0 && g.kwrap != 0 && g.K == 3 * g.kwrap &&
+                                (CONV ? cg.cwrap != 0 : (g.a2 == g.a && g.lda2 == g.lda && g.ksplit == 2 * g.kwrap));
+                const int nks = s3 ? g.kwrap / 32 : nk;
+                const int kper = gl_cdiv(nks, splitk);
+                const int zs = gl_cdiv(nks, kper);
                 const int order_m = g_opt_order == 1 ? ((CONV ? 9L : 1L) * g.N > (long)g.M) : (g_opt_order == 2);
-                const int e = gl8_launch(g, cg, CONV, bm, bn, zs, kper, order_m | (CONV && g_opt_g8_tapmajor ? 2 : 0), st);
+                const int e = gl8_launch(g, cg, CONV, bm, bn, zs, kper, order_m | (CONV && g_opt_g8_tapmajor ? 2 : 0), st, s3);
                 if (e) return e;
                 g8_launches.fetch_add(1, std::memory_order_relaxed);
                 if (zs > 1) {

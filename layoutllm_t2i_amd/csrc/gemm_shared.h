@@ -128,6 +128,7 @@ __device__ __forceinline__ void finish8(const gl_gemm_args& p, float gate, int m
 // Returns < 0 (GL_ERR_UNSUPPORTED) when the problem is outside what it implements; the caller then uses the 4-wave kernels.
 // zs > 1: fp32 partial tiles go to g.workspace[z][M][N] and the caller runs the reduction.
 int gl8_supported(const gl_gemm_args& g, bool conv, int* bn_out);
-int gl8_launch(const gl_gemm_args& g, const ConvGeom& cg, bool conv, int bm, int bn, int zs, int kper, int order_m, hipStream_t st);
+// s3: the dedicated three-pass main loop for the split-fp16 product (g in its K-walk form, K = 3 * kwrap; kper in 32-wide stages of kwrap)
+int gl8_launch(const gl_gemm_args& g, const ConvGeom& cg, bool conv, int bm, int bn, int zs, int kper, int order_m, hipStream_t st, bool s3 = false);
 int gl8_init(void);
 int gl8_read_stamps(void* dst, int64_t bytes);

@@ -309,6 +309,7 @@ static gl_opts make_default_opts() {
     o.v[47] = 100;
     o.v[50] = 0;       // strict mode (handles created with split_weights)
     o.v[51] = 1;       // ... with the third pass x.Wlo
+    o.v[52] = 1;       // three-pass products on the dedicated three-pass loop of the 8-wave kernel (gemm8.hip S3; 0 = K-walk)
     return o;
 }
 gl_opts g_gl_opts = make_default_opts();
@@ -318,7 +319,7 @@ int g_gl_option_epoch = 0;
 bool gl_opts_store(gl_opts& t, int key, int value) {
     switch (key) {
         case 2: case 3: case 4: case 6: case 7: case 8: case 10: case 13: case 17: case 20: case 21: case 23: case 24: case 25:
-        case 27: case 29: case 30: case 31: case 32: case 33: case 35: case 37: case 38: case 41: case 42: case 43: case 44: case 45: case 46: case 47: case 50: case 51:
+        case 27: case 29: case 30: case 31: case 32: case 33: case 35: case 37: case 38: case 41: case 42: case 43: case 44: case 45: case 46: case 47: case 50: case 51: case 52: case 53:
             t.v[key] = value;
             return true;
         case 5:                                  // < 0: the built-in thresholds (plain GEMM 300 tiles, conv 450)

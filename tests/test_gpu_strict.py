@@ -164,6 +164,97 @@ def test_conv3x3_split_input_and_weight(mode, Cin, Cout, hw, force8):
     assert r2 < 2e-6 and r2w < 2e-6 and r3 < 2e-6 and abs(r1 - r1w) < 1e-6 and r1 > 20 * r2
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(8192, 320, 320, "res"), (33000, 320, 320, "res"), (32768, 960, 320, "hilo"), (8192, 2560, 320, "geglu"),
+                                       (8192, 640, 2560, "res"), (2048, 1280, 1280, "res"), (2048, 1280, 5120, "res"), (512, 1280, 2560, "res"),
+                                       (300, 320, 320, "res"), (4500, 1920, 640, "hilo")])
+def test_gemm_three_pass_loop_vs_kwalk(M, N, K, epi):
+    """Option 52: the dedicated three-pass main loop of the 8-wave kernel (one 32-wide slice of {xhi, xlo, Whi, Wlo} per ring stage, three
+    MFMA groups) against the K-walk over [xhi | xlo | xhi] x [Whi | Whi | Wlo] it replaces and against the fp64 product of the unrounded
+    operands: same products, other fp32 summation order.  Shapes: multi-round, ragged last tile, half-height tiles, split-K, every epilogue
+    the strict forward uses (fp32 residual stream, [hi | lo] rows, GEGLU + [hi | lo])."""
+    x = rnd(f"ta{M}{K}", (M, K)) * 1.7 + 0.4
+    w = rnd(f"tw{N}{K}", (N, K), 1 / math.sqrt(K))
+    b = rnd(f"tb{N}", (N,), 0.1)
+    if epi == "geglu":
+        wq, bq = geglu_interleave(w), geglu_interleave(b)
+    else:
+        wq, bq = w, b
+    hi, lo = split(x)
+    whi, wlo = split(wq)
+    a = torch.cat([hi, lo], 1).to(DEV)
+    w2 = torch.cat([whi, wlo], 1).contiguous().to(DEV)
+    outs = []
+    ops.set_option(30, 2)
+    try:
+        for key in (1, 0):
+            ops.set_option(52, key)
+            n0 = ops.gemm8_launch_count()
+            if epi == "res":
+                r = rnd(f"tr{M}{N}", (M, N))
+                o = torch.empty(M, N, dtype=torch.float32, device=DEV)
+                ops.gemm(a, w2, o, bq.to(DEV), EPI_RES, res=r.to(DEV), hilo_a=True, wsplit=2)
+                got = o.cpu()
+                ref = F.linear(x.double(), w.double(), b.double()) + r.double()
+            elif epi == "hilo":
+                o = torch.empty(M, 2 * N, dtype=torch.float16, device=DEV)
+                ops.gemm(a, w2, o, bq.to(DEV), EPI_BIAS, hilo_a=True, wsplit=2, hilo_out=True)
+                got = o[:, :N].float().cpu() + o[:, N:].float().cpu()
+                ref = F.linear(x.double(), w.double(), b.double())
+            else:
+                o = torch.empty(M, N, dtype=torch.float16, device=DEV)
+                ops.gemm(a, w2, o, bq.to(DEV), EPI_GEGLU, hilo_a=True, wsplit=2, hilo_out=True)
+                got = o[:, :N // 2].float().cpu() + o[:, N // 2:].float().cpu()
+                y = F.linear(x.double(), w.double(), b.double())
+                ref = y[:, :N // 2] * F.gelu(y[:, N // 2:])
+            if M >= 256:
+                assert ops.gemm8_launch_count() == n0 + 1, "the 8-wave kernel was not used"
+            outs.append((got, rel(got, ref)))
+    finally:
+        ops.set_option(52, 1)
+        ops.set_option(30, 1)
+    (g3, e3), (gk, ek) = outs
+    d = rel(g3, gk)
+    print(f"[three-pass loop {M}x{N}x{K} {epi}] vs fp64: loop {e3:.2e}, K-walk {ek:.2e}; loop vs K-walk {d:.2e}")
+    bound = 2e-6 if epi == "res" else 4e-6          # [hi | lo] fp16 rows carry ~2^-22 of their own
+    assert e3 < bound and ek < bound and d < bound
+
+
+@pytest.mark.parametrize("mode,Cin,Cout,hw,B", [("s1", 320, 320, 64, 2), ("s1", 640, 640, 32, 8), ("s1", 1280, 1280, 8, 8), ("s1", 2560, 1280, 16, 4),
+                                                ("s2", 320, 320, 64, 2), ("up", 1280, 1280, 16, 4), ("s1", 192, 64, 12, 2), ("s1", 960, 320, 24, 3)])
+def test_conv_three_pass_loop_vs_kwalk(mode, Cin, Cout, hw, B):
+    """Option 52 for gl_conv3x3 in_split = 3: dedicated three-pass loop vs the K-walk vs the fp64 conv of the unrounded operands
+    (full-chip grids, split-K slices with odd stage counts, half-height tiles, stride 2, nearest-2x, non-power-of-two maps)."""
+    stride, ups = (2 if mode == "s2" else 1), mode == "up"
+    x = rnd(f"tcx{Cin}{hw}{B}", (B * hw * hw, Cin)) * 1.3 + 0.2
+    xh, xl = split(x)
+    w32 = rnd(f"tcw{Cin}{Cout}", (Cout, Cin, 3, 3), 1 / math.sqrt(9 * Cin))
+    whi = w32.half().float()
+    wlo = (w32 - whi).half().float()
+    b = rnd(f"tcb{Cout}", (Cout,), 0.1)
+    xs = torch.cat([xh, xl], 1).contiguous().to(DEV)
+    ho = 2 * hw if ups else (hw + 2 - 3) // stride + 1
+    wp = torch.cat([pack_conv3x3(whi), pack_conv3x3(wlo)], 1).contiguous().to(DEV)
+    want = conv_ref64(x, w32, b, B, hw, hw, stride, ups)
+    outs = []
+    ops.set_option(30, 2)
+    try:
+        for key in (1, 0):
+            ops.set_option(52, key)
+            out = torch.empty(B * ho * ho, Cout, dtype=torch.float32, device=DEV)
+            n0 = ops.gemm8_launch_count()
+            ops.conv3x3(xs, wp, out, B, hw, hw, b.to(DEV), stride=stride, upsample2x=ups, in_split=3, w_split=True)
+            assert ops.gemm8_launch_count() == n0 + 1, "the 8-wave kernel was not used"
+            outs.append((out.cpu(), rel(out, want)))
+    finally:
+        ops.set_option(52, 1)
+        ops.set_option(30, 1)
+    (g3, e3), (gk, ek) = outs
+    d = rel(g3, gk)
+    print(f"[three-pass conv {mode} {Cin}->{Cout} @{hw} B{B}] vs fp64: loop {e3:.2e}, K-walk {ek:.2e}; loop vs K-walk {d:.2e}")
+    bound = 4e-6           # fp32 accumulation over K = 9 Cin >= 11520 terms (both forms measure 2.0-2.7e-6 from Cin = 1280 on; single fp16: 3e-4)
+    assert e3 < bound and ek < bound and d < bound
+
+
 def test_conv3x3_split_nchw_out_conv():
     """the UNet's last conv (N = 4 -> fp32 NCHW store, 4-wave kernel) with a split input and split weights"""
     B, hw, Cin, Cout = 2, 16, 320, 4
@@ -184,7 +275,11 @@ def test_conv3x3_split_nchw_out_conv():
 
 # ------------------------------------------------------------------------------------------- split attention
 @pytest.mark.parametrize("d,H,Nq,Nk,B", [(40, 8, 256, 256, 2), (40, 8, 300, 286, 1), (80, 8, 128, 77, 2), (160, 8, 64, 94, 2), (160, 8, 256, 256, 1),
-                                         (16, 4, 256, 286, 1), (64, 2, 130, 10, 1)])
+                                         (16, 4, 256, 286, 1), (64, 2, 130, 10, 1),
+                                         # Nq >= 512 at d = 32 / 40 / 48: the software-pipelined kernel (round 6): whole tiles, ragged query and key
+                                         # ranges, one / two / many key tiles, the 77-key text context, the fuser's N + 30 keys
+                                         (40, 8, 1024, 1024, 1), (40, 2, 640, 700, 2), (32, 4, 512, 130, 1), (48, 2, 512, 64, 1), (40, 1, 520, 77, 1),
+                                         (40, 8, 4096, 4126, 1), (48, 3, 777, 1000, 1), (32, 2, 1024, 33, 2)])
 def test_split_attention(d, H, Nq, Nk, B):
     """gl_attention with q_lo / k_lo / vt_lo: three-pass QK^T and P.V on hi + lo operands vs fp64 attention of the unrounded q, k, v;
     out_lo holds the residual of the output."""

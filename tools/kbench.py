@@ -23,6 +23,7 @@ DEV = "cuda:0"
 B2 = int(os.environ.get("KB_B2", "8"))
 SIDE = int(os.environ.get("KB_SIDE", "64"))
 ITERS = int(os.environ.get("KB_ITERS", "20"))
+STRICT = bool(int(os.environ.get("KB_STRICT", "0")))    # the strict mode's operand forms: [hi | lo] activations, [Whi | Wlo] weights, three passes
 
 
 def timeit(fn, iters=ITERS):
@@ -167,7 +168,20 @@ def main():
             fuser = len(key) > 4
             a, w = h(M, K), h(N, K) * (K ** -0.5)
             bias = torch.zeros(N, device=DEV)
-            if epi == "geglu":
+            if STRICT:
+                # the engine's strict forms: A rows [hi | lo], weight rows [Whi | Wlo], three passes; projections write [hi | lo] rows,
+                # residual projections the fp32 stream
+                a, w = h(M, 2 * K), h(N, 2 * K) * (K ** -0.5)
+                if epi == "geglu":
+                    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+                    fn = lambda: ops.gemm(a, w, out, bias, EPI_GEGLU, hilo_a=True, wsplit=2, hilo_out=True)
+                elif epi == "res":
+                    out, r = torch.empty(M, N, dtype=torch.float32, device=DEV), torch.randn(M, N, device=DEV)
+                    fn = lambda: ops.gemm(a, w, out, bias, EPI_RES, res=r, hilo_a=True, wsplit=2)
+                else:
+                    out = torch.empty(M, 2 * N, dtype=torch.float16, device=DEV)
+                    fn = lambda: ops.gemm(a, w, out, bias, hilo_a=True, wsplit=2, hilo_out=True)
+            elif epi == "geglu":
                 out = torch.empty(M, N // 2, dtype=torch.float16, device=DEV)
                 fn = lambda: ops.gemm(a, w, out, bias, EPI_GEGLU)
             elif epi == "res":
@@ -193,6 +207,10 @@ def main():
             out = torch.empty(B2 * ho * ho, cout, dtype=torch.float16, device=DEV)
             bias = torch.zeros(cout, device=DEV)
             fn = lambda: ops.conv3x3(x, w, out, B2, side, side, bias, stride=stride, upsample2x=bool(up))
+            if STRICT:
+                x, w = h(B2 * side * side, 2 * cin), h(cout, 18 * cin) * ((9 * cin) ** -0.5)
+                out = torch.empty(B2 * ho * ho, cout, dtype=torch.float32, device=DEV)
+                fn = lambda: ops.conv3x3(x, w, out, B2, side, side, bias, stride=stride, upsample2x=bool(up), in_split=3, w_split=True)
             t = timeit(fn)
             fl = 2.0 * B2 * ho * ho * cout * 9 * cin
             tc += t * n
@@ -211,6 +229,10 @@ def main():
             out = torch.empty(B2, Nq, C, dtype=torch.float16, device=DEV)
             pre = bool(int(os.environ.get("KB_PRE", "1")))      # the engine's form: scale folded into q
             fn = lambda: ops.attention(q, Nq * C, C, k, Nk * C, C, vt, out, Nq * C, C, B2, H, d, Nq, Nk, d ** -0.5, q_prescaled=pre)
+            if STRICT:
+                ql, kl, vtl, outl = q * 1e-3, k * 1e-3, vt * 1e-3, torch.empty_like(out)
+                fn = lambda: ops.attention(q, Nq * C, C, k, Nk * C, C, vt, out, Nq * C, C, B2, H, d, Nq, Nk, d ** -0.5, q_prescaled=pre,
+                                           q_lo=ql, k_lo=kl, vt_lo=vtl, out_lo=outl)
             t = timeit(fn)
             tt = timeit(lambda: ops.transpose_v(v, Nk * C, C, vt, B2, H, d, Nk))
             fl = 4.0 * B2 * H * Nq * Nk * d

@@ -6,14 +6,27 @@ import sys
 
 path = sys.argv[1]
 nf = float(sys.argv[2]) if len(sys.argv) > 2 else 104.0
-classes = [("8-wave conv (gemm8<.,true>)", lambda n: "gemm8_kernel" in n and ", true" in n),
+import re
+
+
+def g8(n, conv, s3):
+    """gemm8_kernel<BM, BN, CONV, DBG[, S3]>: the conv flag is the THIRD template argument, the three-pass loop the fifth (round 6)"""
+    m = re.search(r"gemm8_kernel<(\d+), (\d+), (true|false), (\d+)(?:, (true|false))?>", n)
+    return bool(m) and (m.group(3) == "true") == conv and ((m.group(5) or "false") == "true") == s3
+
+
+classes = [("8-wave conv, three-pass loop", lambda n: g8(n, True, True)),
+           ("8-wave GEMM, three-pass loop", lambda n: g8(n, False, True)),
+           ("8-wave conv (gemm8<.,true>)", lambda n: g8(n, True, False)),
            ("8-wave GEMM (gemm8<.,false>)", lambda n: "gemm8_kernel" in n),
            ("4-wave conv", lambda n: "gemm_kernel<" in n and ", true," in n),
            ("4-wave GEMM", lambda n: "gemm_kernel<" in n),
            ("skinny GEMM", lambda n: "gemm_skinny" in n),
            ("split-K reduce", lambda n: "splitk_reduce" in n),
            ("fused FeedForward", lambda n: "ff_fused" in n),
+           ("split-fp16 attention (strict)", lambda n: "attn_split" in n),
            ("attention", lambda n: "attn_kernel" in n or "transpose_v" in n or "attention_small" in n),
+           ("split_f32 (strict)", lambda n: "split_f32" in n),
            ("GroupNorm", lambda n: "gn_" in n),
            ("LayerNorm", lambda n: "layernorm" in n),
            ("relation cross-attention", lambda n: "rela_" in n),
