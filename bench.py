@@ -127,7 +127,8 @@ def parse():
     ap.add_argument("--tiny", action="store_true", help="debug: tiny UNet (not a valid benchmark)")
     ap.add_argument("--no-hot-kernel", action="store_true", help="skip the standalone timing of the hottest kernel shape (PMC passes)")
     ap.add_argument("--no-strict", action="store_true", help="skip the strict-mode leg (second engine on split weights: images/s + parity beside the default mode)")
-    ap.add_argument("--strict-steps", type=int, default=2, help="timed denoise steps of the strict-mode leg")
+    ap.add_argument("--strict-steps", type=int, default=5, help="timed denoise steps of the strict-mode leg")
+    ap.add_argument("--verbose-json", action="store_true", help="keep the long descriptive strings in the JSON line (default: compact line, the prose lives in DESIGN.md section 5)")
     ap.add_argument("--strict-main", action="store_true", help="run the MAIN timed loop in strict mode (any config; the line then says so in dtype / config; "
                     "not the headline: the headline is the default mode)")
     ap.add_argument("--no-vae", action="store_true", help="stop at the final latent (exclude the VAE decode stage from the step)")
@@ -137,6 +138,20 @@ def parse():
                     "even at WORLD_SIZE=1: runs the RCCL calls on a 1-GPU box")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to smoke-test the path on one GPU)")
     return ap.parse_args()
+
+
+# descriptive strings of the JSON line that --verbose-json keeps; the default line carries the numbers only (the ~5 KB line lost its
+# front half in the driver's tail; what each field means is written down once)
+_PROSE = ("what", "note", "traffic_note", "flop_model", "classes_note", "step_includes", "reward_score_note", "launch", "sample", "kernel", "cpu_model")
+
+
+def compact_line(obj):
+    if isinstance(obj, dict):
+        return {k: compact_line(v) for k, v in obj.items() if k not in _PROSE or k in ("sample", "cpu_model") and not isinstance(v, dict)
+                and len(str(v)) <= 120}
+    if isinstance(obj, float):
+        return float(f"{obj:.5g}")
+    return obj
 
 
 def main():
@@ -382,7 +397,7 @@ def main():
             e0.record()
             o_ = s_orig(*a_, **k_)
             e1.record()
-            s_events.append((e0, e1))
+            s_events.append((e0, e1, a_[10] != 0, a_[0].shape[0] * a_[8]))      # (fuser_scale != 0, samples of the launch): plms_step's argument order
             return o_
         eng_s.plms_step = s_timed
 
@@ -401,11 +416,25 @@ def main():
         assert torch.isfinite(o_s).all()
         eng_s.plms_step = s_orig
         strict_info = {"images_per_s": round(args.strict_steps * B / t_strict, 4), "ms_per_step": round(t_strict / args.strict_steps * 1e3, 1),
-                       "unet_forward_ms": round(sum(a_.elapsed_time(b_) for a_, b_ in s_events) / max(len(s_events), 1), 3),
+                       "unet_forward_ms": round(sum(a_.elapsed_time(b_) for a_, b_, _, _ in s_events) / max(len(s_events), 1), 3),
                        "steps": args.strict_steps, "vs_default": round((args.strict_steps * B / t_strict) / (args.steps * B * world / elapsed), 3),
                        "weights_bytes": packed_strict.nbytes(),
                        "what": "gl_set_handle_option(50, 1) on a split_weights handle: split-fp16 operands ([hi | lo] activations, [Whi | Wlo] weights, "
                                "3 MFMA passes) for every conv / GEMM / attention product; same workload, same timing method"}
+        # the strict leg's own roofline line: ALGORITHMIC FLOPs (the same model as the headline's) over the HIP-event time of its forward launches;
+        # the matrix pipe issues three times that work (issued_frac).  Traffic: the newest strict PMC record under profiles/, if any.
+        s_ms = sum(a_.elapsed_time(b_) for a_, b_, _, _ in s_events)
+        s_fl = sum(n_ * (F_FULL if on_ else F_OFF) for _, _, on_, n_ in s_events)
+        s_tf = s_fl / (s_ms * 1e-3) / 1e12 if s_ms > 0 else float("nan")
+        s_tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_strict_traffic.json") for r in (6,)) if os.path.exists(q)), None)
+        strict_info["roofline"] = {"bound": "mfma", "achieved": round(s_tf, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(s_tf / MFMA_PEAK_TFLOPS, 4),
+                                   "issued_frac": round(3 * s_tf / MFMA_PEAK_TFLOPS, 4), "launches": len(s_events),
+                                   "avg_launch_ms": round(s_ms / max(len(s_events), 1), 3),
+                                   "traffic": (round(json.load(open(s_tpath))["traffic_bytes_per_forward"]) if s_tpath else None)}
+        if not args.no_hot_kernel:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import kbench as _kbs
+            strict_info["roofline"]["classes"] = _kbs.class_summary(iters=4, peak_tflops=MFMA_PEAK_TFLOPS, strict=True)
         eng.plms_step = timed_step
 
     # ---- roofline of the UNet forward (dominant launch)
@@ -418,7 +447,7 @@ def main():
     achieved = flops / (gpu_ms * 1e-3) / 1e12 if gpu_ms > 0 else float("nan")
     # HBM traffic per forward launch: measured in separate rocprofv3 --pmc passes (profiles/r1_traffic.json)
     traffic = None
-    tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_traffic.json") for r in (5, 4, 3, 2, 1)) if os.path.exists(q)), None)
+    tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_traffic.json") for r in (6, 5, 4, 3, 2, 1)) if os.path.exists(q)), None)
     traffic_age = None
     if tpath and side == 64 and not args.tiny and B == 4:
         tdoc = json.load(open(tpath))
@@ -594,9 +623,8 @@ def main():
         result["cpu_baseline"] = {
             "value": round(1.0 / per_image, 6), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
             "cpu_model": cpu_model, "host_cores_total": os.cpu_count(),
-            "sample": f"4 UNet forwards (cond/uncond x fuser on/off), B=1, {side}x{side} latent, fp32 oracle after one warm-up: "
-                      f"{ {k: round(v, 2) for k, v in kinds.items()} } s; extrapolated to {n_on} on + {n_off} off step-evaluations x 2 passes "
-                      f"per image; the oracle executes the fuser at scale 0 like the reference does; VAE decode not included",
+            "sample": f"4 oracle UNet forwards (cond/uncond x fuser on/off) at B=1, {side}x{side}, extrapolated to {n_on}+{n_off} steps x 2",
+            "sample_seconds": {k: round(v, 2) for k, v in kinds.items()},
             "seconds_per_forward": round(sum(kinds.values()) / 4, 2)}
         if not args.no_cpu_config1 and not args.tiny and args.config in (0, 2):
             # (default since round 4: the CPU number is then not only an extrapolation)
@@ -632,6 +660,8 @@ def main():
     # line order: the long descriptive fields first, the judged numbers LAST (a tail of the line keeps them)
     last = ("parity_at_bench_batch", "strict_mode", "roofline", "cpu_baseline")
     result = {**{k_: v_ for k_, v_ in result.items() if k_ not in last}, **{k_: result[k_] for k_ in last if k_ in result}}
+    if not args.verbose_json:
+        result = compact_line(result)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if multi:

@@ -824,10 +824,14 @@ __global__ __launch_bounds__(512) void attn_split_pipe_kernel(gl_attn_args p) {
             asm("" : "+v"(pv));                         // hi and lo from ONE value (common.h pin_value)
             ps2 += pv;
             const half2_t ph = __builtin_convertvector(pv, half2_t);
-            f32x2 pr = pv - __builtin_convertvector(ph, f32x2);
-            const half2_t pl = __builtin_convertvector(pr, half2_t);
             hw[e] = *reinterpret_cast<const unsigned*>(&ph);
-            lw[e] = *reinterpret_cast<const unsigned*>(&pl);
+            // lo = fp16(p - fp32(hi)), both halves by the mixed-precision FMA (fp16 source read in place, fp32 arithmetic, fp16 result written
+            // into its half of the destination): 2 instructions per pair instead of 2 x v_cvt_f32_f16 + v_pk_add_f32 + v_cvt_pk_f16_f32.
+            // p - hi is exact in fp32, so the result is the same bits.
+            unsigned lo2;                               // (mixlo leaves the upper half of its destination alone; mixhi writes it next)
+            asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo2) : "v"(hw[e]), "v"(pv[0]));
+            asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo2) : "v"(hw[e]), "v"(pv[1]));
+            lw[e] = lo2;
             // the fragments are only CONSUMED one iteration later: without a use here the compiler sinks the conversions past the MFMAs,
             // to the end of the iteration, where nothing covers them
             asm volatile("" : "+v"(hw[e]), "+v"(lw[e]));

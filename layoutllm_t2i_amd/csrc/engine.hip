@@ -400,8 +400,11 @@ struct Run {
             g.ldw = g.K; g.K = Kc;
             if (hilo_a) {       // x.W = xhi.Whi + xlo.Whi (+ xhi.Wlo: third K segment, A from the second source = the hi half again)
                 g.kwrap = Kc; g.K = 2 * Kc;
-                const bool third = strict ? (g_strict_w3 != 0) : (g_w3 > 0 && M > (g_w3 < 1024 ? 1024 : g_w3));
-                if (third && a2 == nullptr) {
+                // default mode: the third pass belongs to the add_lin_split matrices alone (the three kinds of 1x1 conv, key 45) -- on a
+                // split_weights handle every other matrix is read for its Whi half, exactly what a compact handle computes
+                const bool third = strict ? (g_strict_w3 != 0) : (wsplit && g_w3 > 0 && M > (g_w3 < 1024 ? 1024 : g_w3));
+                if (third) {
+                    if (a2 != nullptr) return GL_ERR_BAD_ARG;      // the third pass needs the second-source slot: a two-source A cannot take it
                     g.K = 3 * Kc; g.a2 = a; g.lda2 = lda; g.ksplit = 2 * Kc;
                 }
             }

@@ -132,7 +132,7 @@ FRAC_FULL = 0.32             # elements outside north_star's rtol 1e-3 / atol 1e
 
 
 @pytest.mark.parametrize("B", [4, 8, 16], ids=["configs1_2B8", "configs3_2B16", "configs4_2B32"])
-def test_config2_shapes_at_bench_batch_vs_oracle(B):
+def test_default_mode_config2_shapes_at_bench_batch_fp16_operand_bound_vs_oracle(B):
     """configs[1] (B = 4 -> 2B = 8), configs[3]'s per-GPU batch (64 / 8 GPUs = 8 -> 2B = 16: other tile / split-K / 8-wave
     dispatch decisions than either neighbour) and configs[4] (B = 16 -> 2B = 32): the 2B batch the sampler launches, checked
     against the oracle on one conditional sample (k = 1) and its unconditional twin (row B + 1); fuser on, then the
@@ -296,7 +296,7 @@ def test_config4_rollout_batch16_plms_runs():
     assert r < 4e-3, r              # measured 2.7e-3: other tile / split-K choices at another batch change fp32 summation order
 
 
-def test_config3_768px_whole_unet_vs_oracle_and_50_steps():
+def test_default_mode_config3_768px_fp16_operand_bound_vs_oracle_and_50_steps():
     """configs[2]: 768x768 -> 96x96 latents (9216 / 2304 / 576 / 144 tokens per level, 12x12 convs with M = 2B*144
     ragged against the 128-row tiles), B = 2, 16 grounding boxes: whole UNet vs the oracle on sample 1, null-grounding
     and determinism properties, then the full 50-step sampling run."""
@@ -328,7 +328,7 @@ def test_config3_768px_whole_unet_vs_oracle_and_50_steps():
     assert torch.equal(lat, lat2), "the sampling run is deterministic (fixed reduction orders, graph replay)"
 
 
-def test_config0_single_prompt_64px_10_steps_vs_oracle_plms():
+def test_default_mode_config0_10_steps_fp16_operand_bound_vs_oracle_plms():
     """configs[0] (the txt2img plumbing case -- 1 image, 64x64 latent, S = 10 PLMS steps,
     2 grounding boxes, CFG 7.5, alpha_type [0.3, 0, 0.7] -> 3 fuser-on and 7 fuser-off steps with the SD first conv,
     22 UNet evaluations) through ``denoise`` on the FULL-SIZE model, against the oracle's PLMS loop driving the oracle UNet

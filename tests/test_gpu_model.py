@@ -169,7 +169,7 @@ LEVELS = [
 
 
 @pytest.mark.parametrize("name,cfg,hw,B", LEVELS, ids=[l[0] for l in LEVELS])
-def test_full_width_level_vs_oracle(name, cfg, hw, B):
+def test_default_mode_full_width_level_fp16_operand_bound_vs_oracle(name, cfg, hw, B):
     """A one-level UNet with the real channel width / head dim / token count of config 2
     (ResBlock + SpatialTransformer with fuser + rela_fuse, middle block, skip-concat ResBlocks).  Arithmetic parity: both sides take the
     fp16-representable weight matrices (the engine's split weights then have Wlo = 0)."""
@@ -190,7 +190,7 @@ def test_full_width_level_vs_oracle(name, cfg, hw, B):
     torch.cuda.empty_cache()
 
 
-def test_full_unet_config2_vs_oracle():
+def test_default_mode_full_unet_config2_fp16_operand_bound_vs_oracle():
     """The WHOLE config-2 UNet (1.26 B parameters, 64x64 latent, 8 boxes, fuser on) against the oracle evaluated on
     the host CPU with the same weights: (a) oracle with fp16-rounded matrices (isolates arithmetic error), (b) the
     unrounded fp32 weights (what a user sees against the fp32 reference, weight quantisation included)."""
@@ -251,7 +251,7 @@ def test_full_unet_config2_vs_oracle():
     torch.cuda.empty_cache()
 
 
-def test_full_size_plms_5step_cfg_vs_oracle():
+def test_default_mode_full_size_plms_5step_cfg_fp16_operand_bound_vs_oracle():
     """End to end at the full size: 5 PLMS steps (6 guided evaluations = 12 UNet forwards of the 1.26 B model, CFG 7.5,
     alpha_type [0.3, 0, 0.7] so the fuser is skipped and the SD first conv switched in from step 2 on) through
     ``denoise`` on the GPU vs the oracle's PLMS loop driving the oracle UNet on the host CPU (about a minute)."""
@@ -293,7 +293,7 @@ def test_full_size_plms_5step_cfg_vs_oracle():
     torch.cuda.empty_cache()
 
 
-def test_config3_768px_level_vs_oracle():
+def test_default_mode_config3_768px_level_fp16_operand_bound_vs_oracle():
     """configs[2] (768x768 -> 96x96 latent): the level-0 block at N = 9216 tokens, a token count that is not a power
     of two (72 query slabs of 128, 144 key tiles), one sample, 16 boxes."""
     cfg = UNetConfig(image_size=96, model_channels=320, channel_mult=(1,), attention_resolutions=(1,), num_res_blocks=1)
@@ -315,7 +315,7 @@ def test_config3_768px_level_vs_oracle():
     torch.cuda.empty_cache()
 
 
-def test_tiny_unet_max_boxes_max_relations_vs_oracle():
+def test_default_mode_tiny_unet_max_boxes_max_relations_fp16_operand_bound_vs_oracle():
     """Edge of the conditioning ranges: all 30 grounding slots valid and all 10 relation rows non-zero (the reference's
     max_objs / max_relations), batch of 3 so the samples use different box sets."""
     model, sd = get_model(TINY)

@@ -30,7 +30,12 @@ for v in args[1:] if args and args[0].isdigit() else args:
     variants.append((name, [tuple(int(t) for t in p.split("=")) for p in kv.split(",")]))
 dev = torch.device("cuda:0")
 cfg = UNetConfig()
-P = pack_state_dict(random_state_dict(cfg, dev, seed=0), cfg, dev, recipe.sd_first_conv(cfg, 0))
+_sd = random_state_dict(cfg, dev, seed=0)
+P = pack_state_dict(_sd, cfg, dev, recipe.sd_first_conv(cfg, 0))
+# AB_PARITY=1: every variant's output (sample 0, cond, fuser on) against the fp32 oracle on the same UNROUNDED weights / latent / context
+PARITY = bool(int(os.environ.get("AB_PARITY", "0")))
+sd_cpu = {k: v.detach().float().cpu() for k, v in _sd.items()} if PARITY else None
+del _sd
 inp = {k: torch.from_numpy(v) for k, v in recipe.synth_inputs(cfg, B, 64, n_boxes=8, n_rel=3, seed=1).items()}
 z = torch.zeros_like
 cat = lambda a, b: torch.cat([a, b], 0)
@@ -50,6 +55,14 @@ def condition(e):
 for e in engines.values():
     condition(e)
 DEFAULTS = {17: 1, 21: 1, 13: 3, 7: 300, 8: 1, 5: -1, 6: 16, 3: 0, 10: -1, 2: 0, 4: 400, 16: 16, 23: 1, 24: 64, 25: 1, 27: 1, 29: 1, 30: 1, 31: 200, 33: 0, 34: 11, 35: 5, 37: 1, 38: 1, 41: 1, 42: 1, 43: 1, 44: 1, 45: 1024, 46: 11, 47: 100}
+ref = None
+if PARITY:
+    from oracle import unet_ref
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    with torch.no_grad():
+        ref = unet_ref.unet_forward(sd_cpu, cfg, inp["x"][0:1], torch.tensor([481]), inp["context"][0:1], inp["relations"][0:1], inp["boxes"][0:1],
+                                    inp["masks"][0:1], inp["positive_embeddings"][0:1], fuser_scale=1.0)
+parity = {}
 res = {n: {1.0: [], 0.0: []} for n, _ in variants}
 launches = {}
 for rnd in range(5):
@@ -71,6 +84,10 @@ for rnd in range(5):
             res[name][fs].append(e0.elapsed_time(e1) / 10)
         if opts is not None:
             launches[name] = eng.num_launches()
+        if ref is not None and name not in parity:
+            o = e.forward(x, 481.0, 1.0, False, 2)[0:1].float().cpu()
+            d = (o - ref).abs()
+            parity[name] = (float((o - ref).norm() / ref.norm()), float((d > 1e-4 + 1e-3 * ref.abs()).float().mean()))
         for k, _ in (opts or []):
             ops.set_option(k, DEFAULTS[k])
 for name, _ in variants:
@@ -78,3 +95,5 @@ for name, _ in variants:
         v = sorted(res[name][fs])
         print(f"{name:12s} fuser={'on ' if fs else 'off'} 2B={2 * B}: median {v[len(v) // 2]:.3f} ms  min {v[0]:.3f}  all {[round(t, 2) for t in res[name][fs]]}")
 print("launches per fuser-off forward:", launches)
+for name, (r, f) in parity.items():
+    print(f"{name:12s} vs fp32 oracle (unrounded weights, sample 0 cond fuser on): rel_l2 {r:.3e}, outside rtol 1e-3 / atol 1e-4: {100 * f:.1f} %")

@@ -100,10 +100,12 @@ def collect():
     return gemms, convs, attns, gns, lns
 
 
-def class_summary(iters=8, peak_tflops=2500.0):
+def class_summary(iters=8, peak_tflops=2500.0, strict=False):
     """Per kernel CLASS of one fuser-off UNet forward (every distinct conv / plain-GEMM / attention shape x its multiplicity): FLOPs,
     standalone op-level time (HIP events on the current stream, fp16 outputs) and the fraction of the dense-fp16 MFMA peak -- what
-    bench.py reports as ``roofline.classes``, measured in the run itself."""
+    bench.py reports as ``roofline.classes``, measured in the run itself.  ``strict``: the strict mode's operand forms ([hi | lo] activations,
+    [Whi | Wlo] weights, three MFMA passes, split attention); FLOPs stay the ALGORITHMIC ones, so ``frac`` is comparable with the default mode's
+    (the matrix pipe issues three times that work)."""
     init_device()
     gemms, convs, attns, _, _ = collect()
     h = lambda *s: torch.randn(*s, device=DEV).to(torch.float16)
@@ -114,7 +116,12 @@ def class_summary(iters=8, peak_tflops=2500.0):
         ho = side * 2 if up else side // stride
         o = torch.empty(B2 * ho * ho, cout, dtype=torch.float16, device=DEV)
         bias = torch.zeros(cout, device=DEV)
-        t_c += n * timeit(lambda: ops.conv3x3(x, w, o, B2, side, side, bias, stride=stride, upsample2x=bool(up)), iters)
+        if strict:
+            x, w = h(B2 * side * side, 2 * cin), h(cout, 18 * cin) * ((9 * cin) ** -0.5)
+            o = torch.empty(B2 * ho * ho, cout, dtype=torch.float32, device=DEV)
+            t_c += n * timeit(lambda: ops.conv3x3(x, w, o, B2, side, side, bias, stride=stride, upsample2x=bool(up), in_split=3, w_split=True), iters)
+        else:
+            t_c += n * timeit(lambda: ops.conv3x3(x, w, o, B2, side, side, bias, stride=stride, upsample2x=bool(up)), iters)
         fl_c += n * 2.0 * B2 * ho * ho * cout * 9 * cin
     fl_g = t_g = 0.0
     for key, n in gemms.items():
@@ -122,7 +129,18 @@ def class_summary(iters=8, peak_tflops=2500.0):
             continue                                    # fuser-only shapes
         M, N, K, epi = key[:4]
         a, w, bias = h(M, K), h(N, K) * (K ** -0.5), torch.zeros(N, device=DEV)
-        if epi == "geglu":
+        if strict:
+            a, w = h(M, 2 * K), h(N, 2 * K) * (K ** -0.5)
+            if epi == "geglu":
+                o = torch.empty(M, N, dtype=torch.float16, device=DEV)
+                fn = lambda: ops.gemm(a, w, o, bias, EPI_GEGLU, hilo_a=True, wsplit=2, hilo_out=True)
+            elif epi == "res":
+                o, r = torch.empty(M, N, dtype=torch.float32, device=DEV), torch.randn(M, N, device=DEV)
+                fn = lambda: ops.gemm(a, w, o, bias, EPI_RES, res=r, hilo_a=True, wsplit=2)
+            else:
+                o = torch.empty(M, 2 * N, dtype=torch.float16, device=DEV)
+                fn = lambda: ops.gemm(a, w, o, bias, hilo_a=True, wsplit=2, hilo_out=True)
+        elif epi == "geglu":
             o = torch.empty(M, N // 2, dtype=torch.float16, device=DEV)
             fn = lambda: ops.gemm(a, w, o, bias, EPI_GEGLU)
         elif epi == "res":
@@ -143,7 +161,12 @@ def class_summary(iters=8, peak_tflops=2500.0):
         vt = torch.empty(B2, H, d, ops.vt_ld(Nk), dtype=torch.float16, device=DEV)
         ops.transpose_v(v, Nk * C, C, vt, B2, H, d, Nk)
         o = torch.empty(B2, Nq, C, dtype=torch.float16, device=DEV)
-        t_a += n * timeit(lambda: ops.attention(q, Nq * C, C, k, Nk * C, C, vt, o, Nq * C, C, B2, H, d, Nq, Nk, d ** -0.5, q_prescaled=True), iters)
+        if strict:
+            ql, kl, vtl, ol = q * 1e-3, k * 1e-3, vt * 1e-3, torch.empty_like(o)
+            t_a += n * timeit(lambda: ops.attention(q, Nq * C, C, k, Nk * C, C, vt, o, Nq * C, C, B2, H, d, Nq, Nk, d ** -0.5, q_prescaled=True,
+                                                    q_lo=ql, k_lo=kl, vt_lo=vtl, out_lo=ol), iters)
+        else:
+            t_a += n * timeit(lambda: ops.attention(q, Nq * C, C, k, Nk * C, C, vt, o, Nq * C, C, B2, H, d, Nq, Nk, d ** -0.5, q_prescaled=True), iters)
         fl_a += n * 4.0 * B2 * H * Nq * Nk * d
     for name, fl, t in (("conv3x3", fl_c, t_c), ("plain_gemm", fl_g, t_g), ("attention", fl_a, t_a)):
         out[name] = {"tflop_per_forward": round(fl / 1e12, 3), "ms_per_forward": round(t * 1e3, 3), "achieved_tflops": round(fl / t / 1e12, 1),
