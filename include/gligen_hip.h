@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GL_ABI_VERSION 14
+#define GL_ABI_VERSION 15
 
 /* error codes (negative; positive values are hipError_t) */
 #define GL_ERR_BAD_ARG (-1)
@@ -93,6 +93,10 @@ typedef struct gl_gemm_args {
     int32_t ldw, kwrap;
     int32_t rowbias_f32;                /* != 0: rowbias is fp32 [B, N] (ld_rowbias in floats) instead of fp16: the ResBlock's emb_layers output is
                                            added to the conv result unrounded (openaimodel.py:220-226) */
+    /* ABI 15 (strict mode): with out_mode GL_OUT_F16_HILO the transposed tail takes BOTH halves -- vt receives fp16(v) and vt_lo (same layout)
+     * fp16(v - fp16(v)) of the V columns [vt_col0, N): the two V^T operands of the split-fp16 attention (gl_attn_args.vt / vt_lo) straight
+     * from the fused QKV projection's epilogue.  Required (non-NULL) exactly when vt != NULL and out_mode == GL_OUT_F16_HILO. */
+    void* vt_lo;
 } gl_gemm_args;
 
 /*

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GLIGEN_HIP_LIB: measurement hook -- the file name of an A/B build of the same library next to the product one
 # (csrc/build.py --variant); never a path outside this package, never a fallback: a missing file raises like the product library
 LIB_PATH = os.path.join(_HERE, os.path.basename(os.environ.get("GLIGEN_HIP_LIB", "") or "libgligen_hip.so"))
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 # enum gl_epilogue / gl_out_mode
 EPI_BIAS, EPI_SILU, EPI_GEGLU, EPI_RES, EPI_GATE_RES, EPI_ROWBIAS = range(6)
@@ -46,6 +46,7 @@ class GemmArgs(C.Structure):
         ("vt", vp), ("vt_col0", i32), ("vt_rows", i32), ("vt_d", i32), ("vt_ld", i32), ("vt_H", i32),
         ("ldw", i32), ("kwrap", i32),
         ("rowbias_f32", i32),
+        ("vt_lo", vp),
     ]
 
 

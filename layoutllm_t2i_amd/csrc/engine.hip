@@ -383,10 +383,12 @@ struct Run {
     void* ws;
     int launches = 0;
 
+    // the transposed V tail of a fused QKV projection (gl_gemm_args.vt ...; vt_lo with a [hi | lo] output)
+    struct VtTail { void* vt; void* vt_lo; int col0, rows, d, ld, H; };
     int gemm(const void* a, int lda, const std::string& w, int M, void* out, int ldc, int out_mode = GL_OUT_F16_ROWMAJOR,
              const std::string& bias = "", int epi = GL_EPI_BIAS, const void* res = nullptr, int ldres = 0, int res_f32 = 0,
              const float* gate = nullptr, void* out2 = nullptr, int ldc2 = 0, const void* a2 = nullptr, int lda2 = 0, int ksplit = 0,
-             bool hilo_a = false, bool wsplit = false) {
+             bool hilo_a = false, bool wsplit = false, const VtTail* tail = nullptr) {
         const WInfo* wi = e->wi(w);
         if (!wi) return GL_ERR_BAD_ARG;
         gl_gemm_args g{};
@@ -414,6 +416,9 @@ struct Run {
         g.epi = epi; g.out_mode = out_mode; g.out = out; g.ldc = ldc;
         g.res = res; g.ldres = ldres; g.res_f32 = res_f32; g.gate = gate;
         g.out2 = out2; g.ldc2 = ldc2;
+        if (tail) {
+            g.vt = tail->vt; g.vt_lo = tail->vt_lo; g.vt_col0 = tail->col0; g.vt_rows = tail->rows; g.vt_d = tail->d; g.vt_ld = tail->ld; g.vt_H = tail->H;
+        }
         g.workspace = ws; g.workspace_bytes = WS_BYTES;
         ++launches;
         return gl_gemm(&g, st);
@@ -569,11 +574,18 @@ int self_attention(Run& r, const half_t* src, int rows_per_b, int Nq, int Nk, in
         half_t* vtl = vt + (size_t)Bn * H * d * ldvt;
         half_t* att = e->h16(tag + ".att", (size_t)Bn * Nq * 2 * C);
         CKP(qkv); CKP(vt); CKP(att);
-        CK(r.gemm(src, 2 * C, wp + ".qkv.w", Bn * rows_per_b, qkv, 6 * C, GL_OUT_F16_HILO, "", GL_EPI_BIAS, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, 0, 0,
-                  true));
         const int64_t bs = (int64_t)rows_per_b * 6 * C;
-        CK(r.transpose_v(qkv + 2 * C, bs, 6 * C, vt, ldvt, Bn, H, d, Nk));
-        CK(r.transpose_v(qkv + 5 * C, bs, 6 * C, vtl, ldvt, Bn, H, d, Nk));
+        if (g_fuse_vt && (C % 32) == 0) {
+            // the V third leaves the projection's epilogue directly as the two V^T operands (hi, lo) of the split attention (ABI 15)
+            const Run::VtTail tail{vt, vtl, 2 * C, rows_per_b, d, ldvt, H};
+            CK(r.gemm(src, 2 * C, wp + ".qkv.w", Bn * rows_per_b, qkv, 6 * C, GL_OUT_F16_HILO, "", GL_EPI_BIAS, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, 0, 0,
+                      true, false, &tail));
+        } else {
+            CK(r.gemm(src, 2 * C, wp + ".qkv.w", Bn * rows_per_b, qkv, 6 * C, GL_OUT_F16_HILO, "", GL_EPI_BIAS, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, 0, 0,
+                      true));
+            CK(r.transpose_v(qkv + 2 * C, bs, 6 * C, vt, ldvt, Bn, H, d, Nk));
+            CK(r.transpose_v(qkv + 5 * C, bs, 6 * C, vtl, ldvt, Bn, H, d, Nk));
+        }
         CK(r.attn(qkv, bs, 6 * C, qkv + C, bs, 6 * C, vt, ldvt, att, (int64_t)Nq * 2 * C, 2 * C, Bn, H, d, Nq, Nk, qkv + 3 * C, qkv + 4 * C, vtl, att + C));
         *out = att;
         return 0;

@@ -595,17 +595,25 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
                     const int hh = nv / p.vt_d;
                     const int cc = nv - hh * p.vt_d;
                     const float bv = vt_bias[c0 / 64];
+                    half_t* vtl = reinterpret_cast<half_t*>(p.vt_lo);          // strict: the fp16 residual of V^T in the same layout (GL_OUT_F16_HILO)
 #pragma unroll
                     for (int tg = 0; tg < 4; ++tg) {
                         const int m = mbase + tg * 8;
                         if (m >= M) continue;
-                        half8_t o;
+                        half8_t o, l;
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) o[k] = (half_t)(stage[(tg * 8 + k) * EPS + col] + bv);
+                        for (int k = 0; k < 8; ++k) {
+                            float v = stage[(tg * 8 + k) * EPS + col] + bv;
+                            if (vtl) v = pin_value(v);                         // hi and lo from ONE value (common.h)
+                            o[k] = (half_t)v;
+                            l[k] = vtl ? (half_t)(v - (float)o[k]) : (half_t)0.0f;
+                        }
                         if ((p.vt_rows & 7) == 0) {
                             const int b = m / p.vt_rows;
                             const int key = m - b * p.vt_rows;
-                            st16(vtp + ((size_t)(b * p.vt_H + hh) * p.vt_d + cc) * p.vt_ld + key, *reinterpret_cast<uint4*>(&o));
+                            const size_t at = ((size_t)(b * p.vt_H + hh) * p.vt_d + cc) * p.vt_ld + key;
+                            st16(vtp + at, *reinterpret_cast<uint4*>(&o));
+                            if (vtl) st16(vtl + at, *reinterpret_cast<uint4*>(&l));
                         } else {
                             // ragged rows per sample (the fuser's N + 30 keys): 8 tokens may straddle two samples
 #pragma unroll
@@ -614,7 +622,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(gl_gemm_args p, ConvGeom 
                                 if (mm < M) {
                                     const int b = mm / p.vt_rows;
                                     const int key = mm - b * p.vt_rows;
-                                    vtp[((size_t)(b * p.vt_H + hh) * p.vt_d + cc) * p.vt_ld + key] = o[k];
+                                    const size_t at = ((size_t)(b * p.vt_H + hh) * p.vt_d + cc) * p.vt_ld + key;
+                                    vtp[at] = o[k];
+                                    if (vtl) vtl[at] = l[k];
                                 }
                             }
                         }

@@ -469,17 +469,25 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
                     const int cc = nv - hh * p.vt_d;
                     const float bv = bias ? bias[n] : 0.0f;
                     half_t* vtp = reinterpret_cast<half_t*>(p.vt);
+                    half_t* vtl = reinterpret_cast<half_t*>(p.vt_lo);          // strict: the fp16 residual of V^T in the same layout (GL_OUT_F16_HILO)
 #pragma unroll
                     for (int tg = 0; tg < 4; ++tg) {
                         const int m = mbase + tg * 8;
                         if (m >= M) continue;
-                        half8_t o;
+                        half8_t o, l;
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) o[k] = (half_t)(stage[(tg * 8 + k) * EPS + lane] + bv);
+                        for (int k = 0; k < 8; ++k) {
+                            float v = stage[(tg * 8 + k) * EPS + lane] + bv;
+                            if (vtl) v = pin_value(v);                         // hi and lo from ONE value (common.h)
+                            o[k] = (half_t)v;
+                            l[k] = vtl ? (half_t)(v - (float)o[k]) : (half_t)0.0f;
+                        }
                         if ((p.vt_rows & 7) == 0) {
                             const int b = m / p.vt_rows;
                             const int key = m - b * p.vt_rows;
-                            st16(vtp + ((size_t)(b * p.vt_H + hh) * p.vt_d + cc) * p.vt_ld + key, *reinterpret_cast<uint4*>(&o));
+                            const size_t at = ((size_t)(b * p.vt_H + hh) * p.vt_d + cc) * p.vt_ld + key;
+                            st16(vtp + at, *reinterpret_cast<uint4*>(&o));
+                            if (vtl) st16(vtl + at, *reinterpret_cast<uint4*>(&l));
                         } else {
                             // ragged rows per sample (the fuser's N + 30 keys): 8 tokens may straddle two samples
 #pragma unroll
@@ -488,7 +496,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
                                 if (mm < M) {
                                     const int b = mm / p.vt_rows;
                                     const int key = mm - b * p.vt_rows;
-                                    vtp[((size_t)(b * p.vt_H + hh) * p.vt_d + cc) * p.vt_ld + key] = o[k];
+                                    const size_t at = ((size_t)(b * p.vt_H + hh) * p.vt_d + cc) * p.vt_ld + key;
+                                    vtp[at] = o[k];
+                                    if (vtl) vtl[at] = l[k];
                                 }
                             }
                         }
@@ -767,7 +777,9 @@ template <bool CONV>
 int dispatch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K % 64) != 0) return GL_ERR_BAD_ARG;
     if (g.out_mode < 0 || g.out_mode > GL_OUT_F16_HILO) return GL_ERR_BAD_ARG;
-    if (g.out_mode == GL_OUT_F16_HILO && (g.vt != nullptr || g.ldc < (g.epi == GL_EPI_GEGLU ? g.N : 2 * g.N))) return GL_ERR_BAD_ARG;
+    if (g.out_mode == GL_OUT_F16_HILO && g.ldc < (g.epi == GL_EPI_GEGLU ? g.N : 2 * g.N)) return GL_ERR_BAD_ARG;
+    // the transposed tail of a [hi | lo] output takes both halves (vt_lo, ABI 15); a plain output has no residual to write
+    if ((g.vt != nullptr && (g.out_mode == GL_OUT_F16_HILO) != (g.vt_lo != nullptr)) || (g.vt == nullptr && g.vt_lo != nullptr)) return GL_ERR_BAD_ARG;
     if (g.out_mode != GL_OUT_F32_NCHW && ((g.N % 8) != 0 || (g.ldc % 8) != 0)) return GL_ERR_BAD_ARG;
     if (g.out_mode == GL_OUT_F32_ROWMAJOR && g.out2 != nullptr && (g.ldc2 % 8) != 0) return GL_ERR_BAD_ARG;
     if (g.out_mode == GL_OUT_F32_ROWMAJOR && g.epi == GL_EPI_GEGLU) return GL_ERR_UNSUPPORTED;
@@ -778,7 +790,7 @@ int dispatch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     if ((g.epi == GL_EPI_RES || g.epi == GL_EPI_GATE_RES) && g.res == nullptr) return GL_ERR_BAD_ARG;
     if (g.epi == GL_EPI_GATE_RES && g.gate == nullptr) return GL_ERR_BAD_ARG;
     if (g.epi == GL_EPI_ROWBIAS && (g.rowbias == nullptr || g.rows_per_sample <= 0)) return GL_ERR_BAD_ARG;
-    if (g.vt != nullptr && (g.epi != GL_EPI_BIAS || g.out_mode != GL_OUT_F16_ROWMAJOR || (g.vt_col0 % 64) != 0 || g.vt_col0 <= 0 ||
+    if (g.vt != nullptr && (g.epi != GL_EPI_BIAS || (g.out_mode != GL_OUT_F16_ROWMAJOR && g.out_mode != GL_OUT_F16_HILO) || (g.vt_col0 % 64) != 0 || g.vt_col0 <= 0 ||
                             g.vt_col0 >= g.N || g.vt_rows <= 0 || g.vt_d <= 0 || ((g.N - g.vt_col0) % g.vt_d) != 0 || (g.vt_ld % 8) != 0 ||
                             g.vt_ld < g.vt_rows || g.vt_H * g.vt_d != g.N - g.vt_col0))
         return GL_ERR_BAD_ARG;

@@ -115,7 +115,7 @@ def _fill_epilogue(g: GemmArgs, epi, out, N_out, bias, res, gate, rowbias, rows_
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias=None, epi: int = EPI_BIAS, res=None, gate=None,
          rowbias=None, rows_per_sample: int = 0, a2: Optional[torch.Tensor] = None, nchw_hw: int = 0, out16=None,
          vt: Optional[torch.Tensor] = None, vt_col0: int = 0, vt_rows: int = 0, hilo_a: bool = False, hilo_out: bool = False,
-         wsplit: int = 0) -> torch.Tensor:
+         wsplit: int = 0, vt_lo: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = [a | a2] @ w.T (+ epilogue).  a [M, K1], a2 [M, K2] (optional), w [N, K1+K2] fp16.
     ``hilo_a``: a is [M, 2K] = [hi | lo] of a split-fp16 activation and w [N, K] is used for both halves (gl_gemm_args.kwrap);
     ``hilo_out``: out is fp16 [M, 2N] = [hi | lo] of the result (GL_OUT_F16_HILO).
@@ -166,6 +166,11 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias=None, epi: in
             raise ValueError("vt must be a contiguous [B, H, d, ldvt] tensor")
         g.vt, g.vt_col0, g.vt_rows = vt.data_ptr(), vt_col0, vt_rows
         g.vt_H, g.vt_d, g.vt_ld = vt.shape[1], vt.shape[2], vt.shape[3]
+        if vt_lo is not None:              # ``hilo_out``: the fp16 residual of the V^T tail, same layout as ``vt`` (ABI 15)
+            _req(vt_lo, F16, "vt_lo")
+            if tuple(vt_lo.shape) != tuple(vt.shape) or not vt_lo.is_contiguous():
+                raise ValueError("vt_lo must have vt's shape")
+            g.vt_lo = vt_lo.data_ptr()
     check(_lib.lib().gl_gemm(C.byref(g), _stream()), "gl_gemm")
     return out
 

@@ -274,6 +274,48 @@ def test_conv3x3_split_nchw_out_conv():
 
 
 # ------------------------------------------------------------------------------------------- split attention
+@pytest.mark.parametrize("force8", [0, 2])
+@pytest.mark.parametrize("B,rows,C,d", [(2, 1024, 320, 40), (2, 286, 320, 40), (1, 64, 1280, 160), (3, 94, 640, 80)])
+def test_qkv_projection_writes_both_vt_halves(B, rows, C, d, force8):
+    """ABI 15: a [hi | lo] fused QKV projection (three-pass, GL_OUT_F16_HILO) with the transposed tail writes vt = fp16(v)^T and vt_lo =
+    fp16(v - fp16(v))^T for the V columns -- bit-equal to transposing the V thirds of the same projection's row-major [hi | lo] output
+    (whole and ragged rows per sample, 4-wave and 8-wave epilogues); the q | k columns are unchanged."""
+    H = C // d
+    M = B * rows
+    x = rnd(f"vx{M}{C}", (M, C)) * 1.3
+    w = rnd(f"vw{C}", (3 * C, C), 1 / math.sqrt(C))
+    b = rnd(f"vb{C}", (3 * C,), 0.1)
+    xh, xl = split(x)
+    whi, wlo = split(w)
+    a = torch.cat([xh, xl], 1).to(DEV)
+    w2 = torch.cat([whi, wlo], 1).contiguous().to(DEV)
+    ld = ops.vt_ld(rows)
+    ops.set_option(30, force8)
+    ops.set_option(5, 0)               # no split-K slices in the reference launch either (a launch with the transposed tail never splits K):
+    ops.set_option(31, 0)              # same fp32 summation order on both sides, so the comparison is bitwise
+    try:
+        ref = torch.empty(M, 6 * C, dtype=torch.float16, device=DEV)
+        ops.gemm(a, w2, ref, b.to(DEV), EPI_BIAS, hilo_a=True, wsplit=2, hilo_out=True)
+        out = torch.full((M, 6 * C), 7.0, dtype=torch.float16, device=DEV)
+        vt = torch.full((B, H, d, ld), 3.0, dtype=torch.float16, device=DEV)
+        vtl = torch.full((B, H, d, ld), 3.0, dtype=torch.float16, device=DEV)
+        ops.gemm(a, w2, out, b.to(DEV), EPI_BIAS, hilo_a=True, wsplit=2, hilo_out=True, vt=vt, vt_col0=2 * C, vt_rows=rows, vt_lo=vtl)
+    finally:
+        ops.set_option(30, 1)
+        ops.set_option(5, -1)
+        ops.set_option(31, 200)
+    r = ref.cpu()
+    o = out.cpu()
+    assert torch.equal(o[:, :2 * C], r[:, :2 * C]) and torch.equal(o[:, 3 * C:5 * C], r[:, 3 * C:5 * C])          # q | k, hi and lo
+    want_h = r[:, 2 * C:3 * C].view(B, rows, H, d).permute(0, 2, 3, 1)
+    want_l = r[:, 5 * C:6 * C].view(B, rows, H, d).permute(0, 2, 3, 1)
+    assert torch.equal(vt.cpu()[..., :rows], want_h) and torch.equal(vtl.cpu()[..., :rows], want_l)
+    # and a plain output must not be given a residual tail
+    with pytest.raises(Exception):
+        ops.gemm(xh.contiguous().to(DEV), whi.contiguous().to(DEV), torch.empty(M, 3 * C, dtype=torch.float16, device=DEV), b.to(DEV), EPI_BIAS, vt=vt,
+                 vt_col0=2 * C, vt_rows=rows, vt_lo=vtl)
+
+
 @pytest.mark.parametrize("d,H,Nq,Nk,B", [(40, 8, 256, 256, 2), (40, 8, 300, 286, 1), (80, 8, 128, 77, 2), (160, 8, 64, 94, 2), (160, 8, 256, 256, 1),
                                          (16, 4, 256, 286, 1), (64, 2, 130, 10, 1),
                                          # Nq >= 512 at d = 32 / 40 / 48: the software-pipelined kernel (round 6): whole tiles, ragged query and key

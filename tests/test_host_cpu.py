@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(l, name), f"{name} declared in gligen_hip.h but not exported"
     assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
-    assert l.gl_abi_version() == _lib.ABI_VERSION == 14
+    assert l.gl_abi_version() == _lib.ABI_VERSION == 15
     assert l.gl_sizeof_gemm_args() == ctypes.sizeof(_lib.GemmArgs)
     assert l.gl_sizeof_conv_args() == ctypes.sizeof(_lib.ConvArgs)
     assert l.gl_sizeof_attn_args() == ctypes.sizeof(_lib.AttnArgs)
