@@ -547,8 +547,9 @@ int gl_sizeof_gn_args(void);
  * rtol 1e-3 / atol 1e-4 of the fp32 reference for > 99 % of the elements (measured 0.1-0.2 % outside, rel-L2 < 1e-4, at 2-3x the
  * default mode's time).  The relation chain of rela_fuse (1/30 weight, 3e-6 of the result) and the fused first conv keep their forms.
  * key 51 = strict mode's third pass x.Wlo (1 default; 0 = activations split only: exact for fp16-representable weights except the
- * folded softmax scale of the q projections).  gl_set_conditioning reads keys 50 / 51 too (its strict hoists follow key 51): call it
- * again after changing key 51.
+ * folded softmax scale of the q projections).  The strict mode's conditioning hoists are computed lazily: by gl_set_conditioning when key 50
+ * is set at that time, else by the first strict forward after it (and again after key 51 changed) -- a split_weights handle that stays in
+ * default mode never runs them.
  * key 52 = three-pass split-fp16 products xhi.Whi + xlo.Whi + xhi.Wlo (gl_gemm with K = 3 * kwrap whose second source is the first one again;
  * gl_conv3x3 with in_split = 3) run the DEDICATED three-pass main loop of the 8-wave kernel (1 default; csrc/gemm8.hip S3: a ring stage holds
  * one 32-wide k slice of {xhi, xlo, Whi, Wlo} and feeds three MFMA groups, so no operand is staged twice); 0 = the K-walk over

@@ -92,6 +92,11 @@ class ClipTowers:
         self.use_graphs = True
         self._graphs: Dict[tuple, tuple] = {}
 
+    @staticmethod
+    def _tower_of(tag: str) -> str:
+        """graph keys "v" / "t" / "h" and pool tags "v.*" / "t.*": which tower a captured graph or a pooled buffer belongs to"""
+        return "v" if str(tag).startswith("v") else "t"
+
     def buf(self, tag, shape, dtype=F16):
         key = (tag, tuple(shape), dtype)
         t = self._pool.get(key)
@@ -138,10 +143,17 @@ class ClipTowers:
         buffer) and captures it on a side stream; later calls copy the input into the static buffer and replay."""
         g = self._graphs.get(key)
         if g is None:
-            if len(self._graphs) >= 16:                         # a host that keeps changing batch sizes: do not hoard graphs --
-                torch.cuda.synchronize(self.device)             # nor the pooled buffers they were captured on (keyed by shape, never reused
-                self._graphs.clear()                            # by another shape: without this the pool grows monotonically over a rollout)
-                self._pool.clear()
+            # a host that keeps changing batch sizes: do not hoard graphs, nor the pooled buffers they were captured on (keyed by shape, never
+            # reused by another shape: without this the pool grows monotonically over a rollout).  Eviction is per TOWER (key[0]: "v" vision,
+            # "t" / "h" text): a run of new text shapes must not throw away the vision tower's graph and buffers, and vice versa
+            mine = [k for k in self._graphs if self._tower_of(k[0]) == self._tower_of(key[0])]
+            if len(mine) >= 8:
+                torch.cuda.synchronize(self.device)
+                for k in mine:
+                    del self._graphs[k]
+                pre = self._tower_of(key[0]) + "."
+                for pk in [pk for pk in self._pool if str(pk[0]).startswith(pre)]:
+                    del self._pool[pk]
             buf = static_in.clone()
             fn(buf)                                             # warm-up: pool allocations, LDS attributes
             torch.cuda.synchronize(self.device)
@@ -202,7 +214,7 @@ class ClipTowers:
         return out
 
     def _bucket_ids(self, ids: torch.Tensor):
-        """Token rows [B, T] -> [B8, Tb] int32 on the device, B rounded up to a multiple of 8 and T up to 16 / 32 / the position
+        """Token rows [B, T] -> [B8, Tb] int32 on the device, B rounded up to a multiple of 8 and T up to 16 / 32 / 48 / 64 / the position
         table; a row is padded with ITS OWN largest id (the eos id for tokenizer output), pad rows repeat row 0: the conditioning path calls
         with B = the number of relation / grounding phrases and T = the longest phrase, both different on every call, and every
         new (B, T) would cost an eager warm-up, a synchronize, a capture and its own set of pooled buffers (~1.5 MB per row).
@@ -210,7 +222,7 @@ class ClipTowers:
         rows are dropped by the caller."""
         B, T = ids.shape
         tmax = min(int(self.tpos.shape[0]), 128)
-        Tb = next((t for t in (16, 32) if T <= t <= tmax), tmax)
+        Tb = next((t for t in (16, 32, 48, 64) if T <= t <= tmax), tmax)      # (48 / 64: a 33-token phrase no longer pays for the whole 77-row table)
         B8 = (B + 7) // 8 * 8
         if B8 == B and Tb == T:
             return ids.to(torch.int32).contiguous()

@@ -794,7 +794,11 @@ __global__ __launch_bounds__(512) void attn_split_pipe_kernel(gl_attn_args p) {
 #pragma unroll
         for (int i = 0; i < NT; ++i) vf[i] = *reinterpret_cast<const half8_t*>(Vsm + (i * 32 + ql) * VSTR2 + 16 * j + 8 * hi);
     };
-    constexpr int KG = 2;                               // K fragments per prefetch group (registers: two groups are in flight)
+    constexpr int KG = 2;                               // K fragments per prefetch group
+#ifndef ATTN_PIPE_KRING
+#define ATTN_PIPE_KRING 2
+#endif
+    constexpr int KRING = ATTN_PIPE_KRING;              // groups resident in registers (KRING - 1 ahead of the MFMAs)
     constexpr int NKG = (NKS + KG - 1) / KG;            // groups per 32-key half
     auto load_kf = [&](const half_t* Ksm, const int kh, const int g, half8_t (&kf)[KG]) __attribute__((always_inline)) {
 #pragma unroll
@@ -905,7 +909,9 @@ __global__ __launch_bounds__(512) void attn_split_pipe_kernel(gl_attn_args p) {
         __builtin_amdgcn_sched_barrier(0);
         // ---- segment A: P.V(t-1), fragments 0..3 (V fragments one step ahead) | probabilities of fragments 0, 1 of tile t
         // (a fragment of tile t replaces the fragment of tile t-1 IN PLACE right after the MFMAs that consumed it, in program order)
-        half8_t kfa[KG], kfb[KG];
+        constexpr int NG = 2 * NKG;                     // K fragment groups of the tile: keys 0-31 (NKG groups), then keys 32-63
+        half8_t kf[KRING][KG];                          // ring: group g sits in kf[g % KRING], KRING - 1 groups in flight ahead of the MFMAs
+        auto load_group = [&](const int g) __attribute__((always_inline)) { load_kf(Ksm, g / NKG, g % NKG, kf[g % KRING]); };
         if constexpr (has_prev) { pv_mfma(vf, pfh, pfl, 0); load_vf(Vsm, 1, vf); }
         prob_group(s, 0, pfh[0], pfl[0]);
         __builtin_amdgcn_sched_barrier(0);
@@ -913,31 +919,23 @@ __global__ __launch_bounds__(512) void attn_split_pipe_kernel(gl_attn_args p) {
         prob_group(s, 1, pfh[1], pfl[1]);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (has_prev) { pv_mfma(vf, pfh, pfl, 2); load_vf(Vsm, 3, vf); }
-        if constexpr (has_next) load_kf(Ksm, 0, 0, kfa);
+        if constexpr (has_next) load_group(0);
         prob_group(s, 2, pfh[2], pfl[2]);
         __builtin_amdgcn_sched_barrier(0);
-        // ---- segment B: last P.V fragment, then Q.K^T(t+1) keys 0-31 into s[0] | probabilities of fragment 3 (scores s[1])
+        // ---- segment B: last P.V fragment, then Q.K^T(t+1): keys 0-31 into s[0], keys 32-63 into s[1] | probabilities of fragment 3, row sum
         if constexpr (has_prev) pv_mfma(vf, pfh, pfl, 3);
         if constexpr (has_next) {
 #pragma unroll
-            for (int g = 0; g < NKG; ++g) {
-                // next group (or the first group of the other half) in flight under this group's MFMAs
-                if (g + 1 < NKG) load_kf(Ksm, 0, g + 1, (g & 1) ? kfa : kfb);
-                else load_kf(Ksm, 1, 0, (g & 1) ? kfa : kfb);
+            for (int g = 1; g < KRING - 1; ++g)
+                if (g < NG) load_group(g);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g + KRING - 1 < NG) load_group(g + KRING - 1);
+                const int kh = g / NKG, gi = g % NKG;
 #pragma unroll
                 for (int i = 0; i < KG; ++i)
-                    if (g * KG + i < NKS) s[0] = mfma32(((g & 1) ? kfb : kfa)[i], qcat[g * KG + i], (g | i) == 0 ? zero16 : s[0]);      // C = 0: inline constant
+                    if (gi * KG + i < NKS) s[kh] = mfma32(kf[g % KRING][i], qcat[gi * KG + i], (gi | i) == 0 ? zero16 : s[kh]);      // C = 0: inline constant
                 if (g == 0) prob_group(s, 3, pfh[3], pfl[3]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // ---- segment C: Q.K^T(t+1) keys 32-63 into s[1] | row sum
-#pragma unroll
-            for (int g = 0; g < NKG; ++g) {
-                constexpr int base = NKG & 1;           // buffer parity continues from segment B
-                if (g + 1 < NKG) load_kf(Ksm, 1, g + 1, ((g + base) & 1) ? kfa : kfb);
-#pragma unroll
-                for (int i = 0; i < KG; ++i)
-                    if (g * KG + i < NKS) s[1] = mfma32((((g + base) & 1) ? kfb : kfa)[i], qcat[g * KG + i], (g | i) == 0 ? zero16 : s[1]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {

@@ -115,6 +115,8 @@ __global__ void rela_rects_kernel(const float* __restrict__ boxes, const float* 
 }  // namespace
 
 struct gl_engine {
+    bool strict_hoists_ok = false;     // the strict-mode conditioning hoists match the current conditioning ...
+    int strict_hoists_w3 = -1;         // ... and were computed under this value of key 51
     gl_unet_config cfg;
     std::vector<BlockD> input_blocks, output_blocks;
     BlockD middle;
@@ -1098,6 +1100,66 @@ extern "C" int gl_load_weights(gl_engine* e, const void* packed, int64_t bytes, 
     return 0;
 }
 
+// Strict mode's hoists (handles created with split_weights): the conditioning tensors from split-fp16 operands all the way -- PositionNet on fp32
+// inputs split into [hi | lo], every Linear with [hi | lo] activations (+ the third pass x.Wlo, key 51), K / V of the text context as
+// [k v | k_lo v_lo] rows with V^T hi / lo, fuser.linear(objs) in fp32.  Computed LAZILY: gl_set_conditioning keeps device copies of
+// its inputs on such a handle and runs this only when option 50 is set at that time; otherwise the first strict forward does (outside any
+// capture), and again when key 51 changed since -- a split handle that stays in default mode never pays for the chain.
+int strict_hoists(gl_engine* e, hipStream_t st) {
+    const gl_unet_config& cfg = e->cfg;
+    const int Bn = e->Bn, Lc = e->Lc, mo = cfg.max_objs, ctx = cfg.context_dim, H = cfg.num_heads;
+    const int pin_dim = cfg.pos_in_dim + 8 * cfg.fourier_freqs;
+    const float* context = e->f32("cond.in.context", (size_t)Bn * Lc * ctx);
+    const float* boxes = e->f32("cond.in.boxes", (size_t)Bn * mo * 4);
+    const float* masks = e->f32("cond.in.masks", (size_t)Bn * mo);
+    const float* pos_emb = e->f32("cond.in.posemb", (size_t)Bn * mo * cfg.pos_in_dim);
+    CKP(context); CKP(boxes); CKP(masks); CKP(pos_emb);
+    Run r{e, st, e->buf("splitk.ws", WS_BYTES)};
+    CKP(r.ws);
+    gl_opts strict_opts = *(tl_gl_opts ? tl_gl_opts : &g_gl_opts);
+    strict_opts.v[50] = 1;
+    const gl_opts* prev_opts = tl_gl_opts;
+    tl_gl_opts = &strict_opts;                       // Run::gemm decides the third pass from the strict keys
+    struct Restore { const gl_opts* p; ~Restore() { tl_gl_opts = p; } } restore{prev_opts};
+    const size_t rows = (size_t)Bn * mo;
+    float* pin32 = e->f32("pn.in32", rows * pin_dim);
+    half_t* pins = e->h16("pn.ins", rows * 2 * pin_dim);
+    half_t* h1s = e->h16("pn.h1s", rows * 2 * 512);
+    half_t* h2s = e->h16("pn.h2s", rows * 2 * 512);
+    half_t* objss = e->h16("pn.objss", rows * 2 * cfg.pos_out_dim);
+    half_t* ctxs = e->h16("cond.ctxs", (size_t)Bn * Lc * 2 * ctx);
+    CKP(pin32); CKP(pins); CKP(h1s); CKP(h2s); CKP(objss); CKP(ctxs);
+    CK(gl_posnet_input_f32(boxes, masks, pos_emb, e->Wf("position_net.null_pos"), e->Wf("position_net.null_xyxy"), Bn * mo, cfg.pos_in_dim,
+                           cfg.fourier_freqs, pin32, st));
+    CK(r.split(pin32, (int64_t)rows, pin_dim, pins));
+    auto lin = [&](const half_t* a, int k, const std::string& w, void* out, int ldc, int out_mode, int epi) {
+        return r.gemm(a, 2 * k, w + ".w", (int)rows, out, ldc, out_mode, w + ".b", epi, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, 0, 0, true);
+    };
+    CK(lin(pins, pin_dim, "position_net.linears.0", h1s, 2 * 512, GL_OUT_F16_HILO, GL_EPI_SILU));
+    CK(lin(h1s, 512, "position_net.linears.2", h2s, 2 * 512, GL_OUT_F16_HILO, GL_EPI_SILU));
+    CK(lin(h2s, 512, "position_net.linears.4", objss, 2 * cfg.pos_out_dim, GL_OUT_F16_HILO, GL_EPI_BIAS));
+    CK(r.split(context, (int64_t)Bn * Lc, ctx, ctxs));
+    for (size_t li = 0; li < e->st_layers.size(); ++li) {
+        const LayerD& l = e->st_layers[li];
+        const std::string t = l.prefix + ".transformer_blocks.0";
+        const std::string sl = std::to_string(li);
+        const int C = l.cin, d = l.d_head;
+        float* o32 = e->f32("hoist.objs32s." + sl, rows * C);
+        CKP(o32);
+        CK(lin(objss, cfg.pos_out_dim, t + ".fuser.linear", o32, C, GL_OUT_F32_ROWMAJOR, GL_EPI_BIAS));
+        half_t* kv = e->h16("hoist.kvctxs." + sl, (size_t)Bn * Lc * 4 * C);
+        const int ldc_ = vt_ld(Lc);
+        half_t* vt = e->h16("hoist.vtctxs." + sl, (size_t)2 * Bn * H * d * ldc_);
+        CKP(kv); CKP(vt);
+        CK(r.gemm(ctxs, 2 * ctx, t + ".attn2.kv.w", Bn * Lc, kv, 4 * C, GL_OUT_F16_HILO, "", GL_EPI_BIAS, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, 0, 0, true));
+        CK(r.transpose_v(kv + C, (int64_t)Lc * 4 * C, 4 * C, vt, ldc_, Bn, H, d, Lc));
+        CK(r.transpose_v(kv + 3 * C, (int64_t)Lc * 4 * C, 4 * C, vt + (size_t)Bn * H * d * ldc_, ldc_, Bn, H, d, Lc));
+    }
+    e->strict_hoists_ok = true;
+    e->strict_hoists_w3 = g_strict_w3;
+    return 0;
+}
+
 extern "C" int gl_set_conditioning(gl_engine* e, const float* context, const float* relations, const float* boxes, const float* masks,
                                    const float* pos_emb, int32_t Bn, int32_t Lc, int32_t R, int32_t hw, void* stream) {
     if (!e || !e->wbase || !context || !relations || !boxes || !masks || !pos_emb || Bn <= 0 || Lc <= 0 || R <= 0 || hw <= 0) return GL_ERR_BAD_ARG;
@@ -1154,50 +1216,20 @@ extern "C" int gl_set_conditioning(gl_engine* e, const float* context, const flo
         CK(r.gemm(rel16, ctx, t + ".rela_fuse.attn.kv.w", Bn * R, kvr, 2 * C));
         CK(r.transpose_v(kvr + C, (int64_t)R * 2 * C, 2 * C, vtr, ldr_, Bn, H, d, R));
     }
-    // --- strict mode's hoists (handles created with split_weights; computed with every conditioning so that option 50 can be switched per
-    //     step without a new gl_set_conditioning): the same tensors from split-fp16 operands all the way -- PositionNet on fp32 inputs
-    //     split into [hi | lo], every Linear with [hi | lo] activations (+ the third pass x.Wlo), K / V of the text context as
-    //     [k v | k_lo v_lo] rows with V^T hi / lo, fuser.linear(objs) in fp32
+    // --- strict mode's hoists: lazily (strict_hoists above).  A split_weights handle keeps the inputs they are computed from; they run now only
+    //     when the handle is in strict mode at this point, else with the first strict forward
+    e->strict_hoists_ok = false;
     if (cfg.split_weights) {
-        gl_opts strict_opts = *(tl_gl_opts ? tl_gl_opts : &g_gl_opts);
-        strict_opts.v[50] = 1;
-        const gl_opts* prev_opts = tl_gl_opts;
-        tl_gl_opts = &strict_opts;                       // Run::gemm decides the third pass from the strict keys
-        struct Restore { const gl_opts* p; ~Restore() { tl_gl_opts = p; } } restore{prev_opts};
-        const size_t rows = (size_t)Bn * mo;
-        float* pin32 = e->f32("pn.in32", rows * pin_dim);
-        half_t* pins = e->h16("pn.ins", rows * 2 * pin_dim);
-        half_t* h1s = e->h16("pn.h1s", rows * 2 * 512);
-        half_t* h2s = e->h16("pn.h2s", rows * 2 * 512);
-        half_t* objss = e->h16("pn.objss", rows * 2 * cfg.pos_out_dim);
-        half_t* ctxs = e->h16("cond.ctxs", (size_t)Bn * Lc * 2 * ctx);
-        CKP(pin32); CKP(pins); CKP(h1s); CKP(h2s); CKP(objss); CKP(ctxs);
-        CK(gl_posnet_input_f32(boxes, masks, pos_emb, e->Wf("position_net.null_pos"), e->Wf("position_net.null_xyxy"), Bn * mo, cfg.pos_in_dim,
-                               cfg.fourier_freqs, pin32, st));
-        CK(r.split(pin32, (int64_t)rows, pin_dim, pins));
-        auto lin = [&](const half_t* a, int k, const std::string& w, void* out, int ldc, int out_mode, int epi) {
-            return r.gemm(a, 2 * k, w + ".w", (int)rows, out, ldc, out_mode, w + ".b", epi, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, 0, 0, true);
-        };
-        CK(lin(pins, pin_dim, "position_net.linears.0", h1s, 2 * 512, GL_OUT_F16_HILO, GL_EPI_SILU));
-        CK(lin(h1s, 512, "position_net.linears.2", h2s, 2 * 512, GL_OUT_F16_HILO, GL_EPI_SILU));
-        CK(lin(h2s, 512, "position_net.linears.4", objss, 2 * cfg.pos_out_dim, GL_OUT_F16_HILO, GL_EPI_BIAS));
-        CK(r.split(context, (int64_t)Bn * Lc, ctx, ctxs));
-        for (size_t li = 0; li < e->st_layers.size(); ++li) {
-            const LayerD& l = e->st_layers[li];
-            const std::string t = l.prefix + ".transformer_blocks.0";
-            const std::string sl = std::to_string(li);
-            const int C = l.cin, d = l.d_head;
-            float* o32 = e->f32("hoist.objs32s." + sl, rows * C);
-            CKP(o32);
-            CK(lin(objss, cfg.pos_out_dim, t + ".fuser.linear", o32, C, GL_OUT_F32_ROWMAJOR, GL_EPI_BIAS));
-            half_t* kv = e->h16("hoist.kvctxs." + sl, (size_t)Bn * Lc * 4 * C);
-            const int ldc_ = vt_ld(Lc);
-            half_t* vt = e->h16("hoist.vtctxs." + sl, (size_t)2 * Bn * H * d * ldc_);
-            CKP(kv); CKP(vt);
-            CK(r.gemm(ctxs, 2 * ctx, t + ".attn2.kv.w", Bn * Lc, kv, 4 * C, GL_OUT_F16_HILO, "", GL_EPI_BIAS, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, 0, 0, true));
-            CK(r.transpose_v(kv + C, (int64_t)Lc * 4 * C, 4 * C, vt, ldc_, Bn, H, d, Lc));
-            CK(r.transpose_v(kv + 3 * C, (int64_t)Lc * 4 * C, 4 * C, vt + (size_t)Bn * H * d * ldc_, ldc_, Bn, H, d, Lc));
+        struct { const char* tag; const float* src; size_t n; } keep[] = {{"cond.in.context", context, (size_t)Bn * Lc * ctx},
+                                                                          {"cond.in.boxes", boxes, (size_t)Bn * mo * 4},
+                                                                          {"cond.in.masks", masks, (size_t)Bn * mo},
+                                                                          {"cond.in.posemb", pos_emb, (size_t)Bn * mo * cfg.pos_in_dim}};
+        for (auto& k : keep) {
+            float* dst = e->f32(k.tag, k.n);
+            CKP(dst);
+            if (hipMemcpyAsync(dst, k.src, k.n * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return GL_ERR_BAD_ARG;
         }
+        if (g_strict != 0) CK(strict_hoists(e, st));
     }
     // --- integer rectangles per transformer resolution (attention.py:321-346)
     {
@@ -1268,6 +1300,12 @@ extern "C" int gl_unet_forward(gl_engine* e, const float* x, const float* t_dev,
         GL_CHECK_LAUNCH();
     }
     CK(set_fuser_scale(e, fuser_scale, st));
+    if (g_strict != 0 && cfg.split_weights && (!e->strict_hoists_ok || e->strict_hoists_w3 != g_strict_w3)) {
+        // first strict forward since the conditioning was set (or since key 51 changed): the split-fp16 hoists, on the caller's stream, before any
+        // capture; their buffers are new to the pool the first time, which makes the captured graphs stale
+        CK(strict_hoists(e, st));
+        if (e->pool_changed) { e->drop_graphs(); e->pool_changed = false; }
+    }
     const bool fuser_on = fuser_scale != 0.0f || g_force_fuser != 0;
     if (e->opt_epoch != g_gl_option_epoch || e->ovr_epoch != e->ovr.epoch) {       // a tuning knob changed: the captured launch sequences may be stale
         e->drop_graphs();

@@ -632,14 +632,19 @@ def generate_batch_images_sharded(all_models, captions=None, labels=None, bboxes
                         raise ValueError("clip_model is a torch CLIPModel that only rank %d holds: pass hip_phrase_encoder(clip_model, device) "
                                          "built from the same weights on EVERY rank, or None on every rank to encode the grounding phrases "
                                          "with the checkpoint's text tower" % src)
-                    cached = getattr(clip_model, "_gligen_hip_phrase_encoder", None)
-                    if cached is None:
-                        cached = hip_phrase_encoder(clip_model, device)
+                    # cached on the object together with a fingerprint of what it was built from (target device, storage address and in-place
+                    # version counter of the first parameter): a CLIPModel that is fine-tuned, reloaded or moved afterwards gets a fresh
+                    # fp16 copy instead of silently encoding with the stale one
+                    p0 = next(iter(clip_model.parameters()), None) if hasattr(clip_model, "parameters") else None
+                    fp = (str(device), None if p0 is None else (p0.data_ptr(), int(getattr(p0, "_version", 0)), str(p0.device)))
+                    entry = getattr(clip_model, "_gligen_hip_phrase_encoder", None)
+                    if entry is None or entry[0] != fp:
+                        entry = (fp, hip_phrase_encoder(clip_model, device))
                         try:
-                            clip_model._gligen_hip_phrase_encoder = cached
-                        except Exception:      # noqa: BLE001  (objects without attribute storage: rebuilt per call)
+                            clip_model._gligen_hip_phrase_encoder = entry
+                        except AttributeError:      # objects without attribute storage (__slots__): rebuilt per call
                             pass
-                    clip_model = cached
+                    clip_model = entry[1]
                 box = [dict(tok=tokenize_conditioning(all_models, captions, labels, bboxes, clip_processor), seeds=seeds,
                             own_phrase_encoder=_is_hip_encoder(clip_model))]
             else:

@@ -104,7 +104,7 @@ def test_hip_towers_match_transformers_golden():
     px2 = T(z["pixel_values"]).flip(0) * 0.5
     ids2 = T(z["input_ids"]).flip(0)
     g_img, g_txt, g_img2, g_txt2 = img, txt, tw.get_image_features(px2), tw.get_text_features(ids2)
-    # (text rows are bucketed: batch rounded up to 8, length to 16 / 32 / the position table -- clip.ClipTowers._bucket_ids)
+    # (text rows are bucketed: batch rounded up to 8, length to 16 / 32 / 48 / 64 / the position table -- clip.ClipTowers._bucket_ids)
     assert ("v", px2.shape[0], px2.shape[-1]) in tw._graphs and ("t", 8, 16) in tw._graphs and len(tw._graphs) == 2
     tw.use_graphs = False
     assert torch.equal(tw.get_image_features(T(z["pixel_values"])), g_img) and torch.equal(tw.get_text_features(T(z["input_ids"])), g_txt)

@@ -250,7 +250,7 @@ def test_strict_mode_meets_north_star_tolerance_at_bench_batch():
     # the first conv keeps its [Whi | Whi | Wlo] packing and the q projections their folded softmax scale, whose residuals only the third
     # pass carries (measured 3.5e-4 / 9.7 % outside: first-conv weight rounding 2.9e-4 of it, profiles/r4_weight_rounding_attribution.txt)
     eng.set_option(51, 0)
-    eng.set_conditioning(two["context"], two["relations"], two["boxes"], two["masks"], two["positive_embeddings"], hw)     # the hoists follow key 51
+    eng.set_conditioning(two["context"], two["relations"], two["boxes"], two["masks"], two["positive_embeddings"], hw)     # (not needed any more: the strict hoists follow key 51 lazily)
     sd_r = {k_: (v.half().float() if v.dim() >= 2 else v) for k_, v in sd_cpu.items()}
     ref_r = oracle_one(sd_r, cfg, inp, k, True, 481, round_x=False, round_ctx=False)
     report("STRICT (2 passes: activations split), 2B=8 cond fuser on, fp16-ROUNDED oracle weights", eng.forward(x, 481.0, 1.0, False, 2)[k:k + 1], ref_r)

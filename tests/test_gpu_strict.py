@@ -416,6 +416,16 @@ def test_tiny_unet_strict_vs_oracle_and_default(fuser_scale, sd_conv):
     print(f"[tiny strict fuser={fuser_scale} sd_conv={sd_conv}] default rel_l2 {rel(b, ref):.2e} outside {outside(b) * 100:.1f} % | "
           f"strict (3 passes) rel_l2 {rel(s3, ref):.2e} outside {outside(s3) * 100:.2f} %")
     assert rel(s3, ref) < 5e-5 and outside(s3) < 0.01
+    # the strict conditioning hoists are computed lazily (first strict forward after a default-mode gl_set_conditioning, as above): conditioning
+    # set WHILE in strict mode, and key 51 changed with / without a new conditioning, must give the same bits
+    eng.set_conditioning(inp["context"], inp["relations"], inp["boxes"], inp["masks"], inp["positive_embeddings"], 16)
+    assert torch.equal(eng.forward(x, 481.0, fuser_scale, sd_conv, 1), s3), "hoists at conditioning time == lazy hoists"
+    eng.set_option(51, 0)
+    s2_lazy = eng.forward(x, 481.0, fuser_scale, sd_conv, 1).clone()
+    eng.set_conditioning(inp["context"], inp["relations"], inp["boxes"], inp["masks"], inp["positive_embeddings"], 16)
+    assert torch.equal(eng.forward(x, 481.0, fuser_scale, sd_conv, 1), s2_lazy), "key 51 changed: the hoists are recomputed without a new conditioning"
+    eng.set_option(51, 1)
+    assert torch.equal(eng.forward(x, 481.0, fuser_scale, sd_conv, 1), s3)
     eng.set_option(50, 0)
     b2 = eng.forward(x, 481.0, fuser_scale, sd_conv, 1).clone()
     assert torch.equal(b2, b), "switching strict off restores the default results"
