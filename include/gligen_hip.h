@@ -95,7 +95,8 @@ typedef struct gl_gemm_args {
                                            added to the conv result unrounded (openaimodel.py:220-226) */
     /* ABI 15 (strict mode): with out_mode GL_OUT_F16_HILO the transposed tail takes BOTH halves -- vt receives fp16(v) and vt_lo (same layout)
      * fp16(v - fp16(v)) of the V columns [vt_col0, N): the two V^T operands of the split-fp16 attention (gl_attn_args.vt / vt_lo) straight
-     * from the fused QKV projection's epilogue.  Required (non-NULL) exactly when vt != NULL and out_mode == GL_OUT_F16_HILO. */
+     * from the fused QKV projection's epilogue.  Required (non-NULL) exactly when vt != NULL and out_mode == GL_OUT_F16_HILO.  Implemented by the 8-wave
+     * kernel's epilogue only: GL_ERR_UNSUPPORTED for launches it does not take (M < 256, K % 64, a tail that does not start on a wave's column range). */
     void* vt_lo;
 } gl_gemm_args;
 

@@ -577,12 +577,17 @@ int self_attention(Run& r, const half_t* src, int rows_per_b, int Nq, int Nk, in
         half_t* att = e->h16(tag + ".att", (size_t)Bn * Nq * 2 * C);
         CKP(qkv); CKP(vt); CKP(att);
         const int64_t bs = (int64_t)rows_per_b * 6 * C;
-        if (g_fuse_vt && (C % 32) == 0) {
-            // the V third leaves the projection's epilogue directly as the two V^T operands (hi, lo) of the split attention (ABI 15)
+        int rc = GL_ERR_UNSUPPORTED;
+        if (g_fuse_vt && (C % 64) == 0 && Bn * rows_per_b >= 256) {
+            // the V third leaves the projection's epilogue directly as the two V^T operands (hi, lo) of the split attention (ABI 15); only the
+            // 8-wave kernel implements that tail (GL_ERR_UNSUPPORTED otherwise: the transposes below)
             const Run::VtTail tail{vt, vtl, 2 * C, rows_per_b, d, ldvt, H};
-            CK(r.gemm(src, 2 * C, wp + ".qkv.w", Bn * rows_per_b, qkv, 6 * C, GL_OUT_F16_HILO, "", GL_EPI_BIAS, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, 0, 0,
-                      true, false, &tail));
-        } else {
+            rc = r.gemm(src, 2 * C, wp + ".qkv.w", Bn * rows_per_b, qkv, 6 * C, GL_OUT_F16_HILO, "", GL_EPI_BIAS, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, 0, 0,
+                        true, false, &tail);
+            if (rc != 0 && rc != GL_ERR_UNSUPPORTED) return rc;
+            if (rc != 0) --r.launches;
+        }
+        if (rc != 0) {
             CK(r.gemm(src, 2 * C, wp + ".qkv.w", Bn * rows_per_b, qkv, 6 * C, GL_OUT_F16_HILO, "", GL_EPI_BIAS, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, 0, 0,
                       true));
             CK(r.transpose_v(qkv + 2 * C, bs, 6 * C, vt, ldvt, Bn, H, d, Nk));

@@ -469,25 +469,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
                     const int cc = nv - hh * p.vt_d;
                     const float bv = bias ? bias[n] : 0.0f;
                     half_t* vtp = reinterpret_cast<half_t*>(p.vt);
-                    half_t* vtl = reinterpret_cast<half_t*>(p.vt_lo);          // strict: the fp16 residual of V^T in the same layout (GL_OUT_F16_HILO)
 #pragma unroll
                     for (int tg = 0; tg < 4; ++tg) {
                         const int m = mbase + tg * 8;
                         if (m >= M) continue;
-                        half8_t o, l;
+                        half8_t o;
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) {
-                            float v = stage[(tg * 8 + k) * EPS + lane] + bv;
-                            if (vtl) v = pin_value(v);                         // hi and lo from ONE value (common.h)
-                            o[k] = (half_t)v;
-                            l[k] = vtl ? (half_t)(v - (float)o[k]) : (half_t)0.0f;
-                        }
+                        for (int k = 0; k < 8; ++k) o[k] = (half_t)(stage[(tg * 8 + k) * EPS + lane] + bv);
                         if ((p.vt_rows & 7) == 0) {
                             const int b = m / p.vt_rows;
                             const int key = m - b * p.vt_rows;
-                            const size_t at = ((size_t)(b * p.vt_H + hh) * p.vt_d + cc) * p.vt_ld + key;
-                            st16(vtp + at, *reinterpret_cast<uint4*>(&o));
-                            if (vtl) st16(vtl + at, *reinterpret_cast<uint4*>(&l));
+                            st16(vtp + ((size_t)(b * p.vt_H + hh) * p.vt_d + cc) * p.vt_ld + key, *reinterpret_cast<uint4*>(&o));
                         } else {
                             // ragged rows per sample (the fuser's N + 30 keys): 8 tokens may straddle two samples
 #pragma unroll
@@ -496,9 +488,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (min_waves<BM, BN, BKT
                                 if (mm < M) {
                                     const int b = mm / p.vt_rows;
                                     const int key = mm - b * p.vt_rows;
-                                    const size_t at = ((size_t)(b * p.vt_H + hh) * p.vt_d + cc) * p.vt_ld + key;
-                                    vtp[at] = o[k];
-                                    if (vtl) vtl[at] = l[k];
+                                    vtp[((size_t)(b * p.vt_H + hh) * p.vt_d + cc) * p.vt_ld + key] = o[k];
                                 }
                             }
                         }
@@ -799,11 +789,18 @@ int dispatch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
     // one block's epilogue overlaps the others' main loops (measured 150 -> 135 us and 109 -> 100 us; long-K
     // GEMMs and convs lose 10-20 % to the doubled barrier count, so they stay on BK 64)
     if constexpr (!CONV) {
-        if (skinny_ok(g)) {
+        if (g.vt_lo == nullptr && skinny_ok(g)) {
             gemm_skinny_kernel<<<dim3(g.N / 32, gl_cdiv(g.M, 32)), dim3(256), 0, st>>>(g);
             GL_CHECK_LAUNCH();
             return 0;
         }
+    }
+    // the [hi | lo] transposed tail (vt_lo, ABI 15) is implemented by the 8-wave kernel's epilogue only: the 4-wave instantiations sit at their
+    // register caps (adding the second 8-token vector cost gemm_kernel<256,128,4,1,.,32> 576 bytes of scratch and the default mode 0.3 ms per forward)
+    const bool need8 = g.vt_lo != nullptr;
+    if (need8) {
+        int bn_ = 0;
+        if (!g_opt_g8 || !gl8_supported(g, CONV, &bn_)) return GL_ERR_UNSUPPORTED;
     }
     if (g_opt_g8) {
         int bn = 0;
@@ -864,7 +861,7 @@ int dispatch(const gl_gemm_args& g, const ConvGeom& cg, hipStream_t st) {
                 const bool full_rounds = g_opt_g8_shortk && blocks * 5 >= ((blocks + 255) / 256) * 256 * 4;
                 enough = nk >= 16 || blocks <= 256 || (g.epi == GL_EPI_GEGLU && (nk >= 10 || full_rounds)) || (full_rounds && blocks <= 2048);
             }
-            if (g_opt_g8 == 2 || enough) {
+            if (g_opt_g8 == 2 || enough || need8) {
                 // the three-pass product xhi.Whi + xlo.Whi + xhi.Wlo in its K-walk description (K = 3 * kwrap; GEMM: the third A segment is
                 // the first one again; conv: in_split == 3) -> the dedicated three-pass loop: same slices, counted in 32-wide stages of kwrap
                 const bool s3 = g_opt_g8_s3 != 0 && g.kwrap != 0 && g.K == 3 * g.kwrap &&

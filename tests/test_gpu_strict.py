@@ -274,12 +274,12 @@ def test_conv3x3_split_nchw_out_conv():
 
 
 # ------------------------------------------------------------------------------------------- split attention
-@pytest.mark.parametrize("force8", [0, 2])
-@pytest.mark.parametrize("B,rows,C,d", [(2, 1024, 320, 40), (2, 286, 320, 40), (1, 64, 1280, 160), (3, 94, 640, 80)])
-def test_qkv_projection_writes_both_vt_halves(B, rows, C, d, force8):
+@pytest.mark.parametrize("B,rows,C,d", [(2, 1024, 320, 40), (2, 286, 320, 40), (4, 64, 1280, 160), (3, 94, 640, 80), (1, 64, 1280, 160)])
+def test_qkv_projection_writes_both_vt_halves(B, rows, C, d):
     """ABI 15: a [hi | lo] fused QKV projection (three-pass, GL_OUT_F16_HILO) with the transposed tail writes vt = fp16(v)^T and vt_lo =
     fp16(v - fp16(v))^T for the V columns -- bit-equal to transposing the V thirds of the same projection's row-major [hi | lo] output
-    (whole and ragged rows per sample, 4-wave and 8-wave epilogues); the q | k columns are unchanged."""
+    (whole and ragged rows per sample); the q | k columns are unchanged.  Only the 8-wave kernel implements the tail: launches it cannot
+    take (fewer than 256 rows) are refused, not computed some other way."""
     H = C // d
     M = B * rows
     x = rnd(f"vx{M}{C}", (M, C)) * 1.3
@@ -290,15 +290,20 @@ def test_qkv_projection_writes_both_vt_halves(B, rows, C, d, force8):
     a = torch.cat([xh, xl], 1).to(DEV)
     w2 = torch.cat([whi, wlo], 1).contiguous().to(DEV)
     ld = ops.vt_ld(rows)
-    ops.set_option(30, force8)
+    vt = torch.full((B, H, d, ld), 3.0, dtype=torch.float16, device=DEV)
+    vtl = torch.full((B, H, d, ld), 3.0, dtype=torch.float16, device=DEV)
+    out = torch.full((M, 6 * C), 7.0, dtype=torch.float16, device=DEV)
+    if M < 256:
+        with pytest.raises(Exception):
+            ops.gemm(a, w2, out, b.to(DEV), EPI_BIAS, hilo_a=True, wsplit=2, hilo_out=True, vt=vt, vt_col0=2 * C, vt_rows=rows, vt_lo=vtl)
+        return
+    ops.set_option(30, 2)
     ops.set_option(5, 0)               # no split-K slices in the reference launch either (a launch with the transposed tail never splits K):
     ops.set_option(31, 0)              # same fp32 summation order on both sides, so the comparison is bitwise
     try:
         ref = torch.empty(M, 6 * C, dtype=torch.float16, device=DEV)
         ops.gemm(a, w2, ref, b.to(DEV), EPI_BIAS, hilo_a=True, wsplit=2, hilo_out=True)
-        out = torch.full((M, 6 * C), 7.0, dtype=torch.float16, device=DEV)
-        vt = torch.full((B, H, d, ld), 3.0, dtype=torch.float16, device=DEV)
-        vtl = torch.full((B, H, d, ld), 3.0, dtype=torch.float16, device=DEV)
+        ops.set_option(30, 1)          # the tail itself needs no forcing: the dispatcher sends it to the 8-wave kernel
         ops.gemm(a, w2, out, b.to(DEV), EPI_BIAS, hilo_a=True, wsplit=2, hilo_out=True, vt=vt, vt_col0=2 * C, vt_rows=rows, vt_lo=vtl)
     finally:
         ops.set_option(30, 1)

@@ -12,6 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_gpu_kernels as T  # noqa: E402
+import test_gpu_strict as S  # noqa: E402
+STRICT = bool(int(os.environ.get("FUZZ_STRICT", "0")))      # FUZZ_STRICT=1: only the strict-mode kernels (three-pass loop, split attention, [hi | lo] V^T tail)
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -27,7 +29,28 @@ def c64(lo, hi):
     return 64 * rng.randint(lo // 64, hi // 64)
 
 
+def strict_case():
+    """round 6: the three-pass main loop against the K-walk and fp64 (GEMM and conv), the split-fp16 attention kernels (round-5 kernel below 512
+    queries, the software-pipelined one from 512 on at d = 32 / 40 / 48), the [hi | lo] QKV projection's transposed tail"""
+    k = rng.choice(["gemm3", "gemm3", "conv3", "attn_s", "attn_s", "attn_pipe", "attn_pipe", "vt2"])
+    if k == "gemm3":
+        return S.test_gemm_three_pass_loop_vs_kwalk, (rng.randint(1, 6000), 32 * rng.randint(1, 60), c64(64, 2560), rng.choice(["res", "hilo"]))
+    if k == "conv3":
+        mode = rng.choice(["s1", "s1", "s2", "up"])
+        hw = rng.choice([12, 16, 20, 24, 32]) if mode != "s2" else rng.choice([24, 32, 40])
+        return S.test_conv_three_pass_loop_vs_kwalk, (mode, c64(64, 1280), 32 * rng.randint(1, 24), hw, rng.choice([2, 3, 4]))
+    if k == "attn_s":
+        d = rng.choice([8, 16, 24, 32, 40, 48, 64, 80, 128, 160])
+        return S.test_split_attention, (d, rng.choice([1, 2, 4]), rng.randint(2, 500), rng.randint(1, 900), rng.choice([1, 2]))
+    if k == "attn_pipe":
+        return S.test_split_attention, (rng.choice([32, 40, 48]), rng.choice([1, 2, 4]), rng.randint(512, 2200), rng.randint(1, 2300), 1)
+    H, d = rng.choice([(8, 40), (8, 80), (4, 48), (8, 24), (8, 160), (2, 32)])
+    return S.test_qkv_projection_writes_both_vt_halves, (rng.choice([1, 2, 3]), rng.randint(8, 900), H * d, d)
+
+
 def case():
+    if STRICT:
+        return strict_case()
     k = rng.choice(["gemm", "gemm", "skinny", "res32", "conv", "attn", "attn_pre", "gn", "gn1", "gn32", "hilo_a", "hilo_out", "ln", "ff", "qkv", "merge_ln"])
     if k == "gemm":
         return T.test_gemm_bias, (rng.randint(1, 3000), 8 * rng.randint(1, 200), c64(64, 1536))
