@@ -235,6 +235,18 @@ def test_strict_mode_meets_north_star_tolerance_at_bench_batch():
         out = eng.forward(x, t, fs, sdc, 2)
         worst = max(worst, report(f"STRICT (3 passes), 2B=8 {name}, fp32 reference weights", out[row:row + 1], ref, 0.001))
     assert worst < 3e-5, worst
+    # round 6: the same forward on the round-5 kernel forms (K-walk three-pass products, key 52 = 0; attn_split_kernel, key 53 = 2): same products,
+    # other fp32 summation order -- the two builds of the strict forward must agree far inside the tolerance, and both with the oracle
+    name, ref, row, t, fs, sdc = refs[0]
+    new_forms = eng.forward(x, t, fs, sdc, 2).clone()
+    eng.set_option(52, 0)
+    eng.set_option(53, 2)
+    old_forms = eng.forward(x, t, fs, sdc, 2).clone()
+    eng.set_option(52, 1)
+    eng.set_option(53, 0)
+    d_forms = rel_l2(new_forms, old_forms.cpu())
+    print(f"[strict] round-6 kernel forms vs round-5 forms, whole 2B=8 forward: rel_l2 {d_forms:.2e}; round-5 forms vs oracle {rel_l2(old_forms[row:row + 1], ref):.2e}")
+    assert d_forms < 1e-5 and rel_l2(old_forms[row:row + 1], ref) < 3e-5
     torch.cuda.synchronize()
     t0 = time.time()
     for _ in range(5):
