@@ -624,6 +624,15 @@ __global__ __launch_bounds__(64 * NW) void attn_split_kernel(gl_attn_args p) {
     }
 }
 
+// 16 zero bytes in global memory: what a masked lane of the LDS-DMA staging reads
+__device__ uint4 g_attn_zero16[4];
+
+__device__ __forceinline__ void glds16_attn(const char* src, char* dst) {
+    __builtin_amdgcn_global_load_lds(
+        reinterpret_cast<const __attribute__((address_space(1))) void*>(reinterpret_cast<uintptr_t>(src)),
+        reinterpret_cast<__attribute__((address_space(3))) void*>(reinterpret_cast<uintptr_t>(dst)), 16, 0, 0);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // attn_split_pipe_kernel<D8> (round 6): the split-fp16 attention of the level-0 head dims (d = 8 * D8 in {32, 40, 48}), restructured.
 // attn_split_kernel runs [Q.K^T MFMAs] [softmax VALU] [P.V MFMAs] back to back in every wave, and the two waves of a SIMD, locked to one
@@ -647,7 +656,10 @@ __global__ __launch_bounds__(512) void attn_split_pipe_kernel(gl_attn_args p) {
     constexpr int NTL = (D + 31) / 32;              // ... that hold vhi rows
     constexpr int KSTR = 2 * D + 8;                 // K row [khi | klo] + 16 bytes: (KSTR / 2) / 4 is odd -> conflict-free 16-byte fragment reads
     constexpr int VROWS = NT * 32;
-    constexpr int KBUF = KT * KSTR, VBUF = VROWS * VSTR2;
+    constexpr int VCH = VSTR2 / 8;                  // 16-byte chunks per staged V^T row (8 of keys + 1 of padding)
+    constexpr int KCH = KSTR / 8;                   // ... per staged K row (2 D8 of [khi | klo] + 1 of padding)
+    constexpr int NV_I = (2 * D * VCH + 63) / 64;   // LDS-DMA wave instructions (64 x 16 bytes) per V^T tile; a K tile takes exactly KCH
+    constexpr int KBUF = KT * KSTR, VBUF = (VROWS * VCH > NV_I * 64 ? VROWS * VCH : NV_I * 64) * 8;
     constexpr int NTHR = 512;
     static_assert(D8 >= 4 && D8 <= 6 && ((KSTR / 2) / 4) % 2 == 1, "head dims 32 / 40 / 48");
     __shared__ __attribute__((aligned(16))) half_t sK[2][KBUF];
@@ -710,94 +722,92 @@ __global__ __launch_bounds__(512) void attn_split_pipe_kernel(gl_attn_args p) {
     const float c_scale = p.q_prescaled ? 1.0f : p.scale * 1.4426950408889634f;
 
     // ---- staging (global -> registers -> LDS): K rows [khi | klo], stacked V^T rows with the key order of the P fragments (attn_kernel)
-    // Staging: 4 D8 wave-level loads of 64 x 16 bytes per tile -- [khi | klo | vhi | vlo] x D8 -- dealt round-robin to the 8 waves, so that
-    // the KIND of a wave's load i (which source array, which tile) is wave-uniform: scalar base pointers and branches, one per-lane byte
-    // offset (loop-invariant) per load.  Chunk x = 64 (L % D8) + lane of a kind: K row x / D8, column chunk x % D8; V^T row x / 8, key chunk x % 8.
-    constexpr int NLOAD = 4 * D8;
-    constexpr int KV_PER_T = (NLOAD + 7) / 8;
-    uint4 rkv[KV_PER_T];
-    // per-thread, loop-invariant: byte offset inside the source array at key0 = 0 and destination (halves) inside sK[slot] / sV[slot].  Kept in
-    // LDS, not in registers: the main loop runs at the 256-register limit of two waves per SIMD, and a compiler spill of these would come back
-    // through scratch loads whose s_waitcnt vmcnt(0) also drains the K / V prefetch just issued
-    __shared__ unsigned sGoff[KV_PER_T][NTHR];
-    __shared__ int sSoff[KV_PER_T][NTHR];
+    // Staging by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes land at consecutive LDS addresses, so the LDS image is produced by choosing
+    // each lane's SOURCE address): no staging registers, no ds_write, nothing to wait for before the stores -- the loop runs at the 256-register
+    // limit and the 15 registers this frees pay for a deeper K-fragment ring.  A K tile is 64 rows x KCH chunks = KCH wave instructions, a stacked
+    // V^T tile 2 D rows x VCH chunks = NV_I; the KCH + NV_I instructions of a tile are dealt round-robin to the 8 waves (the KIND of a wave's
+    // instruction i is wave-uniform).  Per lane and instruction one loop-invariant byte offset from the kind's hi array at key0 = 0 (the lo arrays
+    // are reached through their distance from the hi ones: the launcher checks that it fits); ZPAGE = the lane reads 16 zero bytes instead (pad
+    // rows of the V^T image; K rows at or past Nk; pad chunks read a valid neighbour).
+    constexpr int NI = KCH + NV_I, DPW = (NI + 7) / 8;
+    constexpr unsigned ZPAGE = 0xFFFFFFFFu;
+    const char* zpage = reinterpret_cast<const char*>(g_attn_zero16);
+    // (offsets are taken from the LOWER of the hi / lo arrays, so they are non-negative whichever way round the caller allocated them)
+    const char* kmin = reinterpret_cast<const char*>(Kg[0] < Kg[1] ? Kg[0] : Kg[1]);
+    const char* vmin = reinterpret_cast<const char*>(Vg[0] < Vg[1] ? Vg[0] : Vg[1]);
+    const unsigned kd[2] = {(unsigned)(reinterpret_cast<const char*>(Kg[0]) - kmin), (unsigned)(reinterpret_cast<const char*>(Kg[1]) - kmin)};
+    const unsigned vd[2] = {(unsigned)(reinterpret_cast<const char*>(Vg[0]) - vmin), (unsigned)(reinterpret_cast<const char*>(Vg[1]) - vmin)};
+    unsigned doff[DPW];
 #pragma unroll
-    for (int i = 0; i < KV_PER_T; ++i) {
-        const int L = wave + 8 * i;                     // wave-uniform
-        const int kind = L / D8;                        // 0 khi, 1 klo, 2 vhi, 3 vlo (>= 4: nothing)
-        const int x = 64 * (L - kind * D8) + lane;
-        if (kind < 2) {
-            const int row = x / D8, c = x - row * D8;
-            sGoff[i][tid] = (unsigned)(row * p.ldk + c * 8) * 2u;
-            sSoff[i][tid] = row * KSTR + kind * D + c * 8;
+    for (int i = 0; i < DPW; ++i) {
+        const int I = wave + 8 * i;                     // wave-uniform
+        if (I < KCH) {
+            const int pch = 64 * I + lane, row = pch / KCH, c = pch - row * KCH;
+            doff[i] = (unsigned)(row * p.ldk * 2) + (c < D8 ? kd[0] + (unsigned)(c * 16) : (c < 2 * D8 ? kd[1] + (unsigned)((c - D8) * 16) : kd[0]));
         } else {
-            const int row = x >> 3, c = x & 7;
-            sGoff[i][tid] = (unsigned)(row * p.ldvt + c * 8) * 2u;
-            sSoff[i][tid] = ((kind - 2) * D + row) * VSTR2 + 16 * (c >> 1) + 4 * (c & 1);
+            const int pch = 64 * (I - KCH) + lane, row = pch / VCH, c = pch - row * VCH;
+            doff[i] = row >= 2 * D ? ZPAGE : (unsigned)((row >= D ? row - D : row) * p.ldvt * 2) + (row >= D ? vd[1] : vd[0]) + (c < 8 ? (unsigned)(c * 16) : 0u);
         }
     }
-    int soff[KV_PER_T];
-    auto load_kv = [&](const int key0_k, const bool do_k, const int key0_v, const bool do_v) __attribute__((always_inline)) {
-        // wave-uniform fast path: both tiles lie inside [0, Nk) -> no per-key masking (every tile but the last one or two)
-        const bool full = (!do_k || key0_k + KT <= Nk) && (!do_v || key0_v + KT <= Nk);
+    auto stage_dma = [&](const int key0_k, const bool do_k, const int kslot, const int key0_v, const bool do_v, const int vslot) __attribute__((always_inline)) {
+        const bool full_k = key0_k + KT <= Nk;
 #pragma unroll
-        for (int i = 0; i < KV_PER_T; ++i) {
-            const int L = __builtin_amdgcn_readfirstlane(wave) + 8 * i;
-            const int kind = L / D8;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (kind < 2) {
+        for (int i = 0; i < DPW; ++i) {
+            const int I = __builtin_amdgcn_readfirstlane(wave) + 8 * i;
+            if (I < KCH) {
                 if (do_k) {
-                    const char* base = reinterpret_cast<const char*>(kind == 0 ? Kg[0] : Kg[1]) + (size_t)key0_k * p.ldk * 2;
-                    if (full || key0_k + (64 * (L - kind * D8) + lane) / D8 < Nk) v = ld16(base + sGoff[i][tid]);
+                    const char* src = kmin + (size_t)key0_k * p.ldk * 2 + doff[i];
+                    if (!full_k && key0_k + (64 * I + lane) / KCH >= Nk) src = zpage;
+                    glds16_attn(src, reinterpret_cast<char*>(&sK[kslot][0]) + I * 1024);
                 }
-            } else if (kind < 4) {
+            } else if (I < NI) {
                 if (do_v) {
-                    const char* base = reinterpret_cast<const char*>(kind == 2 ? Vg[0] : Vg[1]) + (size_t)key0_v * 2;
-                    v = ld16(base + sGoff[i][tid]);
-                    if (!full) {
-                        const int kfirst = key0_v + (lane & 7) * 8;
-                        if (kfirst + 8 > Nk) {          // pad keys: their V^T columns may hold anything (NaN included)
-                            const int keep = Nk - kfirst;
-                            unsigned w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                if (2 * q >= keep) w[q] = 0u;
-                                else if (2 * q + 1 >= keep) w[q] &= 0xFFFFu;
-                            }
-                            v = make_uint4(w[0], w[1], w[2], w[3]);
-                        }
-                    }
+                    const char* src = doff[i] == ZPAGE ? zpage : vmin + (size_t)key0_v * 2 + doff[i];
+                    glds16_attn(src, reinterpret_cast<char*>(&sV[vslot][0]) + (I - KCH) * 1024);
                 }
             }
-            rkv[i] = v;
-            soff[i] = sSoff[i][tid];
         }
     };
-    auto store_kv = [&](const int kslot, const bool do_k, const int vslot, const bool do_v) __attribute__((always_inline)) {
+    // the LAST key tile's V^T (key columns past Nk may hold anything, NaN included, and a 16-byte chunk may straddle Nk) goes through registers with
+    // the per-key masking of attn_kernel, into the same contiguous-key image; once per block, synchronous
+    auto stage_v_masked = [&](const int key0_v, const int vslot) __attribute__((always_inline)) {
+        for (int idx = tid; idx < 2 * D * 8; idx += NTHR) {
+            const int row = idx >> 3, c = idx & 7;
+            const half_t* src = (row >= D ? Vg[1] + (size_t)(row - D) * p.ldvt : Vg[0] + (size_t)row * p.ldvt) + key0_v + c * 8;
+            uint4 v = ld16(src);
+            const int kfirst = key0_v + c * 8;
+            if (kfirst + 8 > Nk) {
+                const int keep = Nk - kfirst;
+                unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int i = 0; i < KV_PER_T; ++i) {
-            const int L = __builtin_amdgcn_readfirstlane(wave) + 8 * i;
-            const int kind = L / D8;
-            if (kind < 2) {
-                if (do_k) st16(&sK[kslot][soff[i]], rkv[i]);
-            } else if (kind < 4) {
-                if (do_v) {
-                    uint2* dst = reinterpret_cast<uint2*>(&sV[vslot][soff[i]]);
-                    dst[0] = make_uint2(rkv[i].x, rkv[i].y);
-                    dst[2] = make_uint2(rkv[i].z, rkv[i].w);
+                for (int q = 0; q < 4; ++q) {
+                    if (2 * q >= keep) w[q] = 0u;
+                    else if (2 * q + 1 >= keep) w[q] &= 0xFFFFu;
                 }
+                v = make_uint4(w[0], w[1], w[2], w[3]);
             }
+            st16(&sV[vslot][row * VSTR2 + c * 8], v);
         }
     };
     // fragment loads (LDS -> registers); every consumer below prefetches one group ahead of its MFMAs
     auto load_vf = [&](const half_t* Vsm, const int j, half8_t (&vf)[NT]) __attribute__((always_inline)) {
+        // the P fragment of step j holds, per lane half hi, keys 16 j + 4 hi + [0, 4) and 16 j + 8 + 4 hi + [0, 4) (attn_kernel): two 8-byte reads
+        // of the contiguous-key row (the LDS-DMA image cannot carry attn_kernel's permuted key order)
 #pragma unroll
-        for (int i = 0; i < NT; ++i) vf[i] = *reinterpret_cast<const half8_t*>(Vsm + (i * 32 + ql) * VSTR2 + 16 * j + 8 * hi);
+        for (int i = 0; i < NT; ++i) {
+            const half_t* rp = Vsm + (i * 32 + ql) * VSTR2 + 16 * j + 4 * hi;
+            const uint2 a = *reinterpret_cast<const uint2*>(rp), b2 = *reinterpret_cast<const uint2*>(rp + 8);
+            const uint4 v = make_uint4(a.x, a.y, b2.x, b2.y);
+            vf[i] = *reinterpret_cast<const half8_t*>(&v);
+        }
     };
     constexpr int KG = 2;                               // K fragments per prefetch group
 #ifndef ATTN_PIPE_KRING
 #define ATTN_PIPE_KRING 2
 #endif
+#ifndef ATTN_PIPE_DBG
+#define ATTN_PIPE_DBG 0       // timing probes (results invalid): bit 0 = no staging stores / barrier in the loop, bit 1 = one K fragment group reused for all Q.K^T MFMAs,
+#endif                        // bit 2 = no staging global loads
     constexpr int KRING = ATTN_PIPE_KRING;              // groups resident in registers (KRING - 1 ahead of the MFMAs)
     constexpr int NKG = (NKS + KG - 1) / KG;            // groups per 32-key half
     auto load_kf = [&](const half_t* Ksm, const int kh, const int g, half8_t (&kf)[KG]) __attribute__((always_inline)) {
@@ -846,9 +856,9 @@ __global__ __launch_bounds__(512) void attn_split_pipe_kernel(gl_attn_args p) {
 
     const int ntiles = (Nk + KT - 1) / KT;
     // prologue: K(0), K(1) staged; scores of tile 0
-    load_kv(0, true, 0, false);
-    store_kv(0, true, 0, false);
-    if (ntiles > 1) { load_kv(KT, true, 0, false); store_kv(1, true, 0, false); }
+    stage_dma(0, true, 0, 0, false, 0);
+    if (ntiles > 1) stage_dma(KT, true, 1, 0, false, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     f32x16 s[2];                            // scores of the current tile; overwritten IN PLACE by the next tile's, half by half, as its probabilities are done
     f32x16 zero16;
@@ -880,7 +890,8 @@ __global__ __launch_bounds__(512) void attn_split_pipe_kernel(gl_attn_args p) {
         const half_t* Vsm = sV[(t + 1) & 1];            // V(t-1)
         half8_t vf[NT];                                 // ONE buffer: the next fragment's loads are issued right behind the MFMAs that read it
         if constexpr (has_prev) load_vf(Vsm, 0, vf);
-        load_kv(key0 + 2 * KT, more_k, key0, true);
+        // K(t+2) and V(t) straight into the slots last read one iteration ago (free since the barrier that ended it); landed before this iteration's barrier
+        if constexpr (!(ATTN_PIPE_DBG & 4)) stage_dma(key0 + 2 * KT, more_k, t & 1, key0, !tail, t & 1);
         if constexpr (tail) {
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh)
@@ -930,11 +941,13 @@ __global__ __launch_bounds__(512) void attn_split_pipe_kernel(gl_attn_args p) {
                 if (g < NG) load_group(g);
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
-                if (g + KRING - 1 < NG) load_group(g + KRING - 1);
+                if constexpr (!(ATTN_PIPE_DBG & 2)) {
+                    if (g + KRING - 1 < NG) load_group(g + KRING - 1);
+                }
                 const int kh = g / NKG, gi = g % NKG;
 #pragma unroll
                 for (int i = 0; i < KG; ++i)
-                    if (gi * KG + i < NKS) s[kh] = mfma32(kf[g % KRING][i], qcat[gi * KG + i], (gi | i) == 0 ? zero16 : s[kh]);      // C = 0: inline constant
+                    if (gi * KG + i < NKS) s[kh] = mfma32(kf[(ATTN_PIPE_DBG & 2) ? 0 : g % KRING][i], qcat[gi * KG + i], (gi | i) == 0 ? zero16 : s[kh]);      // C = 0: inline constant
                 if (g == 0) prob_group(s, 3, pfh[3], pfl[3]);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -949,8 +962,11 @@ __global__ __launch_bounds__(512) void attn_split_pipe_kernel(gl_attn_args p) {
                 for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
         }
         // ---- stage K(t+2) and V(t) into the slots last read one iteration ago; one barrier per tile
-        store_kv(t & 1, more_k, t & 1, true);
-        __syncthreads();
+        if constexpr (!(ATTN_PIPE_DBG & 1)) {
+            if constexpr (tail) stage_v_masked(key0, t & 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
     };
     {
         using T = std::true_type;
@@ -1006,7 +1022,13 @@ template <int DQK>
 int launch_attn_split(const gl_attn_args& a, hipStream_t st) {
     if constexpr (DQK == 32 || DQK == 48) {
         // level-0 head dims on long query ranges: the software-pipelined kernel (key 53 = 2: the round-5 kernel, A/B)
-        if (a.Nq >= 512 && g_attn_split_var == 0 && (a.d == 32 || a.d == 40 || a.d == 48)) {
+        // (its LDS-DMA staging reaches the lo arrays through 32-bit offsets from the lower of each hi / lo pair)
+        auto near32 = [](const void* x, const void* y, int64_t span) {
+            const int64_t dlt = reinterpret_cast<const char*>(x) - reinterpret_cast<const char*>(y);
+            return (dlt < 0 ? -dlt : dlt) + span < (int64_t)0xFFFF0000LL;
+        };
+        const bool reach = near32(a.k, a.k_lo, (int64_t)64 * a.ldk * 2 + 256) && near32(a.vt, a.vt_lo, (int64_t)a.d * a.ldvt * 2 + 256);
+        if (a.Nq >= 512 && g_attn_split_var == 0 && (a.d == 32 || a.d == 40 || a.d == 48) && reach) {
             const dim3 grid(gl_cdiv(a.Nq, 256) * a.H * a.B);
             if (a.d == 32) attn_split_pipe_kernel<4><<<grid, dim3(512), 0, st>>>(a);
             else if (a.d == 40) attn_split_pipe_kernel<5><<<grid, dim3(512), 0, st>>>(a);
