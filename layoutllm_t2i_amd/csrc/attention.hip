@@ -32,6 +32,17 @@ namespace {
 constexpr int KT = 64;          // keys per tile
 constexpr int VSTR2 = KT + 8;   // main kernel: 144 B rows = 9 x 16 B, conflict-free 16-byte fragment reads
 
+// build knobs of attn_split_pipe_kernel (A/B builds: csrc/build.py --variant)
+#ifndef ATTN_PIPE_KRING
+#define ATTN_PIPE_KRING 2
+#endif
+#ifndef ATTN_PIPE_SLOTS
+#define ATTN_PIPE_SLOTS 4     // LDS slots per operand: 4 = tiles staged one iteration further ahead, ONE BARRIER PER TWO TILES (the waves of a block may drift by a
+#endif                        // tile); 2 = one barrier per tile (A/B)
+#ifndef ATTN_PIPE_DBG
+#define ATTN_PIPE_DBG 0       // timing probes (results invalid): bit 0 = no staging stores / barrier in the loop, bit 1 = one K fragment group reused for all Q.K^T MFMAs,
+#endif                        // bit 2 = no staging global loads
+
 // PRE: the softmax scale AND log2(e) are already folded into Q (q_prescaled: the packer folds them into the q projection
 // weights), so the logits leave the MFMA in exp2 units.  The running max is then subtracted by the MFMA itself -- the
 // accumulator is initialised with -m instead of 0 -- and the common (no-rescale) path of the online softmax is ONE v_exp
@@ -662,8 +673,11 @@ __global__ __launch_bounds__(512) void attn_split_pipe_kernel(gl_attn_args p) {
     constexpr int KBUF = KT * KSTR, VBUF = (VROWS * VCH > NV_I * 64 ? VROWS * VCH : NV_I * 64) * 8;
     constexpr int NTHR = 512;
     static_assert(D8 >= 4 && D8 <= 6 && ((KSTR / 2) / 4) % 2 == 1, "head dims 32 / 40 / 48");
-    __shared__ __attribute__((aligned(16))) half_t sK[2][KBUF];
-    __shared__ __attribute__((aligned(16))) half_t sV[2][VBUF];
+    constexpr int NS = ATTN_PIPE_SLOTS;             // tile k of either operand lives in slot k % NS
+    static_assert(NS == 2 || NS == 4, "slots");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_pipe[];
+    half_t (*sK)[KBUF] = reinterpret_cast<half_t (*)[KBUF]>(smem_pipe);
+    half_t (*sV)[VBUF] = reinterpret_cast<half_t (*)[VBUF]>(smem_pipe + (size_t)NS * KBUF * sizeof(half_t));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ql = lane & 31, hi = lane >> 5;
     const int nqb = (p.Nq + 255) / 256;
@@ -684,7 +698,7 @@ __global__ __launch_bounds__(512) void attn_split_pipe_kernel(gl_attn_args p) {
     // rows [2 D, VROWS) of both V slots are never staged: zero them once (they meet P in the MFMAs: 0, not stale LDS bits)
     if constexpr (VROWS > 2 * D) {
         constexpr int ZW = (VROWS - 2 * D) * VSTR2 / 8;
-        for (int i = tid; i < 2 * ZW; i += NTHR) st16(&sV[i / ZW][2 * D * VSTR2 + 8 * (i % ZW)], make_uint4(0u, 0u, 0u, 0u));
+        for (int i = tid; i < NS * ZW; i += NTHR) st16(&sV[i / ZW][2 * D * VSTR2 + 8 * (i % ZW)], make_uint4(0u, 0u, 0u, 0u));
     }
 
     // The concatenated K dimension of Q.K^T, 16 columns (two 8-column chunks: lanes hi = 0 / 1) per MFMA step, paired so that the K-side
@@ -802,12 +816,6 @@ __global__ __launch_bounds__(512) void attn_split_pipe_kernel(gl_attn_args p) {
         }
     };
     constexpr int KG = 2;                               // K fragments per prefetch group
-#ifndef ATTN_PIPE_KRING
-#define ATTN_PIPE_KRING 2
-#endif
-#ifndef ATTN_PIPE_DBG
-#define ATTN_PIPE_DBG 0       // timing probes (results invalid): bit 0 = no staging stores / barrier in the loop, bit 1 = one K fragment group reused for all Q.K^T MFMAs,
-#endif                        // bit 2 = no staging global loads
     constexpr int KRING = ATTN_PIPE_KRING;              // groups resident in registers (KRING - 1 ahead of the MFMAs)
     constexpr int NKG = (NKS + KG - 1) / KG;            // groups per 32-key half
     auto load_kf = [&](const half_t* Ksm, const int kh, const int g, half8_t (&kf)[KG]) __attribute__((always_inline)) {
@@ -855,9 +863,15 @@ __global__ __launch_bounds__(512) void attn_split_pipe_kernel(gl_attn_args p) {
     };
 
     const int ntiles = (Nk + KT - 1) / KT;
-    // prologue: K(0), K(1) staged; scores of tile 0
-    stage_dma(0, true, 0, 0, false, 0);
-    if (ntiles > 1) stage_dma(KT, true, 1, 0, false, 0);
+    // Schedule (NS = 4): iteration t READS K(t+1) and V(t-1) and STAGES K(t+3) and V(t+1) -- first read in iteration t+2 -- into the slots of K(t-1) / V(t-3),
+    // last read in iteration t-2; a barrier (with vmcnt(0)) at the end of every ODD iteration and of the last one lies between every such write and its
+    // readers (RAW) and between every slot's last readers and its next writer (WAR).  NS = 2: K(t+2) / V(t) staged in iteration t, a barrier every iteration.
+    constexpr int AHEAD = NS == 4 ? 1 : 0;
+    // prologue: K(0) .. K(1 + AHEAD) (and V(0) when it is staged a tile ahead); scores of tile 0
+    stage_dma(0, true, 0, 0, AHEAD == 1 && KT <= Nk, 0);
+    if (ntiles > 1) stage_dma(KT, true, 1 % NS, 0, false, 0);
+    if (AHEAD == 1 && ntiles > 2) stage_dma(2 * KT, true, 2, 0, false, 0);
+    if (AHEAD == 1 && KT > Nk) stage_v_masked(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     f32x16 s[2];                            // scores of the current tile; overwritten IN PLACE by the next tile's, half by half, as its probabilities are done
@@ -875,6 +889,7 @@ __global__ __launch_bounds__(512) void attn_split_pipe_kernel(gl_attn_args p) {
                 if (g * KG + i < NKS) s[kh] = mfma32(kf[i], qcat[g * KG + i], (g | i) == 0 ? zero16 : s[kh]);
         }
     }
+    if constexpr (NS == 4) __syncthreads();  // every wave is done with K(0) before iteration 1 restages its slot (no barrier ends iteration 0)
     uint4 pfh[4], pfl[4];                   // P fragments: of tile t-1 while its P.V MFMAs run, replaced IN PLACE by tile t's, fragment by fragment
 #pragma unroll
     for (int j = 0; j < 4; ++j) { pfh[j] = make_uint4(0u, 0u, 0u, 0u); pfl[j] = make_uint4(0u, 0u, 0u, 0u); }
@@ -885,13 +900,16 @@ __global__ __launch_bounds__(512) void attn_split_pipe_kernel(gl_attn_args p) {
     auto body = [&](auto prev_c, auto next_c, auto tail_c, const int t) __attribute__((always_inline)) {
         constexpr bool has_prev = decltype(prev_c)::value, has_next = decltype(next_c)::value, tail = decltype(tail_c)::value;
         const int key0 = t * KT;
-        const bool more_k = t + 2 < ntiles;
-        const half_t* Ksm = sK[(t + 1) & 1];            // K(t+1)
-        const half_t* Vsm = sV[(t + 1) & 1];            // V(t-1)
+        const bool more_k = t + 2 + AHEAD < ntiles;
+        const half_t* Ksm = sK[(t + 1) % NS];           // K(t+1)
+        const half_t* Vsm = sV[(t + NS - 1) % NS];      // V(t-1)
         half8_t vf[NT];                                 // ONE buffer: the next fragment's loads are issued right behind the MFMAs that read it
         if constexpr (has_prev) load_vf(Vsm, 0, vf);
         // K(t+2) and V(t) straight into the slots last read one iteration ago (free since the barrier that ended it); landed before this iteration's barrier
-        if constexpr (!(ATTN_PIPE_DBG & 4)) stage_dma(key0 + 2 * KT, more_k, t & 1, key0, !tail, t & 1);
+        // the V^T tile staged here (t + AHEAD) goes by LDS-DMA unless it is the last, partial one (masked register path at the bottom)
+        const int tv = t + AHEAD;
+        const bool v_dma = tv < ntiles && (tv + 1) * KT <= Nk, v_masked = tv < ntiles && !v_dma;
+        if constexpr (!(ATTN_PIPE_DBG & 4)) stage_dma(key0 + (2 + AHEAD) * KT, more_k, (t + 2 + AHEAD) % NS, tv * KT, v_dma, tv % NS);
         if constexpr (tail) {
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh)
@@ -963,9 +981,11 @@ __global__ __launch_bounds__(512) void attn_split_pipe_kernel(gl_attn_args p) {
         }
         // ---- stage K(t+2) and V(t) into the slots last read one iteration ago; one barrier per tile
         if constexpr (!(ATTN_PIPE_DBG & 1)) {
-            if constexpr (tail) stage_v_masked(key0, t & 1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            if (v_masked) stage_v_masked(tv * KT, tv % NS);
+            if (NS == 2 || (t & 1) || t + 1 >= ntiles) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
         }
     };
     {
@@ -980,7 +1000,7 @@ __global__ __launch_bounds__(512) void attn_split_pipe_kernel(gl_attn_args p) {
     }
     // P.V of the last tile
     {
-        const half_t* Vsm = sV[(ntiles + 1) & 1];
+        const half_t* Vsm = sV[(ntiles - 1) % NS];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             half8_t vf[NT];
@@ -1013,6 +1033,12 @@ __global__ __launch_bounds__(512) void attn_split_pipe_kernel(gl_attn_args p) {
     }
 }
 
+template <int D8>
+constexpr int attn_pipe_lds() {          // attn_split_pipe_kernel: ATTN_PIPE_SLOTS x (K tile [64][2 d + 8] + stacked V^T tile, whole LDS-DMA instructions)
+    constexpr int D = 8 * D8, KB = KT * (2 * D + 8), VR = ((2 * D + 31) / 32) * 32, VCH = VSTR2 / 8, NVI = (2 * D * VCH + 63) / 64;
+    return ATTN_PIPE_SLOTS * (KB + (VR * VCH > NVI * 64 ? VR * VCH : NVI * 64) * 8) * (int)sizeof(half_t);
+}
+
 template <int DQK, bool DBUF>
 constexpr int attn_split_lds() { return (DBUF ? 2 : 1) * 2 * (KT * (DQK + 8) + ((DQK + 31) / 32) * 32 * VSTR2) * (int)sizeof(half_t); }
 
@@ -1030,9 +1056,9 @@ int launch_attn_split(const gl_attn_args& a, hipStream_t st) {
         const bool reach = near32(a.k, a.k_lo, (int64_t)64 * a.ldk * 2 + 256) && near32(a.vt, a.vt_lo, (int64_t)a.d * a.ldvt * 2 + 256);
         if (a.Nq >= 512 && g_attn_split_var == 0 && (a.d == 32 || a.d == 40 || a.d == 48) && reach) {
             const dim3 grid(gl_cdiv(a.Nq, 256) * a.H * a.B);
-            if (a.d == 32) attn_split_pipe_kernel<4><<<grid, dim3(512), 0, st>>>(a);
-            else if (a.d == 40) attn_split_pipe_kernel<5><<<grid, dim3(512), 0, st>>>(a);
-            else attn_split_pipe_kernel<6><<<grid, dim3(512), 0, st>>>(a);
+            if (a.d == 32) attn_split_pipe_kernel<4><<<grid, dim3(512), attn_pipe_lds<4>(), st>>>(a);
+            else if (a.d == 40) attn_split_pipe_kernel<5><<<grid, dim3(512), attn_pipe_lds<5>(), st>>>(a);
+            else attn_split_pipe_kernel<6><<<grid, dim3(512), attn_pipe_lds<6>(), st>>>(a);
             GL_CHECK_LAUNCH();
             return 0;
         }
@@ -1156,7 +1182,15 @@ extern "C" int gl_attention(const gl_attn_args* a, void* stream) {
     return launch_attn_auto<160>(*a, st);
 }
 
+template <int D8>
+static int set_attr_pipe() {
+    return hipFuncSetAttribute((const void*)attn_split_pipe_kernel<D8>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_pipe_lds<D8>()) == hipSuccess ? 0 : GL_ERR_UNSUPPORTED;
+}
+
 extern "C" int gl_init_attn(void) {
+    if (int e = set_attr_pipe<4>()) return e;
+    if (int e = set_attr_pipe<5>()) return e;
+    if (int e = set_attr_pipe<6>()) return e;
     // the split-fp16 kernels' dynamic LDS (above the 64 KB static limit for the double-buffered and the large-head-dim forms)
     int e;
     if ((e = set_attr_split<16>()) || (e = set_attr_split<32>()) || (e = set_attr_split<48>()) || (e = set_attr_split<64>()) || (e = set_attr_split<80>()) ||
