@@ -39,6 +39,9 @@ constexpr int VSTR2 = KT + 8;   // main kernel: 144 B rows = 9 x 16 B, conflict-
 #ifndef ATTN_PIPE_SLOTS
 #define ATTN_PIPE_SLOTS 4     // LDS slots per operand: 4 = tiles staged one iteration further ahead, ONE BARRIER PER TWO TILES (the waves of a block may drift by a
 #endif                        // tile); 2 = one barrier per tile (A/B)
+#ifndef ATTN_PIPE_PRIO
+#define ATTN_PIPE_PRIO 0      // 1 = static s_setprio 1 for the second-dispatched half of the block (waves 4-7), A/B
+#endif
 #ifndef ATTN_PIPE_DBG
 #define ATTN_PIPE_DBG 0       // timing probes (results invalid): bit 0 = no staging stores / barrier in the loop, bit 1 = one K fragment group reused for all Q.K^T MFMAs,
 #endif                        // bit 2 = no staging global loads
@@ -889,6 +892,7 @@ __global__ __launch_bounds__(512) void attn_split_pipe_kernel(gl_attn_args p) {
                 if (g * KG + i < NKS) s[kh] = mfma32(kf[i], qcat[g * KG + i], (g | i) == 0 ? zero16 : s[kh]);
         }
     }
+    if constexpr (ATTN_PIPE_PRIO == 1) { if (wave >= 4) __builtin_amdgcn_s_setprio(1); }
     if constexpr (NS == 4) __syncthreads();  // every wave is done with K(0) before iteration 1 restages its slot (no barrier ends iteration 0)
     uint4 pfh[4], pfl[4];                   // P fragments: of tile t-1 while its P.V MFMAs run, replaced IN PLACE by tile t's, fragment by fragment
 #pragma unroll
